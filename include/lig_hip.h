@@ -1,0 +1,134 @@
+/*
+ * lig_hip.h -- C ABI of the MI355X-native Ligero prover backend (liblig_hip.so).
+ *
+ * This is the drop-in boundary for the reference's GPU executor `ligero::webgpu_context`
+ * (include/wgpu.hpp:50-183, include/ligetron/webgpu/device_context.hpp:29-98).  In the reference the
+ * executor is a C++ template parameter (`using executor_t = webgpu_context`, src/webgpu_prover.cpp:54)
+ * passed into the stage contexts (include/zkp/nonbatch_context.hpp:68-80); `include/lig_hip_context.hpp`
+ * wraps this ABI in a class with the same member names so those drivers compile against it.
+ *
+ * Conventions
+ *   - plain C: opaque context, raw DEVICE pointers (hipMalloc'ed or any HIP-visible allocation, e.g. a
+ *     torch tensor's data_ptr()), sizes in elements unless a name says bytes; no C++/torch types.
+ *   - a field element is 32 bytes: 8 little-endian u32 limbs, canonical in [0,p) (BN254 Fr), the
+ *     reference's device/host/proof format (include/ligetron/webgpu/device_bignum.hpp:76-86).
+ *   - every op is asynchronous and ordered on the context's single HIP stream (the reference's single
+ *     in-order WebGPU queue, src/webgpu/device_context.cpp:344-354); lig_sync() blocks.
+ *   - functions return 0 on success, a negative LIG_E_* code otherwise; lig_last_error() gives text.
+ *     (The reference has no error returns: device errors abort, device_context.cpp:121-127.)
+ *   - thread-compatible, not thread-safe (the reference is single-threaded).
+ */
+#ifndef LIG_HIP_H
+#define LIG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lig_ctx lig_ctx;
+
+enum { LIG_OK = 0, LIG_E_ARG = -1, LIG_E_HIP = -2, LIG_E_STATE = -3, LIG_E_NOMEM = -4 };
+enum { LIG_ELEM_BYTES = 32, LIG_DIGEST_BYTES = 32 };
+
+/* ---- lifecycle: webgpu_init + ntt_init (include/wgpu.hpp:71-82; src/webgpu/engine.cpp:196-260).
+ * p, mu and the three roots are derived from the fixed BN254 constants (the reference's shader hard-codes
+ * them too, shader/bn254fr.wgsl.in:19-45); k must be a power of two >= 512 (engine.cpp:849-850), n = 4k. */
+int  lig_ctx_create(lig_ctx **out, int device, uint32_t l, uint32_t k, uint32_t n);
+void lig_ctx_destroy(lig_ctx *ctx);                       /* syncs, then frees (wgpu.hpp dtor) */
+int  lig_sync(lig_ctx *ctx);                              /* device_synchronize() */
+const char *lig_last_error(const lig_ctx *ctx);
+const char *lig_version(void);
+uint32_t lig_message_size(const lig_ctx *ctx);            /* l  (wgpu.hpp:153) */
+uint32_t lig_padding_size(const lig_ctx *ctx);            /* k  (wgpu.hpp:154) */
+uint32_t lig_encoding_size(const lig_ctx *ctx);           /* n  (wgpu.hpp:155) */
+void *lig_stream(lig_ctx *ctx);                           /* hipStream_t, for callers that enqueue their own work */
+
+/* ---- buffers: make_device_buffer (zero-initialised like WebGPU), write_buffer, write_buffer_clear,
+ * clear_buffer, copy_buffer_to_buffer, copy_to_host (device_context.hpp:79-98, device_context.cpp:364-449) */
+int lig_malloc(lig_ctx *ctx, size_t bytes, void **dptr);
+int lig_free(lig_ctx *ctx, void *dptr);
+int lig_write(lig_ctx *ctx, void *dst, const void *host_src, size_t bytes);
+int lig_write_clear(lig_ctx *ctx, void *dst, size_t dst_bytes, const void *host_src, size_t bytes);
+int lig_clear(lig_ctx *ctx, void *dst, size_t bytes);
+int lig_copy(lig_ctx *ctx, void *dst, const void *src, size_t bytes);
+int lig_read(lig_ctx *ctx, void *host_dst, const void *src, size_t bytes);   /* blocking */
+
+/* ---- Reed-Solomon transforms on ONE n-element buffer, in place
+ * (encode_ntt_device / decode_ntt_device / ntt_{forward,inverse}_{k,2k,n}: engine.cpp:755-968) */
+enum { LIG_SIZE_K = 0, LIG_SIZE_2K = 1, LIG_SIZE_N = 2 };
+int lig_encode(lig_ctx *ctx, void *buf);                  /* buf[0..k) message, buf[k..n) must be 0 */
+int lig_encode_2k(lig_ctx *ctx, void *buf);               /* ntt_inverse_2k + ntt_forward_n (mask rows) */
+int lig_decode(lig_ctx *ctx, void *buf);                  /* INTT_n, fold k..2k onto 0..k, NTT_k */
+int lig_ntt(lig_ctx *ctx, void *buf, int which, int inverse);
+
+/* ---- eltwise (shader/kernels.wgsl.in:326-538; wgpu.hpp:98-139).  x, y, out may alias; `scalar` is a host
+ * pointer to one 32-byte element (the reference passes an mpz through a uniform buffer). */
+enum {
+    LIG_OP_ADD = 0,        /* out = x + y          EltwiseAddMod            */
+    LIG_OP_SUB,            /* out = x - y          EltwiseSubMod            */
+    LIG_OP_ADD_ASSIGN,     /* out += x             EltwiseAddAssignMod      */
+    LIG_OP_ADD_CONST,      /* out = x + c          EltwiseAddMod(scalar)    */
+    LIG_OP_SUB_CONST,      /* out = x - c          EltwiseSubConstMod       */
+    LIG_OP_CONST_SUB,      /* out = c - x          EltwiseConstSubMod       */
+    LIG_OP_MUL,            /* out = x * y          EltwiseMultMod           */
+    LIG_OP_MUL_CONST,      /* out = x * c          EltwiseMultMod(scalar)   */
+    LIG_OP_MONTMUL_CONST,  /* out = x * c / R      EltwiseMontMultMod       */
+    LIG_OP_FMA,            /* out += x * y         EltwiseFMAMod            */
+    LIG_OP_FMA_CONST,      /* out += x * c         EltwiseFMAMod(scalar)    */
+    LIG_OP_DIV,            /* out = x / y (y=0->0) EltwiseDivMod            */
+    LIG_OP_BIT_DECOMPOSE   /* out = bit `bit` of x EltwiseBitDecompose      */
+};
+int lig_eltwise(lig_ctx *ctx, int op, const void *x, const void *y, void *out, size_t count,
+                const uint8_t *scalar32, uint32_t bit);
+/* EltwisePowMod / EltwisePowAddMod (src/webgpu/powmod_context.cpp:178-268): out (=|+=) coeff * base^exp */
+int lig_powmod(lig_ctx *ctx, const uint8_t *base32, const void *exp_u32, const void *coeff, void *out,
+               size_t count, int add);
+
+/* ---- column SHA-256 (shader/sha256.wgsl; engine.cpp:1514-1686).  `state` is a device buffer of
+ * lig_sha_state_bytes(n_inst) bytes owned by the caller (the reference's sha256_context, wgpu.hpp:63-68). */
+size_t lig_sha_state_bytes(size_t n_inst);
+int lig_sha_init(lig_ctx *ctx, void *state, size_t n_inst);                   /* sha256_digest_init  */
+int lig_sha_update(lig_ctx *ctx, void *state, const void *row);               /* sha256_digest_update: n_inst elems */
+int lig_sha_final(lig_ctx *ctx, void *state, void *digests);                  /* sha256_digest_final: n_inst x 32 B */
+
+/* ---- sampling (engine.cpp:1689-1809; kernels.wgsl.in:541-549) */
+int lig_sample_init(lig_ctx *ctx, const uint32_t *host_idx, size_t count);    /* sampling_init */
+int lig_sample_gather(lig_ctx *ctx, const void *from, void *to, size_t slot); /* to[slot*count + i] = from[idx[i]] */
+
+/* ==== batched entry points (no reference counterpart: the reference pushes one row per call; these are what
+ * a row-batching driver and bench.py call so the GPU sees hundreds of rows per launch) ==== */
+/* msgs: rows x k elements (row-major, contiguous); codewords: rows x n elements */
+int lig_encode_rows(lig_ctx *ctx, const void *msgs, void *codewords, size_t rows);
+/* absorb `rows` codeword rows (rows x n_inst elements, row-major) in order */
+int lig_sha_update_rows(lig_ctx *ctx, void *state, const void *codewords, size_t rows);
+/* Merkle tree over n_leaves digests (merkle_tree::initialize_from_digest/build_tree, merkle_tree.hpp:344-375):
+ * nodes = (2*bit_ceil(n_leaves)-1) x 32 B device buffer in heap order, root = node 0 */
+size_t lig_merkle_nodes(size_t n_leaves);
+int lig_merkle_build(lig_ctx *ctx, const void *leaves, size_t n_leaves, void *nodes);
+/* stage-2 accumulators over a batch (check_code / check_linear / check_quadratic,
+ * nonbatch_context.hpp:756-780): for r < rows
+ *    code[j]  += rc[r] * U[r][j]                      (rc: rows host scalars, 32 B each)
+ *    lin[j]   += U[r][j] * Rn[r][j]                   (Rn may be NULL: skipped)
+ *    quad[j]  += rq[t] * (U[x_t][j]*U[y_t][j] - U[z_t][j])   for each triple t (triples: 3 row indices each)
+ */
+int lig_rlc_rows(lig_ctx *ctx, const void *U, const void *Rn, size_t rows,
+                 const uint8_t *rc_host, void *code, void *lin,
+                 const uint32_t *triples_host, const uint8_t *rq_host, size_t n_triples, void *quad);
+/* out[r*count + i] = codewords[r][idx[i]]  for r < rows (stage 3, nonbatch_context.hpp:924-942) */
+int lig_gather_rows(lig_ctx *ctx, const void *codewords, size_t rows, void *out);
+/* AES-256-CTR field sampler on the GPU (include/util/csprng.hpp:54-107 + finite_field_gmp.hpp:66-78):
+ * out[i] = element number first_elem + i of the stream keyed by key32 (IV = 0) */
+int lig_rng_fill(lig_ctx *ctx, const uint8_t *key32, uint64_t first_elem, void *out, size_t count);
+
+/* Measurement hook (no reference counterpart): while enabled, every lig_encode_rows launch group records HIP
+ * events on the context stream immediately around the dominant kernel (encode_mid).  lig_profile_read syncs
+ * and returns the number of bracketed launches, the rows they covered and the summed kernel time. */
+int lig_profile_enable(lig_ctx *ctx, int on);
+int lig_profile_read(lig_ctx *ctx, uint64_t *launches, uint64_t *rows, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIG_HIP_H */

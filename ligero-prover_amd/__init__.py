@@ -1,0 +1,220 @@
+"""ligero-prover_amd -- ctypes binding of liblig_hip.so (the MI355X-native Ligero prover backend).
+
+This is a thin loader for tests and bench.py; the product is the C-ABI library (include/lig_hip.h) and the
+C++ `hip_context` mirror of the reference's `webgpu_context` (include/lig_hip_context.hpp).  There is NO CPU
+fallback: if the HIP library is missing or no GPU is visible, construction raises.
+
+The directory name contains a hyphen, so import it by path:
+    spec = importlib.util.spec_from_file_location("ligero_prover_amd", ".../ligero-prover_amd/__init__.py")
+(tests/hip_lib.py and bench.py do exactly that).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblig_hip.so")
+
+OPS = dict(ADD=0, SUB=1, ADD_ASSIGN=2, ADD_CONST=3, SUB_CONST=4, CONST_SUB=5, MUL=6, MUL_CONST=7,
+           MONTMUL_CONST=8, FMA=9, FMA_CONST=10, DIV=11, BIT_DECOMPOSE=12)
+SIZE_K, SIZE_2K, SIZE_N = 0, 1, 2
+
+EXPORTS = [
+    "lig_ctx_create", "lig_ctx_destroy", "lig_sync", "lig_last_error", "lig_version", "lig_message_size",
+    "lig_padding_size", "lig_encoding_size", "lig_stream", "lig_malloc", "lig_free", "lig_write", "lig_write_clear",
+    "lig_clear", "lig_copy", "lig_read", "lig_encode", "lig_encode_2k", "lig_decode", "lig_ntt", "lig_eltwise",
+    "lig_powmod", "lig_sha_state_bytes", "lig_sha_init", "lig_sha_update", "lig_sha_final", "lig_sample_init",
+    "lig_sample_gather", "lig_encode_rows", "lig_sha_update_rows", "lig_merkle_nodes", "lig_merkle_build",
+    "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
+]
+
+
+def build(force=False):
+    """compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)"""
+    import subprocess
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc, "-j8"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("liblig_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "-- there is no CPU fallback for the HIP path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64
+    L.lig_ctx_create.argtypes = [C.POINTER(vp), C.c_int, u32, u32, u32]
+    L.lig_ctx_destroy.argtypes = [vp]
+    L.lig_ctx_destroy.restype = None
+    L.lig_sync.argtypes = [vp]
+    L.lig_last_error.argtypes = [vp]
+    L.lig_last_error.restype = C.c_char_p
+    L.lig_version.restype = C.c_char_p
+    for f in ("lig_message_size", "lig_padding_size", "lig_encoding_size"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = u32
+    L.lig_stream.argtypes = [vp]
+    L.lig_stream.restype = vp
+    L.lig_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.lig_free.argtypes = [vp, vp]
+    L.lig_write.argtypes = [vp, vp, vp, sz]
+    L.lig_write_clear.argtypes = [vp, vp, sz, vp, sz]
+    L.lig_clear.argtypes = [vp, vp, sz]
+    L.lig_copy.argtypes = [vp, vp, vp, sz]
+    L.lig_read.argtypes = [vp, vp, vp, sz]
+    for f in ("lig_encode", "lig_encode_2k", "lig_decode"):
+        getattr(L, f).argtypes = [vp, vp]
+    L.lig_ntt.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.lig_eltwise.argtypes = [vp, C.c_int, vp, vp, vp, sz, vp, u32]
+    L.lig_powmod.argtypes = [vp, vp, vp, vp, vp, sz, C.c_int]
+    L.lig_sha_state_bytes.argtypes = [sz]
+    L.lig_sha_state_bytes.restype = sz
+    L.lig_sha_init.argtypes = [vp, vp, sz]
+    L.lig_sha_update.argtypes = [vp, vp, vp]
+    L.lig_sha_final.argtypes = [vp, vp, vp]
+    L.lig_sample_init.argtypes = [vp, vp, sz]
+    L.lig_sample_gather.argtypes = [vp, vp, vp, sz]
+    L.lig_encode_rows.argtypes = [vp, vp, vp, sz]
+    L.lig_sha_update_rows.argtypes = [vp, vp, vp, sz]
+    L.lig_merkle_nodes.argtypes = [sz]
+    L.lig_merkle_nodes.restype = sz
+    L.lig_merkle_build.argtypes = [vp, vp, sz, vp]
+    L.lig_rlc_rows.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, sz, vp]
+    L.lig_gather_rows.argtypes = [vp, vp, sz, vp]
+    L.lig_rng_fill.argtypes = [vp, vp, u64, vp, sz]
+    L.lig_profile_enable.argtypes = [vp, C.c_int]
+    L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    return L
+
+
+class LigError(RuntimeError):
+    pass
+
+
+def _hptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """owns a lig_ctx; device buffers are plain integer device pointers"""
+
+    def __init__(self, l, k, n, device=0):
+        self.L = load_library()
+        self.l, self.k, self.n = l, k, n
+        h = C.c_void_p()
+        rc = self.L.lig_ctx_create(C.byref(h), device, l, k, n)
+        self.h = h
+        if rc != 0:
+            msg = self.L.lig_last_error(h).decode() if h else "invalid arguments"
+            if h:
+                self.L.lig_ctx_destroy(h)
+            self.h = None
+            raise LigError("lig_ctx_create failed (%d): %s" % (rc, msg))
+        self._bufs = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            for p in self._bufs:
+                self.L.lig_free(self.h, p)
+            self._bufs = []
+            self.L.lig_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise LigError("lig call failed (%d): %s" % (rc, self.L.lig_last_error(self.h).decode()))
+
+    # ---- buffers
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.L.lig_malloc(self.h, nbytes, C.byref(p)))
+        self._bufs.append(p)
+        return p
+
+    def free(self, p):
+        self._bufs = [q for q in self._bufs if q.value != p.value]
+        self.check(self.L.lig_free(self.h, p))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        self.check(self.L.lig_write(self.h, p, _hptr(arr), arr.nbytes))
+        return p
+
+    def write(self, p, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.L.lig_write(self.h, C.c_void_p(p.value + offset), _hptr(arr), arr.nbytes))
+
+    def download(self, p, shape, dtype=np.uint32, offset=0):
+        out = np.zeros(shape, dtype=dtype)
+        self.check(self.L.lig_read(self.h, _hptr(out), C.c_void_p(p.value + offset), out.nbytes))
+        return out
+
+    def sync(self):
+        self.check(self.L.lig_sync(self.h))
+
+    # ---- ops (thin)
+    def encode(self, p): self.check(self.L.lig_encode(self.h, p))
+    def encode_2k(self, p): self.check(self.L.lig_encode_2k(self.h, p))
+    def decode(self, p): self.check(self.L.lig_decode(self.h, p))
+    def ntt(self, p, which, inverse): self.check(self.L.lig_ntt(self.h, p, which, int(inverse)))
+    def encode_rows(self, msgs, cws, rows): self.check(self.L.lig_encode_rows(self.h, msgs, cws, rows))
+
+    def eltwise(self, op, x, y, out, count, scalar=None, bit=0):
+        sc = None
+        if scalar is not None:
+            sc = np.frombuffer(int(scalar).to_bytes(32, "little"), dtype=np.uint8).copy()
+        self.check(self.L.lig_eltwise(self.h, OPS[op] if isinstance(op, str) else op, x, y, out, count, _hptr(sc), bit))
+
+    def powmod(self, base, exp_p, coeff_p, out_p, count, add=False):
+        b = np.frombuffer(int(base).to_bytes(32, "little"), dtype=np.uint8).copy()
+        self.check(self.L.lig_powmod(self.h, _hptr(b), exp_p, coeff_p, out_p, count, int(add)))
+
+    def sha_state(self, n_inst):
+        p = self.malloc(self.L.lig_sha_state_bytes(n_inst))
+        self.check(self.L.lig_sha_init(self.h, p, n_inst))
+        return p
+
+    def sha_update_rows(self, st, cws, rows): self.check(self.L.lig_sha_update_rows(self.h, st, cws, rows))
+    def sha_final(self, st, digests): self.check(self.L.lig_sha_final(self.h, st, digests))
+
+    def merkle_build(self, leaves, n_leaves):
+        nodes = self.malloc(32 * self.L.lig_merkle_nodes(n_leaves))
+        self.check(self.L.lig_merkle_build(self.h, leaves, n_leaves, nodes))
+        return nodes
+
+    def sample_init(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        self.check(self.L.lig_sample_init(self.h, _hptr(idx), len(idx)))
+
+    def gather_rows(self, cws, rows, out): self.check(self.L.lig_gather_rows(self.h, cws, rows, out))
+
+    def rlc_rows(self, U, Rn, rows, rc, code, lin, triples=None, rq=None, quad=None):
+        def sc(vals):
+            return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+        rcb = sc(rc) if rc is not None else None
+        nt = 0 if triples is None else len(triples)
+        tri = np.ascontiguousarray(np.array(triples, dtype=np.uint32).reshape(-1)) if nt else None
+        rqb = sc(rq) if nt else None
+        self.check(self.L.lig_rlc_rows(self.h, U, Rn, rows, _hptr(rcb), code, lin, _hptr(tri), _hptr(rqb), nt, quad))
+
+    def profile_enable(self, on=True):
+        self.check(self.L.lig_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        self.check(self.L.lig_profile_read(self.h, C.byref(a), C.byref(b), C.byref(ms)))
+        return a.value, b.value, ms.value
+
+    def rng_fill(self, key, first_elem, out, count):
+        k = np.frombuffer(bytes(key), dtype=np.uint8).copy()
+        self.check(self.L.lig_rng_fill(self.h, _hptr(k), first_elem, out, count))

@@ -1,0 +1,118 @@
+// aes.hip -- AES-256-CTR field sampler on gfx950.
+//
+// Device counterpart of mpz_random_engine (include/util/csprng.hpp:28-110: EVP_aes_256_ctr, IV = 0,
+// zero plaintext, 16 KiB refills) + bn254_gmp::generate_random (include/zkp/finite_field_gmp.hpp:66-78:
+// 32 keystream bytes as 4 little-endian u64 -> >>2 -> subtract p if >= p).  The reference draws these one at
+// a time on the host (k-l pads per row, one per constraint in stage 2); on the GPU element e of a stream is
+// computed independently from keystream blocks 2e and 2e+1, so a whole batch of rows is one launch.
+// T-table AES with the tables staged in LDS (1 KiB Te0 + 256 B S-box per workgroup).
+#include "kernels.hpp"
+
+namespace lig {
+
+namespace {
+struct AesTables { uint32_t te0[256]; uint8_t sbox[256]; };
+
+uint8_t xtime_h(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1b)); }
+
+const AesTables& host_tables() {
+    static AesTables T;
+    static bool ready = false;
+    if (!ready) {
+        // S-box from its definition: inverse in GF(2^8) then the affine map (FIPS-197 5.1.1)
+        uint8_t p = 1, q = 1;
+        do {
+            p = (uint8_t)(p ^ (p << 1) ^ ((p & 0x80) ? 0x1b : 0));
+            q ^= (uint8_t)(q << 1); q ^= (uint8_t)(q << 2); q ^= (uint8_t)(q << 4);
+            if (q & 0x80) q ^= 0x09;
+            auto rol = [](uint8_t v, int s) { return (uint8_t)((v << s) | (v >> (8 - s))); };
+            T.sbox[p] = (uint8_t)(q ^ rol(q, 1) ^ rol(q, 2) ^ rol(q, 3) ^ rol(q, 4) ^ 0x63);
+        } while (p != 1);
+        T.sbox[0] = 0x63;
+        for (int i = 0; i < 256; i++) {
+            const uint8_t s = T.sbox[i], s2 = xtime_h(s), s3 = (uint8_t)(s2 ^ s);
+            T.te0[i] = ((uint32_t)s2 << 24) | ((uint32_t)s << 16) | ((uint32_t)s << 8) | s3;
+        }
+        ready = true;
+    }
+    return T;
+}
+}  // namespace
+
+void aes256_expand_host(const uint8_t key[32], uint32_t rk[60]) {
+    const AesTables& T = host_tables();
+    auto subw = [&](uint32_t t) {
+        return ((uint32_t)T.sbox[t >> 24] << 24) | ((uint32_t)T.sbox[(t >> 16) & 255] << 16) |
+               ((uint32_t)T.sbox[(t >> 8) & 255] << 8) | T.sbox[t & 255];
+    };
+    for (int i = 0; i < 8; i++)
+        rk[i] = ((uint32_t)key[4 * i] << 24) | ((uint32_t)key[4 * i + 1] << 16) | ((uint32_t)key[4 * i + 2] << 8) | key[4 * i + 3];
+    uint8_t rcon = 1;
+    for (int i = 8; i < 60; i++) {
+        uint32_t t = rk[i - 1];
+        if (i % 8 == 0) { t = subw((t << 8) | (t >> 24)) ^ ((uint32_t)rcon << 24); rcon = xtime_h(rcon); }
+        else if (i % 8 == 4) t = subw(t);
+        rk[i] = rk[i - 8] ^ t;
+    }
+}
+
+__device__ uint32_t g_te0[256];
+__device__ uint32_t g_sbox[256];
+
+__device__ __forceinline__ uint32_t ror32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const uint32_t* te0, const uint32_t* sb,
+                                             uint64_t block_index, uint32_t out[4]) {
+    uint32_t s0 = rk[0], s1 = rk[1], s2 = (uint32_t)(block_index >> 32) ^ rk[2], s3 = (uint32_t)block_index ^ rk[3];
+#pragma unroll
+    for (int r = 1; r < 14; r++) {
+        const uint32_t t0 = te0[s0 >> 24] ^ ror32(te0[(s1 >> 16) & 255], 8) ^ ror32(te0[(s2 >> 8) & 255], 16) ^ ror32(te0[s3 & 255], 24) ^ rk[4 * r];
+        const uint32_t t1 = te0[s1 >> 24] ^ ror32(te0[(s2 >> 16) & 255], 8) ^ ror32(te0[(s3 >> 8) & 255], 16) ^ ror32(te0[s0 & 255], 24) ^ rk[4 * r + 1];
+        const uint32_t t2 = te0[s2 >> 24] ^ ror32(te0[(s3 >> 16) & 255], 8) ^ ror32(te0[(s0 >> 8) & 255], 16) ^ ror32(te0[s1 & 255], 24) ^ rk[4 * r + 2];
+        const uint32_t t3 = te0[s3 >> 24] ^ ror32(te0[(s0 >> 16) & 255], 8) ^ ror32(te0[(s1 >> 8) & 255], 16) ^ ror32(te0[s2 & 255], 24) ^ rk[4 * r + 3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    }
+    out[0] = ((sb[s0 >> 24] << 24) | (sb[(s1 >> 16) & 255] << 16) | (sb[(s2 >> 8) & 255] << 8) | sb[s3 & 255]) ^ rk[56];
+    out[1] = ((sb[s1 >> 24] << 24) | (sb[(s2 >> 16) & 255] << 16) | (sb[(s3 >> 8) & 255] << 8) | sb[s0 & 255]) ^ rk[57];
+    out[2] = ((sb[s2 >> 24] << 24) | (sb[(s3 >> 16) & 255] << 16) | (sb[(s0 >> 8) & 255] << 8) | sb[s1 & 255]) ^ rk[58];
+    out[3] = ((sb[s3 >> 24] << 24) | (sb[(s0 >> 16) & 255] << 16) | (sb[(s1 >> 8) & 255] << 8) | sb[s2 & 255]) ^ rk[59];
+}
+
+__global__ void k_rng_fill(const uint32_t* __restrict__ rk_g, uint64_t first_elem, fr* __restrict__ out, size_t count) {
+    __shared__ uint32_t te0[256];
+    __shared__ uint32_t sb[256];
+    __shared__ uint32_t rk[60];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { te0[i] = g_te0[i]; sb[i] = g_sbox[i]; }
+    if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
+    __syncthreads();
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t blk = 2 * (first_elem + e);
+        uint32_t o[8];
+        aes256_block(rk, te0, sb, blk, o);
+        aes256_block(rk, te0, sb, blk + 1, o + 4);
+        fr v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v.v[i] = __builtin_bswap32(o[i]);   // keystream bytes -> little-endian limbs
+#pragma unroll
+        for (int i = 0; i < 8; i++) v.v[i] = (v.v[i] >> 2) | (i < 7 ? (v.v[i + 1] << 30) : 0u);
+        fr_store(out + e, fr_reduce_once(v));   // v < 2^254 < 2p
+    }
+}
+
+// per-device table upload, called from lig_ctx_create
+void aes_upload_tables() {
+    const AesTables& T = host_tables();
+    uint32_t sb32[256];
+    for (int i = 0; i < 256; i++) sb32[i] = T.sbox[i];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_te0), T.te0, sizeof(T.te0));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sbox), sb32, sizeof(sb32));
+}
+
+void launch_rng_fill(hipStream_t s, const uint32_t* rk60_dev, uint64_t first_elem, fr* out, size_t count) {
+    if (!count) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_rng_fill, dim3((uint32_t)blocks), dim3(256), 0, s, rk60_dev, first_elem, out, count);
+}
+
+}  // namespace lig

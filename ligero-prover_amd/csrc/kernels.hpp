@@ -1,0 +1,65 @@
+// kernels.hpp -- internal interface between the C ABI (lig_capi.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "fr.hpp"
+
+namespace lig {
+
+// Twiddle tables of one transform size (the reference's ntt_config_t + omega buffers,
+// include/wgpu.hpp:54-61, src/webgpu/engine.cpp:1382-1503); all entries Montgomery form.
+struct NttPlan {
+    uint32_t N = 0, log2N = 0;
+    fr* w = nullptr;      // w^i * R,  i < N/2   (device)
+    fr* winv = nullptr;   // w^-i * R, i < N/2   (device)
+    fr ninv;              // N^-1 * R
+};
+
+// Tables of the fused row-encode path (ntt_encode.hip); see that file for the decomposition.
+struct EncodePlan {
+    uint32_t k = 0, n = 0, log2k = 0;
+    uint32_t A = 0, B = 0, log2B = 0;      // k = A * B, A = 8 outer radix, B = tile length
+    fr* tw_b = nullptr;       // per-stage twiddles of the size-B forward transform (root psi^A, psi = w_n^4): B-1 entries
+    fr* tw_b_inv = nullptr;   // same for the inverse size-B transform (root w_k^-A)
+    fr* seam_inv = nullptr;   // w_k^(-i2*j1) for the INTT seam, [A][B]
+    fr* twist = nullptr;      // k^-1 * w_n^(r*i), [4][k], i in natural order
+    fr* seam_fwd = nullptr;   // psi^(i1*j2), [A][B]
+    fr* w8_inv = nullptr;     // powers of w_k^-(k/8): radix-8 constants (inverse), 8 entries
+    fr* w8_fwd = nullptr;     // powers of psi^(k/8): radix-8 constants (forward), 8 entries
+};
+
+// ---- ntt_generic.hip
+void ntt_generic_forward(hipStream_t s, const NttPlan& pl, fr* buf, size_t rows, size_t row_stride);
+void ntt_generic_inverse(hipStream_t s, const NttPlan& pl, fr* buf, size_t rows, size_t row_stride);
+void ntt_generic_fold(hipStream_t s, fr* buf, uint32_t half, size_t rows, size_t row_stride);
+
+// ---- ntt_encode.hip
+bool encode_fast_supported(uint32_t k);
+// ev0/ev1 (optional): HIP events recorded on `s` immediately before/after the dominant kernel (encode_mid)
+void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* codewords, fr* scratch_y,
+                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1);
+
+// ---- eltwise.hip
+void launch_eltwise(hipStream_t s, int op, const fr* x, const fr* y, fr* out, size_t count, fr scalar, uint32_t bit);
+void launch_powmod(hipStream_t s, const fr* table32, const uint32_t* exp, const fr* coeff, fr* out, size_t count, int add);
+void launch_gather_rows(hipStream_t s, const fr* cw, size_t row_stride, size_t rows, const uint32_t* idx, uint32_t count, fr* out);
+void launch_rlc_rows(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const fr* rc_dev,
+                     fr* code, fr* lin, const uint32_t* triples_dev, const fr* rq_dev, size_t n_triples, fr* quad);
+
+// ---- sha.hip
+struct ShaState {          // layout of the caller-owned device state buffer
+    uint32_t* h;           // [8][n_inst]
+    uint32_t* pend;        // [8][n_inst]  buffered element when an odd number of rows has been absorbed
+};
+void launch_sha_init(hipStream_t s, uint32_t* state, size_t n_inst);
+void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const fr* rows, size_t row_stride,
+                            size_t nrows, uint64_t rows_before);
+void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests);
+void launch_merkle_build(hipStream_t s, const uint32_t* leaves, size_t n_leaves, uint32_t* nodes);
+
+// ---- aes.hip
+void launch_rng_fill(hipStream_t s, const uint32_t* rk60_dev, uint64_t first_elem, fr* out, size_t count);
+void aes256_expand_host(const uint8_t key[32], uint32_t rk[60]);
+
+}  // namespace lig

@@ -1,0 +1,513 @@
+// lig_capi.hip -- the C ABI of include/lig_hip.h: context, tables, buffer plumbing, launch sequences.
+// Host-side counterpart of webgpu_context (include/wgpu.hpp, src/webgpu/engine.cpp) and device_context
+// (src/webgpu/device_context.cpp): one HIP stream instead of a WebGPU queue, plain device pointers instead of
+// WGPUBuffer/bind groups, twiddle tables generated with host_field.hpp instead of GMP.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lig_hip.h"
+#include "host_field.hpp"
+#include "kernels.hpp"
+
+namespace lig {
+void aes_upload_tables();
+}
+
+using lig::fr;
+namespace H = lig::host;
+
+struct lig_ctx {
+    int device = 0;
+    uint32_t l = 0, k = 0, n = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    lig::NttPlan plan[3];
+    lig::EncodePlan ep;
+    bool fast = false;
+    std::vector<void*> owned;                 // device tables freed at destroy
+    fr* scratch_y = nullptr; fr* scratch_z = nullptr; size_t scratch_rows = 0;
+    std::unordered_map<void*, std::pair<size_t, uint64_t>> sha;   // state ptr -> (n_inst, rows absorbed)
+    uint32_t* sample_idx = nullptr; size_t sample_count = 0;
+    uint32_t* rk_dev = nullptr;               // 60 AES round-key words
+    fr* small_dev = nullptr;                  // staging for per-call scalars (rc/rq/tables)
+    size_t small_cap = 0;
+    uint32_t* tri_dev = nullptr; size_t tri_cap = 0;
+    // optional per-kernel timing (lig_profile_*): HIP events recorded on the ctx stream around the dominant kernel
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    uint64_t prof_rows = 0;
+};
+
+#define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; } while (0)
+#define HIP_TRY(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); return LIG_E_HIP; } } while (0)
+#define FAIL(c, code, msg) do { (c)->err = (msg); return (code); } while (0)
+
+static fr to_dev(const H::Fr& a) {
+    fr r;
+    std::memcpy(r.v, a.v, 32);
+    return r;
+}
+static uint32_t ilog2u(uint32_t x) { uint32_t r = 0; while ((1u << r) < x) r++; return r; }
+
+static int upload(lig_ctx* c, const std::vector<fr>& host, fr** dev) {
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, host.size() * sizeof(fr)));
+    c->owned.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, host.data(), host.size() * sizeof(fr), hipMemcpyHostToDevice));
+    *dev = (fr*)p;
+    return LIG_OK;
+}
+
+// ntt_precompute_omegas (src/webgpu/engine.cpp:1382-1503): w^i * R, w^-i * R (i < N/2), N^-1 * R
+static int make_plan(lig_ctx* c, lig::NttPlan& pl, uint32_t N, const H::Fr& root) {
+    pl.N = N; pl.log2N = ilog2u(N);
+    std::vector<fr> w(N / 2), wi(N / 2);
+    const H::Fr rootm = H::to_mont(root), rinvm = H::to_mont(H::inv(root));
+    H::Fr cur = H::R1, curi = H::R1;    // 1 in Montgomery form
+    for (uint32_t i = 0; i < N / 2; i++) {
+        w[i] = to_dev(cur); wi[i] = to_dev(curi);
+        cur = H::montmul(cur, rootm); curi = H::montmul(curi, rinvm);
+    }
+    pl.ninv = to_dev(H::to_mont(H::inv(H::from_u64(N))));
+    int rc;
+    if ((rc = upload(c, w, &pl.w)) != LIG_OK) return rc;
+    return upload(c, wi, &pl.winv);
+}
+
+// powers table in Montgomery form: out[i] = base^(f(i)) generated incrementally
+static std::vector<H::Fr> powers_mont(const H::Fr& base, size_t count) {
+    std::vector<H::Fr> out(count);
+    const H::Fr bm = H::to_mont(base);
+    H::Fr cur = H::R1;
+    for (size_t i = 0; i < count; i++) { out[i] = cur; cur = H::montmul(cur, bm); }
+    return out;
+}
+
+static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
+    lig::EncodePlan& ep = c->ep;
+    const uint32_t k = c->k, A = 8, B = k / 8;
+    ep.k = k; ep.n = c->n; ep.log2k = ilog2u(k); ep.A = A; ep.B = B; ep.log2B = ilog2u(B);
+    const H::Fr wk_inv = H::inv(wk);
+    const H::Fr psi = H::pow_u64(w4k, 4);                       // order k
+    int rc;
+    // per-stage twiddles of the size-B transforms: stage of span M at offset B-M, rho^(idx*B/M)
+    auto stage_table = [&](const H::Fr& rho) {
+        std::vector<H::Fr> pw = powers_mont(rho, B / 2);
+        std::vector<fr> t(B);                                   // B-1 used
+        for (uint32_t M = B; M >= 2; M >>= 1)
+            for (uint32_t idx = 0; idx < M / 2; idx++) t[(B - M) + idx] = to_dev(pw[(size_t)idx * (B / M)]);
+        t[B - 1] = to_dev(H::R1);
+        return t;
+    };
+    if ((rc = upload(c, stage_table(H::pow_u64(wk_inv, A)), &ep.tw_b_inv)) != LIG_OK) return rc;
+    if ((rc = upload(c, stage_table(H::pow_u64(psi, A)), &ep.tw_b)) != LIG_OK) return rc;
+    // seams: seam_inv[j1][i2] = w_k^(-i2*j1), seam_fwd[i1][q2] = psi^(i1*q2)
+    {
+        std::vector<fr> si((size_t)A * B), sf((size_t)A * B);
+        for (uint32_t j1 = 0; j1 < A; j1++) {
+            std::vector<H::Fr> a = powers_mont(H::pow_u64(wk_inv, j1), B), b = powers_mont(H::pow_u64(psi, j1), B);
+            for (uint32_t i = 0; i < B; i++) { si[(size_t)j1 * B + i] = to_dev(a[i]); sf[(size_t)j1 * B + i] = to_dev(b[i]); }
+        }
+        if ((rc = upload(c, si, &ep.seam_inv)) != LIG_OK) return rc;
+        if ((rc = upload(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
+    }
+    // twist[r][j1][i2] = k^-1 * w_n^(r*(j1 + 8*i2))
+    {
+        std::vector<fr> tw((size_t)4 * k);
+        const H::Fr kinv_m = H::to_mont(H::inv(H::from_u64(k)));
+        for (uint32_t r = 0; r < 4; r++) {
+            std::vector<H::Fr> pw = powers_mont(H::pow_u64(w4k, r), k);    // (w_n^r)^i, Montgomery form
+            for (uint32_t j1 = 0; j1 < A; j1++)
+                for (uint32_t i2 = 0; i2 < B; i2++) {
+                    const H::Fr v = H::montmul(pw[j1 + (size_t)A * i2], kinv_m);     // (x*R)(kinv*R)/R = x*kinv*R
+                    tw[((size_t)r * A + j1) * B + i2] = to_dev(v);
+                }
+        }
+        if ((rc = upload(c, tw, &ep.twist)) != LIG_OK) return rc;
+    }
+    // radix-8 constants: w8[i] = w^i, w = w_k^(-k/8) (inverse) / psi^(k/8) (forward)
+    {
+        std::vector<H::Fr> a = powers_mont(H::pow_u64(wk_inv, B), 8), b = powers_mont(H::pow_u64(psi, B), 8);
+        std::vector<fr> da(8), db(8);
+        for (int i = 0; i < 8; i++) { da[i] = to_dev(a[i]); db[i] = to_dev(b[i]); }
+        if ((rc = upload(c, da, &ep.w8_inv)) != LIG_OK) return rc;
+        if ((rc = upload(c, db, &ep.w8_fwd)) != LIG_OK) return rc;
+    }
+    return LIG_OK;
+}
+
+extern "C" {
+
+const char* lig_version(void) { return "lig_hip 0.1 (gfx950)"; }
+
+int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n) {
+    if (!out) return LIG_E_ARG;
+    *out = nullptr;
+    if (k < 512 || (k & (k - 1)) || n != 4 * k || l > k || (uint64_t)n > (1ull << 28)) return LIG_E_ARG;
+    lig_ctx* c = new lig_ctx();
+    c->device = device; c->l = l; c->k = k; c->n = n;
+    *out = c;    // returned even on failure so that lig_last_error works; caller destroys
+    HIP_TRY(c, hipSetDevice(device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    H::Fr wk, w2k, w4k;
+    H::omegas(k, wk, w2k, w4k);
+    int rc;
+    if ((rc = make_plan(c, c->plan[LIG_SIZE_K], k, wk)) != LIG_OK) return rc;
+    if ((rc = make_plan(c, c->plan[LIG_SIZE_2K], 2 * k, w2k)) != LIG_OK) return rc;
+    if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
+    c->fast = lig::encode_fast_supported(k);
+    if (c->fast && (rc = make_encode_plan(c, wk, w4k)) != LIG_OK) return rc;
+    HIP_TRY(c, hipMalloc((void**)&c->rk_dev, 60 * sizeof(uint32_t)));
+    lig::aes_upload_tables();
+    HIP_TRY(c, hipDeviceSynchronize());
+    return LIG_OK;
+}
+
+void lig_ctx_destroy(lig_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->owned) (void)hipFree(p);
+    (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z); (void)hipFree(c->sample_idx);
+    (void)hipFree(c->rk_dev); (void)hipFree(c->small_dev); (void)hipFree(c->tri_dev);
+    for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lig_sync(lig_ctx* c) { CHECK_CTX(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return LIG_OK; }
+const char* lig_last_error(const lig_ctx* c) { return c ? c->err.c_str() : "null context"; }
+uint32_t lig_message_size(const lig_ctx* c) { return c ? c->l : 0; }
+uint32_t lig_padding_size(const lig_ctx* c) { return c ? c->k : 0; }
+uint32_t lig_encoding_size(const lig_ctx* c) { return c ? c->n : 0; }
+void* lig_stream(lig_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---------------------------------------------------------------- buffers
+int lig_malloc(lig_ctx* c, size_t bytes, void** dptr) {
+    CHECK_CTX(c);
+    if (!dptr) return LIG_E_ARG;
+    HIP_TRY(c, hipMalloc(dptr, bytes ? bytes : 1));
+    HIP_TRY(c, hipMemsetAsync(*dptr, 0, bytes, c->stream));     // WebGPU buffers are zero-initialised
+    return LIG_OK;
+}
+int lig_free(lig_ctx* c, void* dptr) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sha.erase(dptr);
+    HIP_TRY(c, hipFree(dptr));
+    return LIG_OK;
+}
+int lig_write(lig_ctx* c, void* dst, const void* src, size_t bytes) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));    // the host buffer may be reused right away (wgpuQueueWriteBuffer semantics)
+    return LIG_OK;
+}
+int lig_write_clear(lig_ctx* c, void* dst, size_t dst_bytes, const void* src, size_t bytes) {
+    CHECK_CTX(c);
+    if (bytes > dst_bytes) FAIL(c, LIG_E_ARG, "write_clear: source larger than destination");
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (dst_bytes > bytes) HIP_TRY(c, hipMemsetAsync((char*)dst + bytes, 0, dst_bytes - bytes, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LIG_OK;
+}
+int lig_clear(lig_ctx* c, void* dst, size_t bytes) { CHECK_CTX(c); HIP_TRY(c, hipMemsetAsync(dst, 0, bytes, c->stream)); return LIG_OK; }
+int lig_copy(lig_ctx* c, void* dst, const void* src, size_t bytes) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return LIG_OK;
+}
+int lig_read(lig_ctx* c, void* host_dst, const void* src, size_t bytes) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------- transforms
+static int ensure_scratch(lig_ctx* c, size_t rows) {
+    if (rows <= c->scratch_rows) return LIG_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z);
+    c->scratch_y = c->scratch_z = nullptr; c->scratch_rows = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->scratch_y, rows * (size_t)c->k * sizeof(fr)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch_z, rows * (size_t)c->n * sizeof(fr)));
+    c->scratch_rows = rows;
+    return LIG_OK;
+}
+
+int lig_encode_rows(lig_ctx* c, const void* msgs, void* codewords, size_t rows) {
+    CHECK_CTX(c);
+    if (!rows) return LIG_OK;
+    if (!msgs || !codewords) return LIG_E_ARG;
+    if (c->fast) {
+        const size_t chunk = 256;     // rows per launch group: keeps the Y/Z scratch (1.25 MiB/row) inside the 256 MiB L3
+        int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
+        if (rc != LIG_OK) return rc;
+        for (size_t r0 = 0; r0 < rows; r0 += chunk) {
+            const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->prof_on) {
+                if (c->prof_used == c->prof_events.size()) {
+                    hipEvent_t a, b;
+                    HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
+                    c->prof_events.push_back({a, b});
+                }
+                e0 = c->prof_events[c->prof_used].first; e1 = c->prof_events[c->prof_used].second;
+                c->prof_used++; c->prof_rows += nr;
+            }
+            lig::encode_rows_fast(c->stream, c->ep, (const fr*)msgs + r0 * c->k, (fr*)codewords + r0 * c->n, c->scratch_y,
+                                  c->scratch_z, nr, e0, e1);
+        }
+    } else {
+        // generic path: copy + zero-pad each row, then INTT_k and NTT_n with the radix-2 kernels
+        HIP_TRY(c, hipMemsetAsync(codewords, 0, rows * (size_t)c->n * sizeof(fr), c->stream));
+        HIP_TRY(c, hipMemcpy2DAsync(codewords, (size_t)c->n * sizeof(fr), msgs, (size_t)c->k * sizeof(fr), (size_t)c->k * sizeof(fr),
+                                    rows, hipMemcpyDeviceToDevice, c->stream));
+        lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)codewords, rows, c->n);
+        lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)codewords, rows, c->n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+int lig_encode(lig_ctx* c, void* buf) {
+    CHECK_CTX(c);
+    if (!buf) return LIG_E_ARG;
+    if (c->fast) {
+        // in place: the message occupies buf[0..k); K1 reads it completely into Y before K3 writes the codeword
+        int rc = ensure_scratch(c, 1);
+        if (rc != LIG_OK) return rc;
+        lig::encode_rows_fast(c->stream, c->ep, (const fr*)buf, (fr*)buf, c->scratch_y, c->scratch_z, 1, nullptr, nullptr);
+    } else {
+        lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
+        lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_encode_2k(lig_ctx* c, void* buf) {
+    CHECK_CTX(c);
+    if (!buf) return LIG_E_ARG;
+    lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_2K], (fr*)buf, 1, c->n);
+    lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_decode(lig_ctx* c, void* buf) {
+    CHECK_CTX(c);
+    if (!buf) return LIG_E_ARG;
+    lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
+    lig::ntt_generic_fold(c->stream, (fr*)buf, c->k, 1, c->n);      // N taken from the 2k config: half = k (engine.cpp:782-786)
+    lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_ntt(lig_ctx* c, void* buf, int which, int inverse) {
+    CHECK_CTX(c);
+    if (!buf || which < 0 || which > 2) return LIG_E_ARG;
+    if (inverse) lig::ntt_generic_inverse(c->stream, c->plan[which], (fr*)buf, 1, c->n);
+    else lig::ntt_generic_forward(c->stream, c->plan[which], (fr*)buf, 1, c->n);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------- eltwise
+static bool canonical32(const uint8_t* s) {
+    H::Fr v; std::memcpy(v.v, s, 32);
+    return !H::geq(v, H::P);
+}
+int lig_eltwise(lig_ctx* c, int op, const void* x, const void* y, void* out, size_t count, const uint8_t* scalar32, uint32_t bit) {
+    CHECK_CTX(c);
+    if (op < LIG_OP_ADD || op > LIG_OP_BIT_DECOMPOSE || !out) return LIG_E_ARG;
+    const bool needs_x = op != LIG_OP_ADD_ASSIGN ? true : true;
+    const bool needs_y = op == LIG_OP_ADD || op == LIG_OP_SUB || op == LIG_OP_MUL || op == LIG_OP_FMA || op == LIG_OP_DIV;
+    const bool needs_c = op == LIG_OP_ADD_CONST || op == LIG_OP_SUB_CONST || op == LIG_OP_CONST_SUB || op == LIG_OP_MUL_CONST ||
+                         op == LIG_OP_MONTMUL_CONST || op == LIG_OP_FMA_CONST;
+    if ((needs_x && !x) || (needs_y && !y) || (needs_c && !scalar32)) FAIL(c, LIG_E_ARG, "eltwise: missing operand");
+    fr sc = lig::fr{};
+    if (needs_c) {
+        if (!canonical32(scalar32)) FAIL(c, LIG_E_ARG, "eltwise: scalar not reduced mod p");
+        H::Fr v; std::memcpy(v.v, scalar32, 32);
+        if (op == LIG_OP_MUL_CONST || op == LIG_OP_FMA_CONST) v = H::to_mont(v);
+        sc = to_dev(v);
+    }
+    if (!count) return LIG_OK;
+    lig::launch_eltwise(c->stream, op, (const fr*)x, (const fr*)y, (fr*)out, count, sc, bit);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+static int ensure_small(lig_ctx* c, size_t elems) {
+    if (elems <= c->small_cap) return LIG_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->small_dev); c->small_dev = nullptr; c->small_cap = 0;
+    size_t cap = elems < 1024 ? 1024 : elems;
+    HIP_TRY(c, hipMalloc((void**)&c->small_dev, cap * sizeof(fr)));
+    c->small_cap = cap;
+    return LIG_OK;
+}
+
+int lig_powmod(lig_ctx* c, const uint8_t* base32, const void* exp_u32, const void* coeff, void* out, size_t count, int add) {
+    CHECK_CTX(c);
+    if (!base32 || !exp_u32 || !coeff || !out) return LIG_E_ARG;
+    if (!canonical32(base32)) FAIL(c, LIG_E_ARG, "powmod: base not reduced mod p");
+    // powmod_context::set_base (src/webgpu/powmod_context.cpp:245-268): table[i] = base^(2^i) * R
+    H::Fr b; std::memcpy(b.v, base32, 32);
+    std::vector<fr> table(32);
+    H::Fr cur = H::to_mont(b);
+    for (int i = 0; i < 32; i++) { table[i] = to_dev(cur); cur = H::montmul(cur, cur); }
+    int rc = ensure_small(c, 32);
+    if (rc != LIG_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->small_dev, table.data(), 32 * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (count) lig::launch_powmod(c->stream, c->small_dev, (const uint32_t*)exp_u32, (const fr*)coeff, (fr*)out, count, add);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------- column SHA-256 + Merkle
+size_t lig_sha_state_bytes(size_t n_inst) { return n_inst * 16 * sizeof(uint32_t); }
+int lig_sha_init(lig_ctx* c, void* state, size_t n_inst) {
+    CHECK_CTX(c);
+    if (!state || !n_inst) return LIG_E_ARG;
+    lig::launch_sha_init(c->stream, (uint32_t*)state, n_inst);
+    c->sha[state] = {n_inst, 0};
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_sha_update_rows(lig_ctx* c, void* state, const void* codewords, size_t rows) {
+    CHECK_CTX(c);
+    auto it = c->sha.find(state);
+    if (it == c->sha.end()) FAIL(c, LIG_E_STATE, "sha_update: state was not initialised with lig_sha_init");
+    if (!rows) return LIG_OK;
+    if (!codewords) return LIG_E_ARG;
+    const size_t n_inst = it->second.first;
+    lig::launch_sha_update_rows(c->stream, (uint32_t*)state, n_inst, (const fr*)codewords, n_inst, rows, it->second.second);
+    it->second.second += rows;
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_sha_update(lig_ctx* c, void* state, const void* row) { return lig_sha_update_rows(c, state, row, 1); }
+int lig_sha_final(lig_ctx* c, void* state, void* digests) {
+    CHECK_CTX(c);
+    auto it = c->sha.find(state);
+    if (it == c->sha.end()) FAIL(c, LIG_E_STATE, "sha_final: state was not initialised with lig_sha_init");
+    if (!digests) return LIG_E_ARG;
+    lig::launch_sha_final(c->stream, (const uint32_t*)state, it->second.first, it->second.second, (uint32_t*)digests);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+size_t lig_merkle_nodes(size_t n_leaves) { size_t P = 1; while (P < n_leaves) P <<= 1; return 2 * P - 1; }
+int lig_merkle_build(lig_ctx* c, const void* leaves, size_t n_leaves, void* nodes) {
+    CHECK_CTX(c);
+    if (!leaves || !nodes || !n_leaves) return LIG_E_ARG;
+    lig::launch_merkle_build(c->stream, (const uint32_t*)leaves, n_leaves, (uint32_t*)nodes);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------- sampling
+int lig_sample_init(lig_ctx* c, const uint32_t* host_idx, size_t count) {
+    CHECK_CTX(c);
+    if (!host_idx || !count) return LIG_E_ARG;
+    for (size_t i = 0; i < count; i++) if (host_idx[i] >= c->n) FAIL(c, LIG_E_ARG, "sample_init: index out of range");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->sample_idx); c->sample_idx = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&c->sample_idx, count * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->sample_idx, host_idx, count * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->sample_count = count;
+    return LIG_OK;
+}
+int lig_gather_rows(lig_ctx* c, const void* codewords, size_t rows, void* out) {
+    CHECK_CTX(c);
+    if (!c->sample_idx) FAIL(c, LIG_E_STATE, "gather: lig_sample_init has not been called");
+    if (!rows) return LIG_OK;
+    if (!codewords || !out) return LIG_E_ARG;
+    lig::launch_gather_rows(c->stream, (const fr*)codewords, c->n, rows, c->sample_idx, (uint32_t)c->sample_count, (fr*)out);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_sample_gather(lig_ctx* c, const void* from, void* to, size_t slot) {
+    CHECK_CTX(c);
+    if (!to) return LIG_E_ARG;
+    return lig_gather_rows(c, from, 1, (fr*)to + slot * c->sample_count);
+}
+
+// ---------------------------------------------------------------- stage-2 accumulators
+int lig_rlc_rows(lig_ctx* c, const void* U, const void* Rn, size_t rows, const uint8_t* rc_host, void* code, void* lin,
+                 const uint32_t* triples_host, const uint8_t* rq_host, size_t n_triples, void* quad) {
+    CHECK_CTX(c);
+    if (!rows) return LIG_OK;
+    if (!U) return LIG_E_ARG;
+    if (code && !rc_host) FAIL(c, LIG_E_ARG, "rlc: code accumulator without coefficients");
+    if (n_triples && (!quad || !triples_host || !rq_host)) FAIL(c, LIG_E_ARG, "rlc: incomplete quadratic arguments");
+    std::vector<fr> sc(rows + n_triples);
+    for (size_t r = 0; r < rows && code; r++) {
+        if (!canonical32(rc_host + 32 * r)) FAIL(c, LIG_E_ARG, "rlc: coefficient not reduced mod p");
+        H::Fr v; std::memcpy(v.v, rc_host + 32 * r, 32); sc[r] = to_dev(H::to_mont(v));
+    }
+    for (size_t t = 0; t < n_triples; t++) {
+        if (!canonical32(rq_host + 32 * t)) FAIL(c, LIG_E_ARG, "rlc: coefficient not reduced mod p");
+        for (int q = 0; q < 3; q++) if (triples_host[3 * t + q] >= rows) FAIL(c, LIG_E_ARG, "rlc: triple row index out of range");
+        H::Fr v; std::memcpy(v.v, rq_host + 32 * t, 32); sc[rows + t] = to_dev(H::to_mont(v));
+    }
+    int rc = ensure_small(c, rows + n_triples);
+    if (rc != LIG_OK) return rc;
+    if (n_triples > c->tri_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->tri_dev); c->tri_dev = nullptr; c->tri_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->tri_dev, 3 * n_triples * sizeof(uint32_t)));
+        c->tri_cap = n_triples;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->small_dev, sc.data(), sc.size() * sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    if (n_triples) HIP_TRY(c, hipMemcpyAsync(c->tri_dev, triples_host, 3 * n_triples * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));    // sc / triples_host are host temporaries
+    lig::launch_rlc_rows(c->stream, (const fr*)U, (const fr*)Rn, rows, c->n, c->small_dev, (fr*)code, (fr*)lin, c->tri_dev,
+                         c->small_dev + rows, n_triples, (fr*)quad);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------- per-kernel timing of the dominant kernel
+int lig_profile_enable(lig_ctx* c, int on) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->prof_on = on != 0; c->prof_used = 0; c->prof_rows = 0;
+    return LIG_OK;
+}
+int lig_profile_read(lig_ctx* c, uint64_t* launches, uint64_t* rows, double* total_ms) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double ms = 0;
+    for (size_t i = 0; i < c->prof_used; i++) {
+        float t = 0;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->prof_events[i].first, c->prof_events[i].second));
+        ms += t;
+    }
+    if (launches) *launches = c->prof_used;
+    if (rows) *rows = c->prof_rows;
+    if (total_ms) *total_ms = ms;
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------- AES-CTR field sampler
+int lig_rng_fill(lig_ctx* c, const uint8_t* key32, uint64_t first_elem, void* out, size_t count) {
+    CHECK_CTX(c);
+    if (!key32 || (!out && count)) return LIG_E_ARG;
+    uint32_t rk[60];
+    lig::aes256_expand_host(key32, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    lig::launch_rng_fill(c->stream, c->rk_dev, first_elem, (fr*)out, count);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+}  // extern "C"

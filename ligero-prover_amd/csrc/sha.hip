@@ -1,0 +1,166 @@
+// sha.hip -- per-column SHA-256 commitment and GPU Merkle tree for gfx950.
+//
+// Replaces shader/sha256.wgsl (sha256_init/update/final, one instance per codeword column) and the host
+// merkle_tree::build_tree (include/zkp/merkle_tree.hpp:361-375).
+//
+// Layout.  The reference keeps a 300-byte context per instance with one message BYTE per u32 in global
+// memory (include/wgpu.hpp:63-68).  Here the chaining value lives in registers for a whole row batch and the
+// persistent state is 2 x 8 x n_inst u32, struct-of-arrays: h[8][n_inst] and pend[8][n_inst] (the buffered
+// element when an odd number of rows has been absorbed: a SHA block is exactly two 32-byte elements).
+// The number of absorbed rows is the same for all instances and is tracked by the host context.
+//
+// Message word order (shader/sha256.wgsl:148-163): every u32 limb is fed most-significant byte first, limbs
+// least-significant first, so the 16 message words of a block are exactly the 8 limbs of row 2q followed by
+// the 8 limbs of row 2q+1.  The leaf is the 8 state words stored as native u32 (:226-228).
+#include "kernels.hpp"
+
+namespace lig {
+
+__device__ __constant__ static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+// one compression; w[16] is consumed (rolling schedule in registers)
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t wi;
+        if (i < 16) wi = w[i];
+        else {
+            const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+            const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            w[i & 15] = wi;
+        }
+        const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + wi;
+        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+__global__ void k_sha_init(uint32_t* __restrict__ st, size_t n_inst) {
+    const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_inst; j += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { st[(size_t)i * n_inst + j] = iv[i]; st[(size_t)(8 + i) * n_inst + j] = 0; }
+    }
+}
+
+// absorb nrows rows (row r at rows + r*row_stride, element j = column j); rows_before = rows absorbed so far
+__global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, const fr* __restrict__ rows, size_t row_stride,
+                                  size_t nrows, uint64_t rows_before) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_inst) return;
+    uint32_t h[8], w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = st[(size_t)i * n_inst + j];
+    size_t r = 0;
+    if (rows_before & 1) {   // complete the pending half block with the first new row
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = st[(size_t)(8 + i) * n_inst + j];
+        fr e = fr_load(rows + j);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[8 + i] = e.v[i];
+        sha256_compress(h, w);
+        r = 1;
+    }
+    for (; r + 1 < nrows; r += 2) {
+        fr e0 = fr_load(rows + r * row_stride + j), e1 = fr_load(rows + (r + 1) * row_stride + j);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { w[i] = e0.v[i]; w[8 + i] = e1.v[i]; }
+        sha256_compress(h, w);
+    }
+    if (r < nrows) {         // odd tail: keep the element for the next call / final
+        fr e = fr_load(rows + r * row_stride + j);
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[(size_t)(8 + i) * n_inst + j] = e.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) st[(size_t)i * n_inst + j] = h[i];
+}
+
+// padding + length (shader/sha256.wgsl:180-224); does not modify the state
+__global__ void k_sha_final(const uint32_t* __restrict__ st, size_t n_inst, uint64_t rows_total, uint32_t* __restrict__ digests) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_inst) return;
+    uint32_t h[8], w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = st[(size_t)i * n_inst + j];
+    const uint64_t bits = rows_total * 256ull;
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    if (rows_total & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = st[(size_t)(8 + i) * n_inst + j];
+        w[8] = 0x80000000u;
+    } else {
+        w[0] = 0x80000000u;
+    }
+    w[14] = (uint32_t)(bits >> 32);
+    w[15] = (uint32_t)bits;
+    sha256_compress(h, w);
+    uint4* out = reinterpret_cast<uint4*>(digests + 8 * j);
+    out[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    out[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+void launch_sha_init(hipStream_t s, uint32_t* state, size_t n_inst) {
+    hipLaunchKernelGGL(k_sha_init, dim3((uint32_t)((n_inst + 255) / 256)), dim3(256), 0, s, state, n_inst);
+}
+void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const fr* rows, size_t row_stride, size_t nrows,
+                            uint64_t rows_before) {
+    if (!nrows) return;
+    hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + 63) / 64)), dim3(64), 0, s, state, n_inst, rows, row_stride,
+                       nrows, rows_before);
+}
+void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests) {
+    hipLaunchKernelGGL(k_sha_final, dim3((uint32_t)((n_inst + 63) / 64)), dim3(64), 0, s, state, n_inst, rows_total, digests);
+}
+
+// ---- Merkle tree: node[i] = SHA256(node[2i+1] || node[2i+2]) over canonical digest BYTES
+// (include/zkp/merkle_tree.hpp:361-375); one launch per level, heap layout, missing leaves = zero digests.
+__global__ void k_merkle_level(uint32_t* __restrict__ nodes, size_t first, size_t count) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const size_t i = first + t;
+    const uint4* ch = reinterpret_cast<const uint4*>(nodes + 8 * (2 * i + 1));
+    uint4 q[4] = {ch[0], ch[1], ch[2], ch[3]};
+    uint32_t w[16] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+                      q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = __builtin_bswap32(w[k]);   // bytes -> big-endian message words
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    sha256_compress(h, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0;
+    w[0] = 0x80000000u;
+    w[15] = 512;
+    sha256_compress(h, w);
+    uint4* out = reinterpret_cast<uint4*>(nodes + 8 * i);
+    out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+    out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+}
+
+void launch_merkle_build(hipStream_t s, const uint32_t* leaves, size_t n_leaves, uint32_t* nodes) {
+    size_t P = 1;
+    while (P < n_leaves) P <<= 1;
+    (void)hipMemsetAsync(nodes, 0, 32 * (2 * P - 1), s);
+    (void)hipMemcpyAsync(nodes + 8 * (P - 1), leaves, 32 * n_leaves, hipMemcpyDeviceToDevice, s);
+    for (size_t width = P / 2; width >= 1; width /= 2) {
+        const size_t first = width - 1;
+        hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)((width + 63) / 64)), dim3(64), 0, s, nodes, first, width);
+    }
+}
+
+}  // namespace lig

@@ -1,0 +1,302 @@
+"""GPU parity tests (-m gpu): every C-ABI entry point of liblig_hip.so against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at the full k=8192/n=32768 size -- through
+size-independent properties (decode(encode(m)) = m, linearity, chunk-invariance of the column hash).
+Bit-exact everywhere: the path is integer arithmetic mod p and SHA-256."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hip_lib
+import oracle_lib as ol
+import pydef
+
+pytestmark = pytest.mark.gpu
+P = pydef.P
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    return hip_lib.load()
+
+
+@pytest.fixture(scope="module")
+def ctx512(amd):
+    c = amd.Context(320, 512, 2048)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx8192(amd):
+    c = amd.Context(8000, 8192, 32768)
+    yield c
+    c.close()
+
+
+def edge_mix(rng, count):
+    x = ol.rand_field(rng, count)
+    edge = ol.to_limbs([0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 253, (1 << 253) + 12345, 0xFFFFFFFF, 1 << 32])
+    x[:len(edge)] = edge
+    return x
+
+
+def test_eltwise_all_ops(ctx512):
+    c = ctx512
+    rng = np.random.default_rng(11)
+    N = 4099                                   # ragged: not a multiple of the block size
+    x, y, o = edge_mix(rng, N), edge_mix(rng, N)[::-1].copy(), edge_mix(rng, N)
+    y[5] = 0                                   # division by zero -> 0
+    dx, dy = c.upload(x), c.upload(y)
+    scalar = int.from_bytes(hashlib.sha256(b"c").digest(), "little") % P
+    for op in range(13):
+        do = c.upload(o)
+        want = o.copy()
+        ol.eltwise(op, x, y, want, scalar=scalar, bit=200)
+        c.eltwise(op, dx, dy, do, N, scalar=scalar, bit=200)
+        got = c.download(do, (N, 8))
+        assert np.array_equal(got, want), "op %d" % op
+        c.free(do)
+    # aliasing: out == x
+    want = x.copy()
+    ol.eltwise(6, x, y, want)
+    c.eltwise("MUL", dx, dy, dx, N)
+    assert np.array_equal(c.download(dx, (N, 8)), want)
+    # empty input is a no-op; non-canonical scalar is rejected
+    c.eltwise("ADD", dx, dy, dx, 0)
+    with pytest.raises(Exception):
+        c.eltwise("MUL_CONST", dx, dy, dx, N, scalar=P)
+
+
+def test_powmod_reference_kats(ctx512):
+    """tests/webgpu/test_powmod.cpp:58-197 on the HIP backend (N = 8192)"""
+    c = ctx512
+    N = 8192
+    exp = np.arange(N, dtype=np.uint32)
+    one, zero = ol.to_limbs([1] * N), ol.to_limbs([0] * N)
+    dexp, done, dzero, dout = c.upload(exp), c.upload(one), c.upload(zero), c.malloc(32 * N)
+    c.powmod(7, dexp, dzero, dout, N)
+    assert not c.download(dout, (N, 8)).any()
+    c.powmod(1, dexp, done, dout, N)
+    assert ol.from_limbs(c.download(dout, (N, 8))) == [1] * N
+    c.powmod(7, dexp, done, dout, N)
+    assert ol.from_limbs(c.download(dout, (N, 8))) == [pow(7, i, P) for i in range(N)]
+    dexp2 = c.upload((np.arange(N, dtype=np.uint64) + (1 << 16)).astype(np.uint32))
+    dcoef = c.upload(ol.to_limbs([P - 1] * N))
+    c.powmod(P - 1, dexp2, dcoef, dout, N)
+    assert ol.from_limbs(c.download(dout, (N, 8))) == [pow(P - 1, (1 << 16) + i + 1, P) for i in range(N)]
+    c.powmod(7, dexp, done, dout, N)
+    for _ in range(9):
+        c.powmod(7, dexp, done, dout, N, add=True)
+    assert ol.from_limbs(c.download(dout, (N, 8))) == [10 * pow(7, i, P) % P for i in range(N)]
+
+
+def test_encode_golden_k512(ctx512):
+    g = gold("encode_k512.json")
+    c = ctx512
+    k, n = 512, 2048
+    rows = ol.rng_fill(bytes.fromhex(g["key"]), 0, 3 * k).reshape(3, k, 8)
+    h256 = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    # single-buffer API, in place
+    buf = c.malloc(32 * n)
+    for r in range(3):
+        c.L.lig_write_clear(c.h, buf, 32 * n, rows[r].ctypes.data_as(C.c_void_p), 32 * k)
+        c.encode(buf)
+        assert h256(c.download(buf, (n, 8))) == g["cw_sha256"][r]
+    # batched API
+    dm, dc = c.upload(rows), c.malloc(3 * 32 * n)
+    c.encode_rows(dm, dc, 3)
+    cws = c.download(dc, (3, n, 8))
+    assert [h256(cws[r]) for r in range(3)] == g["cw_sha256"]
+    # mask-row encode and decode
+    m2 = np.zeros((n, 8), dtype=np.uint32); m2[:2 * k] = np.concatenate([rows[0], rows[1]])
+    c.write(buf, m2); c.encode_2k(buf)
+    assert h256(c.download(buf, (n, 8))) == g["cw2k_sha256"]
+    c.write(buf, cws[0]); c.decode(buf)
+    assert h256(c.download(buf, (n, 8))) == g["decode0_sha256"]
+    # column hash + merkle
+    st, dl = c.sha_state(n), c.malloc(32 * n)
+    c.sha_update_rows(st, dc, 3)
+    c.sha_final(st, dl)
+    leaves = c.download(dl, (n, 32), dtype=np.uint8)
+    assert leaves[0].tobytes().hex() == g["leaf0"] and hashlib.sha256(leaves.tobytes()).hexdigest() == g["leaves_sha256"]
+    nodes = c.merkle_build(dl, n)
+    assert c.download(nodes, (32,), dtype=np.uint8).tobytes().hex() == g["root"]
+
+
+@pytest.mark.parametrize("k", [512, 1024, 2048, 4096, 8192])
+def test_transforms_vs_oracle(amd, k):
+    """fast path (k = 512/2048/8192) and generic radix-2 path (1024/4096) against the oracle"""
+    n, l = 4 * k, k - 192
+    c = amd.Context(l, k, n)
+    o = ol.Ctx(l, k, n)
+    rng = np.random.default_rng(k)
+    try:
+        rows = 5
+        msgs = np.stack([edge_mix(rng, k) for _ in range(rows)])
+        msgs[1] = 0                                      # all-zero row
+        msgs[2] = ol.to_limbs([P - 1] * k)               # all-max row
+        dm, dc = c.upload(msgs), c.malloc(rows * 32 * n)
+        c.encode_rows(dm, dc, rows)
+        got = c.download(dc, (rows, n, 8))
+        want = o.encode_rows(msgs, threads=4)
+        assert np.array_equal(got, want)
+        assert not got[1].any()
+        buf = c.malloc(32 * n)
+        # every transform size/direction of the executor surface
+        for which, size in ((0, k), (1, 2 * k), (2, n)):
+            for inverse in (False, True):
+                x = np.zeros((n, 8), dtype=np.uint32); x[:size] = edge_mix(rng, size)
+                c.write(buf, x); c.ntt(buf, which, inverse)
+                res = c.download(buf, (n, 8))
+                assert np.array_equal(res[:size], o.ntt(which, inverse, x[:size])) and np.array_equal(res[size:], x[size:])
+        m2 = np.zeros((n, 8), dtype=np.uint32); m2[:2 * k] = edge_mix(rng, 2 * k)
+        c.write(buf, m2); c.encode_2k(buf)
+        assert np.array_equal(c.download(buf, (n, 8)), o.encode_2k(m2[:2 * k]))
+        c.write(buf, want[0]); c.decode(buf)
+        dec = c.download(buf, (n, 8))
+        assert np.array_equal(dec, o.decode(want[0]))
+        assert np.array_equal(dec[:k], msgs[0]) and not dec[k:].any()
+        # decode of a non-codeword (accumulator-like): raw coefficients stay in [k,n)
+        x = edge_mix(rng, n)
+        c.write(buf, x); c.decode(buf)
+        assert np.array_equal(c.download(buf, (n, 8)), o.decode(x))
+    finally:
+        c.close()
+
+
+def test_full_size_properties(ctx8192):
+    """k=8192: round trip, linearity and batch-size invariance on 300 rows (sizes the oracle does not sweep)"""
+    c = ctx8192
+    k, n, rows = 8192, 32768, 300
+    key = hashlib.sha256(b"props").digest()
+    dm, dc = c.malloc(rows * 32 * k), c.malloc(rows * 32 * n)
+    c.rng_fill(key, 0, dm, rows * k)
+    c.encode_rows(dm, dc, rows)
+    # (a) rows 0..2 against the oracle
+    msgs = c.download(dm, (3, k, 8))
+    assert np.array_equal(msgs, ol.rng_fill(key, 0, 3 * k).reshape(3, k, 8))
+    o = ol.Ctx(8000, k, n)
+    assert np.array_equal(c.download(dc, (3, n, 8)), o.encode_rows(msgs, threads=3))
+    # (b) row 299 encoded alone (different launch geometry) equals its batched encoding
+    buf = c.malloc(32 * n)
+    c.L.lig_clear(c.h, buf, 32 * n)
+    c.L.lig_copy(c.h, buf, C.c_void_p(dm.value + 299 * 32 * k), 32 * k)
+    c.encode(buf)
+    last = c.download(dc, (n, 8), offset=299 * 32 * n)
+    assert np.array_equal(c.download(buf, (n, 8)), last)
+    # (c) decode(encode(m)) = m || 0
+    c.decode(buf)
+    dec = c.download(buf, (n, 8))
+    assert np.array_equal(dec[:k], c.download(dm, (k, 8), offset=299 * 32 * k)) and not dec[k:].any()
+    # (d) linearity: Enc(m0 + m1) = Enc(m0) + Enc(m1)
+    ds, dsum = c.malloc(32 * n), c.malloc(32 * n)
+    c.L.lig_clear(c.h, ds, 32 * n)
+    c.eltwise("ADD", dm, C.c_void_p(dm.value + 32 * k), ds, k)
+    c.encode(ds)
+    c.eltwise("ADD", dc, C.c_void_p(dc.value + 32 * n), dsum, n)
+    assert np.array_equal(c.download(ds, (n, 8)), c.download(dsum, (n, 8)))
+    # (e) column hash is invariant to how the rows are chunked (odd/even splits exercise the pending half block)
+    leaves = []
+    for split in ([300], [1, 299], [7, 2, 1, 290], [150, 150]):
+        st, dl = c.sha_state(n), c.malloc(32 * n)
+        off = 0
+        for cnt in split:
+            c.sha_update_rows(st, C.c_void_p(dc.value + off * 32 * n), cnt)
+            off += cnt
+        c.sha_final(st, dl)
+        c.sha_final(st, dl)                      # final does not consume the state
+        leaves.append(c.download(dl, (n, 32), dtype=np.uint8))
+        c.free(st); c.free(dl)
+    assert all(np.array_equal(leaves[0], x) for x in leaves[1:])
+    # spot-check 64 leaves against hashlib over the downloaded columns
+    cols = list(range(0, n, n // 64))
+    cw_host = c.download(dc, (rows, n, 8))
+    for j in cols:
+        assert leaves[0][j].tobytes() == pydef.leaf(ol.from_limbs(cw_host[:, j]))
+    # Merkle root vs the oracle tree over the same leaves
+    dl = c.upload(leaves[0])
+    nodes = c.merkle_build(dl, n)
+    got_nodes = c.download(nodes, (2 * n - 1, 32), dtype=np.uint8)
+    assert np.array_equal(got_nodes, ol.merkle_build(leaves[0]))
+
+
+def test_sha_small_and_ragged(ctx512):
+    c = ctx512
+    rng = np.random.default_rng(5)
+    for ninst, rows in ((1, 1), (37, 2), (192, 5), (2048, 1)):
+        data = np.stack([ol.rand_field(rng, ninst) for _ in range(rows)])
+        dd, st, dl = c.upload(data), c.sha_state(ninst), c.malloc(32 * ninst)
+        for r in range(rows):                    # one row at a time: the reference's sha256_digest_update
+            c.check(c.L.lig_sha_update(c.h, st, C.c_void_p(dd.value + r * 32 * ninst)))
+        c.sha_final(st, dl)
+        assert np.array_equal(c.download(dl, (ninst, 32), dtype=np.uint8), ol.colsha(data))
+        # zero rows absorbed: SHA-256 of the empty string, word-swapped
+        st0 = c.sha_state(ninst)
+        c.sha_final(st0, dl)
+        e = hashlib.sha256(b"").digest()
+        assert c.download(dl, (ninst, 32), dtype=np.uint8)[0].tobytes() == b"".join(e[4 * i:4 * i + 4][::-1] for i in range(8))
+    # non power-of-two leaf count is zero padded
+    leaves = rng.integers(0, 256, size=(37, 32), dtype=np.uint8)
+    nodes = c.merkle_build(c.upload(leaves), 37)
+    assert np.array_equal(c.download(nodes, (127, 32), dtype=np.uint8), ol.merkle_build(leaves))
+    # unknown state is an error, not a crash
+    with pytest.raises(Exception):
+        c.sha_update_rows(c.malloc(64), c.malloc(64), 1)
+
+
+def test_rng_fill_vs_oracle_and_openssl(ctx512):
+    c = ctx512
+    for v in gold("aes_ctr.json")["vectors"]:
+        key = bytes.fromhex(v["key"])
+        out = c.malloc(32 * 600)
+        c.rng_fill(key, 0, out, 600)
+        got = c.download(out, (600, 8))
+        assert [hex(e) for e in ol.from_limbs(got[:8])] == v["field_first8"]
+        assert [hex(e) for e in ol.from_limbs(got[511:514])] == v["field_511_512_513"]
+        assert np.array_equal(got, ol.rng_fill(key, 0, 600))
+        c.rng_fill(key, (1 << 33) + 5, out, 100)            # block counter beyond 32 bits
+        assert np.array_equal(c.download(out, (100, 8)), ol.rng_fill(key, (1 << 33) + 5, 100))
+
+
+def test_rlc_and_gather_vs_oracle(ctx512):
+    c = ctx512
+    n, rows, t = 2048, 9, 192
+    rng = np.random.default_rng(9)
+    U = np.stack([edge_mix(rng, n) for _ in range(rows)])
+    Rn = np.stack([edge_mix(rng, n) for _ in range(rows)])
+    acc = [edge_mix(rng, n) for _ in range(3)]
+    rc = [int(v) for v in ol.from_limbs(ol.rand_field(rng, rows))]
+    triples = [(0, 1, 2), (4, 5, 6)]
+    rq = [int(v) for v in ol.from_limbs(ol.rand_field(rng, 2))]
+    code, lin, quad = (a.copy() for a in acc)
+    for r in range(rows):                     # the reference's per-row sequence (nonbatch_context.hpp:756-780)
+        ol.eltwise(10, U[r], None, code, scalar=rc[r])
+        ol.eltwise(9, U[r], Rn[r], lin)
+    for (x, y, z), q in zip(triples, rq):
+        t1, t2 = np.zeros((n, 8), np.uint32), np.zeros((n, 8), np.uint32)
+        ol.eltwise(6, U[x], U[y], t1); ol.eltwise(1, t1, U[z], t2); ol.eltwise(10, t2, None, quad, scalar=q)
+    dU, dR = c.upload(U), c.upload(Rn)
+    dc, dl, dq = (c.upload(a) for a in acc)
+    c.rlc_rows(dU, dR, rows, rc, dc, dl, triples, rq, dq)
+    assert np.array_equal(c.download(dc, (n, 8)), code)
+    assert np.array_equal(c.download(dl, (n, 8)), lin)
+    assert np.array_equal(c.download(dq, (n, 8)), quad)
+    idx = np.sort(rng.choice(n, t, replace=False)).astype(np.uint32)
+    c.sample_init(idx)
+    out = c.malloc(rows * t * 32)
+    c.gather_rows(dU, rows, out)
+    assert np.array_equal(c.download(out, (rows, t, 8)), U[:, idx])
+    c.check(c.L.lig_sample_gather(c.h, C.c_void_p(dU.value + 3 * 32 * n), out, 2))   # reference-style: one row into slot 2
+    assert np.array_equal(c.download(out, (t, 8), offset=2 * t * 32), U[3, idx])
+    with pytest.raises(Exception):
+        c.sample_init(np.array([n], dtype=np.uint32))
