@@ -1,0 +1,168 @@
+// fr29.hpp -- the arithmetic core of the hot kernels: BN254 Fr in 9 limbs of 29 bits (redundant / lazy).
+//
+// Why 29-bit limbs on gfx950 (measured with tools/ubench_valu.hip, profiles/r01_ubench_valu_issue_rates.txt):
+// v_mad_u64_u32 (32x32+64 -> 64) issues at HALF rate, and so do the carry instructions v_add_co/v_addc and the
+// 64-bit v_lshl_add_u64, while plain v_add_u32 / v_and / v_mov are full rate.  A 8 x 32-bit Montgomery product
+// therefore spends more issue slots on carries and register moves (~490) than on its 136 multiplies.  With
+// 29-bit limbs a whole column of 18 partial products (9 of a*b, 9 of m*p) accumulates in one 64-bit register
+// pair with NO carry handling: the product is a chain of v_mad_u64_u32 whose addend is the previous result,
+// plus one 64-bit shift per column.  Additions are 9 independent v_add_u32, subtractions add a precomputed
+// borrow-proof multiple of p, and limbs are renormalised only once per radix-4 step.
+//
+//   value(x) = sum_i x.v[i] * 2^(29 i);  "normalised": v[0..7] < 2^29;  "lazy": v[i] < 2^32, value < 2^261
+//   Montgomery radix R' = 2^261: mont(a, w*R') = a*w  (twiddles are stored as w*R' mod p, normalised)
+//
+// HBM / proof format stays the reference's canonical 8 x u32 (include/ligetron/webgpu/device_bignum.hpp:76-86):
+// unpack29 / pack29 convert at kernel boundaries.  Replaces shader/bigint.wgsl.in + shader/bn254fr.wgsl.in.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fr.hpp"
+#include "fr29_consts.hpp"
+
+namespace lig {
+
+struct f29 {
+    uint32_t v[9];
+};
+// table entry: 9 limbs padded to 48 bytes so that it is fetched with three 16-byte loads
+struct alignas(16) f29s {
+    uint32_t v[12];
+};
+
+__device__ __forceinline__ f29 f29_load_tab(const f29s* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    const uint32_t c = reinterpret_cast<const uint32_t*>(p)[8];
+    f29 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c;
+    return r;
+}
+
+// canonical / < 2^256 value in 8 x u32  ->  normalised 29-bit limbs
+__device__ __forceinline__ f29 unpack29(const fr& w) {
+    f29 r;
+    r.v[0] = w.v[0] & F29_MASK;
+    r.v[1] = __builtin_amdgcn_alignbit(w.v[1], w.v[0], 29) & F29_MASK;
+    r.v[2] = __builtin_amdgcn_alignbit(w.v[2], w.v[1], 26) & F29_MASK;
+    r.v[3] = __builtin_amdgcn_alignbit(w.v[3], w.v[2], 23) & F29_MASK;
+    r.v[4] = __builtin_amdgcn_alignbit(w.v[4], w.v[3], 20) & F29_MASK;
+    r.v[5] = __builtin_amdgcn_alignbit(w.v[5], w.v[4], 17) & F29_MASK;
+    r.v[6] = __builtin_amdgcn_alignbit(w.v[6], w.v[5], 14) & F29_MASK;
+    r.v[7] = __builtin_amdgcn_alignbit(w.v[7], w.v[6], 11) & F29_MASK;
+    r.v[8] = w.v[7] >> 8;
+    return r;
+}
+// normalised limbs, value < 2^256  ->  8 x u32
+__device__ __forceinline__ fr pack29(const f29& x) {
+    fr w;
+    w.v[0] = x.v[0] | (x.v[1] << 29);
+    w.v[1] = (x.v[1] >> 3) | (x.v[2] << 26);
+    w.v[2] = (x.v[2] >> 6) | (x.v[3] << 23);
+    w.v[3] = (x.v[3] >> 9) | (x.v[4] << 20);
+    w.v[4] = (x.v[4] >> 12) | (x.v[5] << 17);
+    w.v[5] = (x.v[5] >> 15) | (x.v[6] << 14);
+    w.v[6] = (x.v[6] >> 18) | (x.v[7] << 11);
+    w.v[7] = (x.v[7] >> 21) | (x.v[8] << 8);
+    return w;
+}
+
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+
+// Montgomery product a*b/2^261 mod p.  a: lazy, limbs < 1.25 * 2^31 (top limb < 2^31); b: normalised, < p.
+// Result: normalised limbs, value < a*p/2^261 + p  (< 1.2 p for value(a) < 32 p).
+// 81 + 81 v_mad_u64_u32 chained through one 64-bit accumulator, 9 v_mul_lo_u32, 17 v_lshrrev_b64.
+// Column bound: 9 * (1.25*2^31 * 2^29) + 9 * 2^58 + carry < 2^64.
+__device__ __forceinline__ f29 f29_montmul(const f29& a, const f29& b) {
+    uint32_t m[9];
+    f29 t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+#pragma unroll
+        for (int i = 0; i <= c; i++) acc = mad64(a.v[i], b.v[c - i], acc);
+#pragma unroll
+        for (int i = 0; i < c; i++) acc = mad64(m[i], F29_P(c - i), acc);
+        m[c] = ((uint32_t)acc * F29_N0) & F29_MASK;
+        acc = mad64(m[c], F29_P(0), acc);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int c = 9; c < 17; c++) {
+#pragma unroll
+        for (int i = c - 8; i <= 8; i++) acc = mad64(a.v[i], b.v[c - i], acc);
+#pragma unroll
+        for (int i = c - 8; i <= 8; i++) acc = mad64(m[i], F29_P(c - i), acc);
+        t.v[c - 9] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    t.v[8] = (uint32_t)acc;
+    return t;
+}
+
+// limb-wise lazy add
+__device__ __forceinline__ f29 f29_add(const f29& a, const f29& b) {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+// a - b + K with K a borrow-proof multiple of p (every K limb >= the matching limb of b, value(K) >= value(b))
+#define F29_SUBK(r, a, b, KMAC)                                              \
+    do {                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 9; i_++)(r).v[i_] = (a).v[i_] + (KMAC(i_) - (b).v[i_]); \
+    } while (0)
+__device__ __forceinline__ f29 f29_sub_k2(const f29& a, const f29& b) { f29 r; F29_SUBK(r, a, b, F29_K2P_C1); return r; }   // b normalised, < 2p
+__device__ __forceinline__ f29 f29_sub_k4(const f29& a, const f29& b) { f29 r; F29_SUBK(r, a, b, F29_K4P_C2); return r; }   // b limbs < 2^30, < 4p
+__device__ __forceinline__ f29 f29_sub_k8(const f29& a, const f29& b) { f29 r; F29_SUBK(r, a, b, F29_K8P_C4); return r; }   // b limbs < 2^31, < 8p
+__device__ __forceinline__ f29 f29_sub_k16(const f29& a, const f29& b) { f29 r; F29_SUBK(r, a, b, F29_K16P_C2); return r; } // b limbs < 2^30, < 16p
+
+// parallel carry pass: limbs < 2^32 -> limbs < 2^29 + 8 (top limb absorbs), value unchanged
+__device__ __forceinline__ f29 f29_qnorm(const f29& a) {
+    f29 r;
+    r.v[0] = a.v[0] & F29_MASK;
+#pragma unroll
+    for (int i = 1; i < 8; i++) r.v[i] = (a.v[i] & F29_MASK) + (a.v[i - 1] >> 29);
+    r.v[8] = a.v[8] + (a.v[7] >> 29);
+    return r;
+}
+
+// V mod p approximately: lazy value < 2^261 (limbs < 2^32) -> normalised, value in [0, 2p).
+// q = floor(V/p) or one less from the top ~30 bits; V - q*p is formed as (V + q*(2^261 - p)) mod 2^261 in one
+// 64-bit carry chain (18 v_mad_u64_u32 + 9 shifts).
+__device__ __forceinline__ f29 f29_reduce_2p(const f29& a) {
+    const uint32_t hh = (a.v[8] << 3) + (a.v[7] >> 26);                       // ~ V / 2^229 (never above)
+    const uint32_t q = (uint32_t)(((uint64_t)hh * F29_RECIP229) >> 56);       // <= floor(V / p)
+    f29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc = mad64(a.v[i], 1u, acc);
+        acc = mad64(q, F29_PBAR(i), acc);
+        r.v[i] = (uint32_t)acc & F29_MASK;        // the top limb mask drops q * 2^261
+        acc >>= 29;
+    }
+    return r;
+}
+// exact canonical residue: lazy value < 2^261 -> normalised limbs, value in [0, p)
+__device__ __forceinline__ f29 f29_canon(const f29& a) {
+    const f29 r = f29_reduce_2p(a);
+    f29 d;
+    int32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t s = (int32_t)r.v[i] - (int32_t)F29_P(i) + br;
+        d.v[i] = (uint32_t)s & F29_MASK;
+        br = s >> 29;                              // arithmetic: 0 or -1
+    }
+    // top limb: a negative final value shows as br = -1 after limb 8 (limb 8 of r < 2^25)
+    f29 o;
+    const bool neg = br < 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.v[i] = neg ? r.v[i] : d.v[i];
+    return o;
+}
+
+}  // namespace lig

@@ -16,17 +16,19 @@ struct NttPlan {
     fr ninv;              // N^-1 * R
 };
 
-// Tables of the fused row-encode path (ntt_encode.hip); see that file for the decomposition.
+// Tables of the batched row-encode path (ntt_encode.hip), all in 9 x 29-bit limbs, Montgomery radix 2^261.
+struct f29s;
 struct EncodePlan {
     uint32_t k = 0, n = 0, log2k = 0;
     uint32_t A = 0, B = 0, log2B = 0;      // k = A * B, A = 8 outer radix, B = tile length
-    fr* tw_b = nullptr;       // per-stage twiddles of the size-B forward transform (root psi^A, psi = w_n^4): B-1 entries
-    fr* tw_b_inv = nullptr;   // same for the inverse size-B transform (root w_k^-A)
-    fr* seam_inv = nullptr;   // w_k^(-i2*j1) for the INTT seam, [A][B]
-    fr* twist = nullptr;      // k^-1 * w_n^(r*i), [4][k], i in natural order
-    fr* seam_fwd = nullptr;   // psi^(i1*j2), [A][B]
-    fr* w8_inv = nullptr;     // powers of w_k^-(k/8): radix-8 constants (inverse), 8 entries
-    fr* w8_fwd = nullptr;     // powers of psi^(k/8): radix-8 constants (forward), 8 entries
+    f29s* tw_b = nullptr;       // DIT stage twiddles of the size-B forward transform (root psi^8, psi = w_n^4): span M' at M'/2-1
+    f29s* tw_b_inv = nullptr;   // same for the inverse size-B transform (root w_k^-8)
+    f29s* seam_inv = nullptr;   // w_k^(-i2*j1), [8][B]
+    f29s* twist = nullptr;      // w_n^(r*(j1 + 8*i2)), [3][8][B] for r = 1..3
+    f29s* seam_fwd = nullptr;   // psi^(i1*q2), [8][B]
+    f29s* w8_inv = nullptr;     // powers of w_k^-(k/8): radix-8 constants (inverse), 8 entries
+    f29s* w8_fwd = nullptr;     // powers of psi^(k/8): radix-8 constants (forward), 8 entries
+    f29s* kinv = nullptr;       // k^-1, 1 entry
 };
 
 // ---- ntt_generic.hip

@@ -13,6 +13,7 @@
 #include "../../include/lig_hip.h"
 #include "host_field.hpp"
 #include "kernels.hpp"
+#include "fr29.hpp"
 
 namespace lig {
 void aes_upload_tables();
@@ -89,6 +90,37 @@ static std::vector<H::Fr> powers_mont(const H::Fr& base, size_t count) {
     return out;
 }
 
+// ---- 29-bit-limb tables of the batched encode path (fr29.hpp): entry = x * 2^261 mod p as 9 limbs, 48-byte stride
+static const H::Fr R261 = {{0x2fd4e1568fffff57ull, 0x75bba827a494b01aull, 0x5301fa84819caa80ull, 0x0dc83629563d4475ull}};   // 2^261 mod p
+static lig::f29s to_f29s(const H::Fr& plain) {
+    const H::Fr m = H::mul(plain, R261);
+    lig::f29s o;
+    std::memset(&o, 0, sizeof o);
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t v = m.v[w] >> sh;
+        if (sh > 35 && w < 3) v |= m.v[w + 1] << (64 - sh);
+        o.v[i] = (uint32_t)(i < 8 ? (v & 0x1FFFFFFFull) : v);
+    }
+    return o;
+}
+static int upload29(lig_ctx* c, const std::vector<lig::f29s>& host, lig::f29s** dev) {
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, host.size() * sizeof(lig::f29s)));
+    c->owned.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, host.data(), host.size() * sizeof(lig::f29s), hipMemcpyHostToDevice));
+    *dev = (lig::f29s*)p;
+    return LIG_OK;
+}
+// plain powers base^0 .. base^(count-1)
+static std::vector<H::Fr> powers_plain(const H::Fr& base, size_t count) {
+    std::vector<H::Fr> out(count);
+    const H::Fr bm = H::to_mont(base);
+    H::Fr cur = H::R1;
+    for (size_t i = 0; i < count; i++) { out[i] = H::from_mont(cur); cur = H::montmul(cur, bm); }
+    return out;
+}
+
 static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
     lig::EncodePlan& ep = c->ep;
     const uint32_t k = c->k, A = 8, B = k / 8;
@@ -96,48 +128,46 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
     const H::Fr wk_inv = H::inv(wk);
     const H::Fr psi = H::pow_u64(w4k, 4);                       // order k
     int rc;
-    // per-stage twiddles of the size-B transforms: stage of span M at offset B-M, rho^(idx*B/M)
+    // DIT stage twiddles of the size-B transforms: the stage of span M starts at entry M/2-1, rho^(j*B/M), j < M/2
     auto stage_table = [&](const H::Fr& rho) {
-        std::vector<H::Fr> pw = powers_mont(rho, B / 2);
-        std::vector<fr> t(B);                                   // B-1 used
-        for (uint32_t M = B; M >= 2; M >>= 1)
-            for (uint32_t idx = 0; idx < M / 2; idx++) t[(B - M) + idx] = to_dev(pw[(size_t)idx * (B / M)]);
-        t[B - 1] = to_dev(H::R1);
+        std::vector<H::Fr> pw = powers_plain(rho, B / 2);
+        std::vector<lig::f29s> t(B);                            // B-1 used
+        for (uint32_t M = 2; M <= B; M <<= 1)
+            for (uint32_t j = 0; j < M / 2; j++) t[(M / 2 - 1) + j] = to_f29s(pw[(size_t)j * (B / M)]);
+        t[B - 1] = to_f29s(H::from_u64(1));
         return t;
     };
-    if ((rc = upload(c, stage_table(H::pow_u64(wk_inv, A)), &ep.tw_b_inv)) != LIG_OK) return rc;
-    if ((rc = upload(c, stage_table(H::pow_u64(psi, A)), &ep.tw_b)) != LIG_OK) return rc;
+    if ((rc = upload29(c, stage_table(H::pow_u64(wk_inv, A)), &ep.tw_b_inv)) != LIG_OK) return rc;
+    if ((rc = upload29(c, stage_table(H::pow_u64(psi, A)), &ep.tw_b)) != LIG_OK) return rc;
     // seams: seam_inv[j1][i2] = w_k^(-i2*j1), seam_fwd[i1][q2] = psi^(i1*q2)
     {
-        std::vector<fr> si((size_t)A * B), sf((size_t)A * B);
+        std::vector<lig::f29s> si((size_t)A * B), sf((size_t)A * B);
         for (uint32_t j1 = 0; j1 < A; j1++) {
-            std::vector<H::Fr> a = powers_mont(H::pow_u64(wk_inv, j1), B), b = powers_mont(H::pow_u64(psi, j1), B);
-            for (uint32_t i = 0; i < B; i++) { si[(size_t)j1 * B + i] = to_dev(a[i]); sf[(size_t)j1 * B + i] = to_dev(b[i]); }
+            std::vector<H::Fr> a = powers_plain(H::pow_u64(wk_inv, j1), B), b = powers_plain(H::pow_u64(psi, j1), B);
+            for (uint32_t i = 0; i < B; i++) { si[(size_t)j1 * B + i] = to_f29s(a[i]); sf[(size_t)j1 * B + i] = to_f29s(b[i]); }
         }
-        if ((rc = upload(c, si, &ep.seam_inv)) != LIG_OK) return rc;
-        if ((rc = upload(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
+        if ((rc = upload29(c, si, &ep.seam_inv)) != LIG_OK) return rc;
+        if ((rc = upload29(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
     }
-    // twist[r][j1][i2] = k^-1 * w_n^(r*(j1 + 8*i2))
+    // twist[r-1][j1][i2] = w_n^(r*(j1 + 8*i2)), r = 1..3
     {
-        std::vector<fr> tw((size_t)4 * k);
-        const H::Fr kinv_m = H::to_mont(H::inv(H::from_u64(k)));
-        for (uint32_t r = 0; r < 4; r++) {
-            std::vector<H::Fr> pw = powers_mont(H::pow_u64(w4k, r), k);    // (w_n^r)^i, Montgomery form
+        std::vector<lig::f29s> tw((size_t)3 * k);
+        for (uint32_t r = 1; r < 4; r++) {
+            std::vector<H::Fr> pw = powers_plain(H::pow_u64(w4k, r), k);
             for (uint32_t j1 = 0; j1 < A; j1++)
-                for (uint32_t i2 = 0; i2 < B; i2++) {
-                    const H::Fr v = H::montmul(pw[j1 + (size_t)A * i2], kinv_m);     // (x*R)(kinv*R)/R = x*kinv*R
-                    tw[((size_t)r * A + j1) * B + i2] = to_dev(v);
-                }
+                for (uint32_t i2 = 0; i2 < B; i2++) tw[((size_t)(r - 1) * A + j1) * B + i2] = to_f29s(pw[j1 + (size_t)A * i2]);
         }
-        if ((rc = upload(c, tw, &ep.twist)) != LIG_OK) return rc;
+        if ((rc = upload29(c, tw, &ep.twist)) != LIG_OK) return rc;
     }
-    // radix-8 constants: w8[i] = w^i, w = w_k^(-k/8) (inverse) / psi^(k/8) (forward)
+    // radix-8 constants: w8[i] = w^i, w = w_k^(-k/8) (inverse) / psi^(k/8) (forward); k^-1
     {
-        std::vector<H::Fr> a = powers_mont(H::pow_u64(wk_inv, B), 8), b = powers_mont(H::pow_u64(psi, B), 8);
-        std::vector<fr> da(8), db(8);
-        for (int i = 0; i < 8; i++) { da[i] = to_dev(a[i]); db[i] = to_dev(b[i]); }
-        if ((rc = upload(c, da, &ep.w8_inv)) != LIG_OK) return rc;
-        if ((rc = upload(c, db, &ep.w8_fwd)) != LIG_OK) return rc;
+        std::vector<H::Fr> a = powers_plain(H::pow_u64(wk_inv, B), 8), b = powers_plain(H::pow_u64(psi, B), 8);
+        std::vector<lig::f29s> da(8), db(8), ki(1);
+        for (int i = 0; i < 8; i++) { da[i] = to_f29s(a[i]); db[i] = to_f29s(b[i]); }
+        ki[0] = to_f29s(H::inv(H::from_u64(k)));
+        if ((rc = upload29(c, da, &ep.w8_inv)) != LIG_OK) return rc;
+        if ((rc = upload29(c, db, &ep.w8_fwd)) != LIG_OK) return rc;
+        if ((rc = upload29(c, ki, &ep.kinv)) != LIG_OK) return rc;
     }
     return LIG_OK;
 }
@@ -236,7 +266,7 @@ static int ensure_scratch(lig_ctx* c, size_t rows) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z);
     c->scratch_y = c->scratch_z = nullptr; c->scratch_rows = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->scratch_y, rows * (size_t)c->k * sizeof(fr)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch_y, 2 * rows * (size_t)c->k * sizeof(fr)));   // Y and C
     HIP_TRY(c, hipMalloc((void**)&c->scratch_z, rows * (size_t)c->n * sizeof(fr)));
     c->scratch_rows = rows;
     return LIG_OK;

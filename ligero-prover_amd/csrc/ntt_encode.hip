@@ -1,231 +1,218 @@
 // ntt_encode.hip -- the hot loop: Reed-Solomon encode of a BATCH of rows on gfx950.
 //
 // Replaces encode_ntt_device (src/webgpu/engine.cpp:755-770: 15 dispatches of <=64 workgroups per row,
-// radix-2 stages through global memory, bit-reversal passes) with three launches per row batch.
+// radix-2 stages through global memory, bit-reversal passes) with four launches per row batch.
 //
 // Math.  codeword[j] = P(w_n^j), j < n = 4k, P = the degree-<k interpolant of the message on
 // the w_k domain.  With c = INTT_k(msg), psi = w_n^4 (order k) and j = 4q + r:
 //     codeword[4q + r] = sum_i (c[i] * w_n^(r*i)) * psi^(i*q)                       (4 coset NTTs of size k;
 // the 3k zero-padded coefficients of the reference's size-n transform are never touched).  Each size-k
-// transform is split k = A*B (A = 8, B = k/8) so that every global access is a contiguous >= 512-byte run
-// per wave and the size-B part lives in LDS:
+// transform is split k = 8*B so that every global store is a contiguous >= 512-byte run per wave and the
+// size-B part runs out of LDS:
 //
-//   K1  encode_in : thread = (row, i2).  Radix-8 butterfly across the 8 strided elements msg[B*i1 + i2],
-//                   seam twiddle w_k^(-i2*j1), writes Y[j1][i2].                     (global -> regs -> global)
-//   K2  encode_mid: workgroup = (row, j1).  Size-B inverse transform of Y[j1][.] in LDS gives the strided
-//                   coefficients c[j1 + 8*i2]; kept in registers, they are twisted by k^-1 * w_n^(r*i) and pushed
-//                   through a size-B forward transform once per coset r, times the seam twiddle psi^(j1*q2),
-//                   written to Z[r][j1][q2].                                         (87% of all multiplies)
-//   K3  encode_out: thread = (row, q2, r).  Radix-8 butterfly across Z[r][0..8)[q2], canonical reduction,
-//                   codeword[4*(q2 + B*q1) + r]: 4 adjacent lanes = 4 cosets = 128 contiguous bytes, a wave
-//                   writes 2 KiB runs in natural order (no bit-reversal pass).
+//   K1  encode_in  : thread = (row, i2).  Radix-8 butterfly across the strided elements msg[B*i1 + i2], seam
+//                    twiddle w_k^(-i2*j1) -> Y[j1][i2].
+//   K2a encode_coef: workgroup = (row, j1).  Size-B inverse transform of Y[j1][.] in LDS, times k^-1
+//                    -> C[j1][j2] = coefficient c[j1 + 8*j2].
+//   K2b encode_mid : workgroup = (row, j1, coset r).  C[j1][.] * w_n^(r*i) -> size-B forward transform in LDS
+//                    -> times seam twiddle psi^(j1*q2) -> Z[r][j1][q2].                 (72% of all multiplies)
+//   K3  encode_out : thread = (row, q2, r).  Radix-8 butterfly across Z[r][0..8)[q2], exact canonical
+//                    reduction, codeword[4*(q2 + B*q1) + r]: 4 adjacent lanes = 4 cosets = 128 contiguous bytes,
+//                    a wave writes 2 KiB runs in natural order (no bit-reversal pass anywhere).
 //
-// Values stay lazily in [0,2p) between butterflies (Montgomery products of a < 4p by a canonical twiddle
-// are < 2p); only K3 produces canonical residues, which is all the reference guarantees too.
+// All butterflies are decimation-in-time on 29-bit-limb lazy values (fr29.hpp): x' = x + w*y, y' = x - w*y + 2p,
+// so magnitudes grow additively (<= 4p per radix-4 step) and no modular reduction is needed inside a transform;
+// limbs are renormalised once per radix-4 step.  Y, C, Z hold values < 2^256 in the canonical 8 x u32 layout
+// (not necessarily < p); only K3 produces canonical residues, which is all the reference guarantees as well.
+//
+// Limb/value bounds are stated next to each operation; the invariants are
+//   "at rest" (LDS / loaded from HBM): limbs < 2^29 + 8, value < 30p;
+//   Montgomery-product input a: limbs <= 2.5 * 2^30 + 8; every subtraction adds a borrow-proof multiple of p
+//   whose limbs dominate the subtrahend's limbs and whose value dominates its value.
+#include "fr29.hpp"
 #include "kernels.hpp"
 
 namespace lig {
 
-// a, b in [0,2p): s = a + b mod 2p-lazy ([0,2p)), d = a - b + 2p in (0,4p)
-__device__ __forceinline__ fr lazy_add(const fr& a, const fr& b) {
-    fr s, t, r;
-    add256(s, a, b);                         // < 4p < 2^256
-    fr p2 = fr_const(FR_2P);
-    uint32_t borrow = sub256(t, s, p2);
-    select256(r, borrow == 0, s, t);
-    return r;
-}
-__device__ __forceinline__ fr lazy_sub(const fr& a, const fr& b) {   // result in (0,4p), input of a Montgomery product
-    fr t, r;
-    fr p2 = fr_const(FR_2P);
-    add256(t, a, p2);
-    sub256(r, t, b);
-    return r;
-}
-__device__ __forceinline__ fr lazy_sub_red(const fr& a, const fr& b) {  // a - b mod 2p-lazy, result [0,2p)
-    fr d, e, r;
-    uint32_t borrow = sub256(d, a, b);
-    fr p2 = fr_const(FR_2P);
-    add256(e, d, p2);
-    select256(r, borrow != 0, d, e);
-    return r;
-}
-__device__ __forceinline__ fr canon(const fr& a) {   // [0,2p) -> [0,p)
-    return fr_reduce_once(a);
-}
+__device__ __forceinline__ constexpr int brev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
 
-// radix-8 DIF butterfly in registers: a[p] <- sum_i a[i] * w^(i * brev3(p)); w1,w2,w3 = w, w^2, w^3 (w of order 8,
-// Montgomery form).  5 Montgomery products.  Inputs/outputs lazy [0,2p).
-__device__ __forceinline__ void radix8_dif(fr (&a)[8], const fr& w1, const fr& w2, const fr& w3) {
-    fr t;
-    // stage M = 8
-    t = lazy_sub(a[0], a[4]); a[0] = lazy_add(a[0], a[4]); a[4] = lazy_add(t, fr_zero());            // (a0-a4)*1: fold (0,4p) -> [0,2p)
-    t = lazy_sub(a[1], a[5]); a[1] = lazy_add(a[1], a[5]); a[5] = fr_montmul_lazy(t, w1);
-    t = lazy_sub(a[2], a[6]); a[2] = lazy_add(a[2], a[6]); a[6] = fr_montmul_lazy(t, w2);
-    t = lazy_sub(a[3], a[7]); a[3] = lazy_add(a[3], a[7]); a[7] = fr_montmul_lazy(t, w3);
-    // stage M = 4 (two halves)
-    t = lazy_sub_red(a[0], a[2]); a[0] = lazy_add(a[0], a[2]); a[2] = t;
-    t = lazy_sub(a[1], a[3]);     a[1] = lazy_add(a[1], a[3]); a[3] = fr_montmul_lazy(t, w2);
-    t = lazy_sub_red(a[4], a[6]); a[4] = lazy_add(a[4], a[6]); a[6] = t;
-    t = lazy_sub(a[5], a[7]);     a[5] = lazy_add(a[5], a[7]); a[7] = fr_montmul_lazy(t, w2);
-    // stage M = 2
+// Radix-8 DIT butterfly in registers.  In: a[p] = input number brev3(p), normalised limbs, value < 3p.
+// Out: a[j] = sum_i in[i] * w^(i*j), lazy (limbs < 2^31 + 8, value < 28p).  w1,w2,w3 = w, w^2, w^3 (Montgomery form).
+__device__ __forceinline__ void radix8_dit(f29 (&a)[8], const f29& w1, const f29& w2, const f29& w3) {
+    f29 t, u;
+    // span 2, twiddle 1.  u: limbs < 2^30, < 6p.  v = x - y + 4p: limbs < 2^31, < 7p.
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
-        t = lazy_sub_red(a[i], a[i + 1]);
-        a[i] = lazy_add(a[i], a[i + 1]);
-        a[i + 1] = t;
+        u = f29_add(a[i], a[i + 1]);
+        a[i + 1] = f29_sub_k4(a[i], a[i + 1]);
+        a[i] = u;
     }
+    // span 4.  pairs (0,2),(4,6): twiddle 1, subtrahend limbs < 2^30, < 6p -> + 8p.  pairs (1,3),(5,7): twiddle w^2.
+#pragma unroll
+    for (int b = 0; b < 8; b += 4) {
+        u = f29_add(a[b], a[b + 2]);               // limbs < 2^31, < 12p
+        a[b + 2] = f29_sub_k8(a[b], a[b + 2]);     // limbs < 3.5 * 2^30, < 14p
+        a[b] = u;
+        t = f29_montmul(a[b + 3], w2);             // input limbs < 2^31
+        u = f29_add(a[b + 1], t);                  // limbs < 2.5 * 2^30, < 8.2p
+        a[b + 3] = f29_sub_k2(a[b + 1], t);        // limbs < 3 * 2^30, < 9p
+        a[b + 1] = u;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = f29_qnorm(a[i]);
+    // span 8.  pair (0,4): twiddle 1, subtrahend limbs < 2^29+8, < 12p -> + 16p.  others: w, w^2, w^3.
+    u = f29_add(a[0], a[4]); a[4] = f29_sub_k16(a[0], a[4]); a[0] = u;                 // < 24p | limbs < 2^31+8, < 28p
+    t = f29_montmul(a[5], w1); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
+    t = f29_montmul(a[6], w2); u = f29_add(a[2], t); a[6] = f29_sub_k2(a[2], t); a[2] = u;
+    t = f29_montmul(a[7], w3); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
 }
-__device__ __forceinline__ constexpr int brev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
 
 // ---------------------------------------------------------------------------------------------------- K1
 template <int LOG2B>
-__global__ void __launch_bounds__(256, 4) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const fr* __restrict__ seam_inv,
-                                                   const fr* __restrict__ w8, size_t rows) {
+__global__ void __launch_bounds__(256) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29s* __restrict__ seam_inv,
+                                                   const f29s* __restrict__ w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = gid >> LOG2B;
     const uint32_t i2 = (uint32_t)gid & (B - 1);
     if (row >= rows) return;
     const fr* m = msgs + row * K;
-    fr a[8];
+    f29 a[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = fr_load(m + (size_t)i * B + i2);       // canonical inputs
-    const fr w1 = fr_load(w8 + 1), w2 = fr_load(w8 + 2), w3 = fr_load(w8 + 3);
-    radix8_dif(a, w1, w2, w3);
+    for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(m + (size_t)brev3(p) * B + i2));      // canonical inputs
+    radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
     fr* y = Y + row * K;
+    fr_store(y + i2, pack29(f29_reduce_2p(a[0])));
 #pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int j1 = brev3(p);
-        fr v = a[p];
-        if (j1 != 0) v = fr_montmul_lazy(v, fr_load(seam_inv + (size_t)j1 * B + i2));
-        fr_store(y + (size_t)j1 * B + i2, v);
-    }
+    for (int j1 = 1; j1 < 8; j1++)
+        fr_store(y + (size_t)j1 * B + i2, pack29(f29_montmul(a[j1], f29_load_tab(seam_inv + (size_t)j1 * B + i2))));
 }
 
-// ---------------------------------------------------------------------------------------------------- K2
-// LDS exchange: element `pos` of the tile lives as two 16-byte halves in two planes.
+// ---------------------------------------------------------------------------------------------------- tile transform
+// LDS exchange buffer: element `pos` of the tile = limbs 0-3 | limbs 4-7 | limb 8 in three planes.
 template <int LOG2B>
 struct TileLds {
     static constexpr uint32_t B = 1u << LOG2B;
     uint4 lo[B];
     uint4 hi[B];
+    uint32_t top[B];
 };
-__device__ __forceinline__ uint32_t swz(uint32_t pos) { return pos ^ ((pos >> 5) & 7u); }
-
 template <int LOG2B>
-__device__ __forceinline__ void lds_put(TileLds<LOG2B>& L, uint32_t pos, const fr& x) {
-    const uint32_t q = swz(pos);
-    L.lo[q] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    L.hi[q] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+__device__ __forceinline__ void lds_put(TileLds<LOG2B>& L, uint32_t pos, const f29& x) {
+    L.lo[pos] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    L.hi[pos] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    L.top[pos] = x.v[8];
 }
 template <int LOG2B>
-__device__ __forceinline__ fr lds_get(const TileLds<LOG2B>& L, uint32_t pos) {
-    const uint32_t q = swz(pos);
-    const uint4 a = L.lo[q], b = L.hi[q];
-    fr r;
+__device__ __forceinline__ f29 lds_get(const TileLds<LOG2B>& L, uint32_t pos) {
+    const uint4 a = L.lo[pos], b = L.hi[pos];
+    f29 r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = L.top[pos];
     return r;
 }
 
-// Size-B DIF transform of the tile, radix-2^2 steps in registers, LDS exchange between steps.
-// Entry/exit: thread t holds positions t + q*(B/4), q = 0..3, natural order, values lazy [0,2p).
-// tw = per-stage twiddles, stage of span M at offset B - M (M/2 entries rho^(idx*B/M)), Montgomery form.
-// one radix-2^2 step (two DIF stages, spans M and M/2) of the size-B tile transform
+// One radix-2^2 DIT step (spans M/2 and M, M = 4^(S+1)) of the size-B transform.  Thread t owns positions
+// base + q*Q (Q = M/4).  tw: the stage of span M' starts at entry M'/2 - 1 (M'/2 entries rho^(j*B/M')).
 template <int LOG2B, int S>
-__device__ __forceinline__ void tile_step(fr (&x)[4], const fr* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
-    constexpr uint32_t B = 1u << LOG2B;
+__device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
     constexpr int STEPS = LOG2B / 2;
-    constexpr uint32_t M = B >> (2 * S), Q = M >> 2;
-    const uint32_t b = t / Q, p = t % Q;            // Q is a power of two: shifts/masks
-    const uint32_t base = b * M + p;
-    if constexpr (S > 0) {   // fetch this step's operands
+    constexpr uint32_t M = 4u << (2 * S), Q = M >> 2;
+    const uint32_t p = t & (Q - 1);
+    const uint32_t base = (t / Q) * M + p;
+    if constexpr (S > 0) {
 #pragma unroll
         for (int q = 0; q < 4; q++) x[q] = lds_get(L, base + q * Q);
         __syncthreads();
     }
-    fr d0 = lazy_sub(x[0], x[2]), d1 = lazy_sub(x[1], x[3]);
-    fr b0 = lazy_add(x[0], x[2]), b1 = lazy_add(x[1], x[3]);
-    fr b2, b3;
-    if constexpr (Q > 1) {
-        b2 = fr_montmul_lazy(d0, fr_load(tw + (B - M) + p));
-        b3 = fr_montmul_lazy(d1, fr_load(tw + (B - M) + p + Q));
+    f29 t1, t3, u;
+    if constexpr (S == 0) {
+        // spans 2 and 4: twiddles 1 | 1, W_4^1.  inputs normalised, < 3p.
+        u = f29_add(x[0], x[1]); x[1] = f29_sub_k4(x[0], x[1]); x[0] = u;         // u: limbs < 2^30, < 6p; v: limbs < 2^31, < 7p
+        u = f29_add(x[2], x[3]); x[3] = f29_sub_k4(x[2], x[3]); x[2] = u;
+        t3 = f29_montmul(x[3], f29_load_tab(tw + 2));                               // W_4^1
+        u = f29_add(x[0], x[2]); x[2] = f29_sub_k8(x[0], x[2]); x[0] = u;           // < 12p | limbs < 3.5*2^30, < 14p
+        u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 3*2^30, < 9p
     } else {
-        b2 = lazy_add(d0, fr_zero());                                   // W_4^0 = 1
-        b3 = fr_montmul_lazy(d1, fr_load(tw + (B - 4) + 1));            // W_4^1
+        // operands at rest: limbs < 2^29 + 8.  every output gains at most 4p.
+        const f29 wa = f29_load_tab(tw + (Q - 1) + p);                               // W_{M/2}^p
+        t1 = f29_montmul(x[1], wa);
+        t3 = f29_montmul(x[3], wa);
+        u = f29_add(x[0], t1); x[1] = f29_sub_k2(x[0], t1); x[0] = u;               // limbs < 2^30+8 | < 1.5*2^30+8
+        u = f29_add(x[2], t3); x[3] = f29_sub_k2(x[2], t3); x[2] = u;
+        t1 = f29_montmul(x[2], f29_load_tab(tw + (2 * Q - 1) + p));                 // W_M^p
+        t3 = f29_montmul(x[3], f29_load_tab(tw + (2 * Q - 1) + p + Q));             // W_M^(p+Q)
+        u = f29_add(x[0], t1); x[2] = f29_sub_k2(x[0], t1); x[0] = u;               // limbs < 2^31 + 8
+        u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 2.5*2^30 + 8
     }
-    fr e0 = lazy_sub(b0, b1), e1 = lazy_sub(b2, b3);
-    x[0] = lazy_add(b0, b1);
-    x[2] = lazy_add(b2, b3);
-    if constexpr (Q > 1) {
-        const fr w = fr_load(tw + (B - M / 2) + p);
-        x[1] = fr_montmul_lazy(e0, w);
-        x[3] = fr_montmul_lazy(e1, w);
-    } else {
-        x[1] = lazy_add(e0, fr_zero());
-        x[3] = lazy_add(e1, fr_zero());
-    }
-    // publish: after the last step scatter to bit-reversed positions so that the tile is in natural order
     if constexpr (S + 1 < STEPS) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, x[q]);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) lds_put(L, __brev(base + q) >> (32 - LOG2B), x[q]);
+        for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
+        __syncthreads();
+        tile_step<LOG2B, S + 1>(x, tw, L, t);
     }
-    __syncthreads();
-    if constexpr (S + 1 < STEPS) tile_step<LOG2B, S + 1>(x, tw, L, t);
 }
-
-// Size-B DIF transform of the tile, radix-2^2 steps in registers, LDS exchange between steps.
-// Entry/exit: thread t holds positions t + q*(B/4), q = 0..3, natural order, values lazy [0,2p).
-// tw = per-stage twiddles, stage of span M at offset B - M (M/2 entries rho^(idx*B/M)), Montgomery form.
+// Size-B DIT transform.  Entry: x[q] = input number brev(4t + q) (bit-reversed load), normalised, < 3p.
+// Exit: x[q] = output number t + q*B/4 (natural order, the coalesced ownership pattern), lazy:
+// limbs < 2.5*2^30 + 8, value < 14p + 4p*(STEPS-1) <= 30p.
 template <int LOG2B>
-__device__ __forceinline__ void tile_dft(fr (&x)[4], const fr* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
-    constexpr uint32_t B = 1u << LOG2B;
-    static_assert(LOG2B % 2 == 0, "tile length must be a power of 4");
+__device__ __forceinline__ void tile_dft(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
+    static_assert(LOG2B % 2 == 0 && LOG2B >= 4, "tile length must be a power of 4, at least 16");
     tile_step<LOG2B, 0>(x, tw, L, t);
-    // natural order back into the entry ownership pattern
-#pragma unroll
-    for (int q = 0; q < 4; q++) x[q] = lds_get(L, t + q * (B / 4));
-    __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------- K2a
 template <int LOG2B>
-__global__ void __launch_bounds__((1 << LOG2B) / 4, 4) k_encode_mid(const fr* __restrict__ Y, fr* __restrict__ Z,
-                                                                 const fr* __restrict__ tw_inv, const fr* __restrict__ tw_fwd,
-                                                                 const fr* __restrict__ twist, const fr* __restrict__ seam_fwd) {
-    constexpr uint32_t B = 1u << LOG2B, K = 8u * B, T = B / 4;
+__global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_coef(const fr* __restrict__ Y, fr* __restrict__ Cc,
+                                                                  const f29s* __restrict__ tw_inv, const f29s* __restrict__ kinv) {
+    constexpr uint32_t B = 1u << LOG2B, T = B / 4;
     __shared__ TileLds<LOG2B> L;
     const uint32_t t = threadIdx.x;
-    const uint32_t j1 = blockIdx.x & 7u;
-    const size_t row = blockIdx.x >> 3;
-    const fr* y = Y + row * K + (size_t)j1 * B;
-    fr c[4], x[4];
+    const fr* y = Y + (size_t)blockIdx.x * B;          // tile (row, j1) = blockIdx.x
+    f29 x[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) c[q] = fr_load(y + t + q * T);
-    tile_dft<LOG2B>(c, tw_inv, L, t);                   // c[q] = k * coefficient[j1 + 8*(t + q*T)]  (lazy)
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) {
-        const fr* tws = twist + ((size_t)r * 8 + j1) * B;   // k^-1 * w_n^(r*(j1 + 8*i2)), layout [r][j1][i2]
+    for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + (__brev(4 * t + q) >> (32 - LOG2B))));
+    tile_dft<LOG2B>(x, tw_inv, L, t);
+    const f29 ki = f29_load_tab(kinv);
+    fr* c = Cc + (size_t)blockIdx.x * B;
 #pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = fr_montmul_lazy(c[q], fr_load(tws + t + q * T));
-        tile_dft<LOG2B>(x, tw_fwd, L, t);
-        fr* z = Z + ((row * 4 + r) * 8 + j1) * (size_t)B;
-        if (j1 != 0) {
-            const fr* sf = seam_fwd + (size_t)j1 * B;
+    for (int q = 0; q < 4; q++) fr_store(c + t + q * T, pack29(f29_montmul(x[q], ki)));
+}
+
+// ---------------------------------------------------------------------------------------------------- K2b
+template <int LOG2B>
+__global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __restrict__ Cc, fr* __restrict__ Z,
+                                                                 const f29s* __restrict__ tw_fwd, const f29s* __restrict__ twist,
+                                                                 const f29s* __restrict__ seam_fwd) {
+    constexpr uint32_t B = 1u << LOG2B, T = B / 4;
+    __shared__ TileLds<LOG2B> L;
+    const uint32_t t = threadIdx.x;
+    const uint32_t r = blockIdx.x & 3u, j1 = (blockIdx.x >> 2) & 7u;
+    const size_t row = blockIdx.x >> 5;
+    const fr* c = Cc + (row * 8 + j1) * (size_t)B;
+    f29 x[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) x[q] = fr_montmul_lazy(x[q], fr_load(sf + t + q * T));
-        }
+    for (int q = 0; q < 4; q++) {
+        const uint32_t pos = __brev(4 * t + q) >> (32 - LOG2B);
+        x[q] = unpack29(fr_load(c + pos));
+        if (r != 0) x[q] = f29_montmul(x[q], f29_load_tab(twist + ((size_t)(r - 1) * 8 + j1) * B + pos));   // w_n^(r*(j1 + 8*pos))
+    }
+    tile_dft<LOG2B>(x, tw_fwd, L, t);
+    fr* z = Z + ((row * 4 + r) * 8 + j1) * (size_t)B;
+    if (j1 != 0) {
+        const f29s* sf = seam_fwd + (size_t)j1 * B;
 #pragma unroll
-        for (int q = 0; q < 4; q++) fr_store(z + t + q * T, x[q]);
+        for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_montmul(x[q], f29_load_tab(sf + t + q * T))));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_reduce_2p(x[q])));
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- K3
 template <int LOG2B>
-__global__ void __launch_bounds__(256, 4) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const fr* __restrict__ w8, size_t rows) {
+__global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = gid >> (LOG2B + 2);
@@ -233,17 +220,13 @@ __global__ void __launch_bounds__(256, 4) k_encode_out(const fr* __restrict__ Z,
     const uint32_t r = (uint32_t)gid & 3u;
     const uint32_t q2 = ((uint32_t)gid >> 2) & (B - 1);
     const fr* z = Z + ((row * 4 + r) * 8) * (size_t)B + q2;
-    fr a[8];
+    f29 a[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = fr_load(z + (size_t)i * B);
-    const fr w1 = fr_load(w8 + 1), w2 = fr_load(w8 + 2), w3 = fr_load(w8 + 3);
-    radix8_dif(a, w1, w2, w3);
+    for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
+    radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
     fr* out = cw + row * (4 * (size_t)K);
 #pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int q1 = brev3(p);
-        fr_store(out + 4 * ((size_t)q2 + (size_t)B * q1) + r, canon(a[p]));
-    }
+    for (int q1 = 0; q1 < 8; q1++) fr_store(out + 4 * ((size_t)q2 + (size_t)B * q1) + r, pack29(f29_canon(a[q1])));
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 2048 || k == 8192; }
@@ -252,10 +235,12 @@ template <int LOG2B>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
                           hipEvent_t ev0, hipEvent_t ev1) {
     constexpr uint32_t B = 1u << LOG2B;
+    fr* Cc = Y + rows * (size_t)(8 * B);      // second half of the Y scratch (2 * rows * k elements)
     const size_t th1 = rows * B;
     hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
+    hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL(k_encode_mid<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+    hipLaunchKernelGGL(k_encode_mid<LOG2B>, dim3((uint32_t)(rows * 32)), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
     if (ev1) (void)hipEventRecord(ev1, s);
     const size_t th3 = rows * B * 4;
     hipLaunchKernelGGL(k_encode_out<LOG2B>, dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, rows);
