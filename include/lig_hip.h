@@ -122,6 +122,36 @@ int lig_gather_rows(lig_ctx *ctx, const void *codewords, size_t rows, void *out)
  * out[i] = element number first_elem + i of the stream keyed by key32 (IV = 0) */
 int lig_rng_fill(lig_ctx *ctx, const uint8_t *key32, uint64_t first_elem, void *out, size_t count);
 
+/* ==== batched three-stage prover over a resident witness matrix (src/webgpu_prover.cpp:226-494 restructured:
+ * rows are encoded once, codewords stay in HBM for stages 2 and 3).  The guest interpreter is replaced by the
+ * synthetic constraint stream of BASELINE.md: n_linear witness slots + n_quad slots of x*y=z, witnesses from the
+ * AES-256-CTR field stream keyed by witness_key, one dense linear-test coefficient per witness.  The envelope
+ * bytes equal the reference's LigeroProofEnvelope (proto/ligero_proof.proto) for the same rows and seeds. ==== */
+typedef struct lig_trace lig_trace;
+typedef struct {
+    uint64_t n_linear, n_quad;
+    uint8_t  encoding_seed[32];      /* src/webgpu_prover.cpp:239-245 (there: std::random_device) */
+    uint8_t  witness_key[32];
+    uint8_t  program_hash[32];
+    int64_t  generated_at;           /* metadata timestamp seconds (there: wall clock) */
+    char     version[16];            /* "1.5.0" */
+} lig_synth_job;
+typedef struct {
+    uint8_t  root[32], stage1_seed[32], stage2_seed[32], const_sum[32];
+    uint64_t rows;                   /* committed rows including the 3 mask rows */
+    int32_t  valid_code, valid_linear, valid_quad;   /* prover self-check, webgpu_prover.cpp:465-469 */
+    int32_t  reserved;
+    double   ms_stage1, ms_stage2, ms_stage3, ms_total;
+} lig_proof_info;
+/* untimed: plans the rows, allocates the resident buffers, generates the witness matrix on the GPU */
+int  lig_synth_prepare(lig_ctx *ctx, const lig_synth_job *job, lig_trace **out);
+/* the hot path: stage 1 (pads, masks, encode, column hash, Merkle), stage 2 (randomness rows, accumulators,
+ * seeds, sampling, self-check), stage 3 (column gather, envelope).  *proof is malloc'ed: lig_proof_free. */
+int  lig_synth_prove(lig_trace *trace, uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+uint64_t lig_trace_rows(const lig_trace *trace);
+void lig_trace_destroy(lig_trace *trace);
+void lig_proof_free(uint8_t *proof);
+
 /* Measurement hook (no reference counterpart): while enabled, every lig_encode_rows launch group records HIP
  * events on the context stream immediately around the dominant kernel (encode_mid).  lig_profile_read syncs
  * and returns the number of bracketed launches, the rows they covered and the summed kernel time. */

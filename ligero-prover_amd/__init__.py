@@ -27,7 +27,21 @@ EXPORTS = [
     "lig_powmod", "lig_sha_state_bytes", "lig_sha_init", "lig_sha_update", "lig_sha_final", "lig_sample_init",
     "lig_sample_gather", "lig_encode_rows", "lig_sha_update_rows", "lig_merkle_nodes", "lig_merkle_build",
     "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
+    "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy", "lig_proof_free",
 ]
+
+
+class SynthJob(C.Structure):
+    _fields_ = [("n_linear", C.c_uint64), ("n_quad", C.c_uint64), ("encoding_seed", C.c_uint8 * 32),
+                ("witness_key", C.c_uint8 * 32), ("program_hash", C.c_uint8 * 32), ("generated_at", C.c_int64),
+                ("version", C.c_char * 16)]
+
+
+class ProofInfo(C.Structure):
+    _fields_ = [("root", C.c_uint8 * 32), ("stage1_seed", C.c_uint8 * 32), ("stage2_seed", C.c_uint8 * 32),
+                ("const_sum", C.c_uint8 * 32), ("rows", C.c_uint64), ("valid_code", C.c_int32),
+                ("valid_linear", C.c_int32), ("valid_quad", C.c_int32), ("reserved", C.c_int32),
+                ("ms_stage1", C.c_double), ("ms_stage2", C.c_double), ("ms_stage3", C.c_double), ("ms_total", C.c_double)]
 
 
 def build(force=False):
@@ -85,6 +99,14 @@ def load_library():
     L.lig_rlc_rows.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, sz, vp]
     L.lig_gather_rows.argtypes = [vp, vp, sz, vp]
     L.lig_rng_fill.argtypes = [vp, vp, u64, vp, sz]
+    L.lig_synth_prepare.argtypes = [vp, C.POINTER(SynthJob), C.POINTER(vp)]
+    L.lig_synth_prove.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
+    L.lig_trace_rows.argtypes = [vp]
+    L.lig_trace_rows.restype = u64
+    L.lig_trace_destroy.argtypes = [vp]
+    L.lig_trace_destroy.restype = None
+    L.lig_proof_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.lig_proof_free.restype = None
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -206,6 +228,32 @@ class Context:
         tri = np.ascontiguousarray(np.array(triples, dtype=np.uint32).reshape(-1)) if nt else None
         rqb = sc(rq) if nt else None
         self.check(self.L.lig_rlc_rows(self.h, U, Rn, rows, _hptr(rcb), code, lin, _hptr(tri), _hptr(rqb), nt, quad))
+
+    # ---- batched prover over a synthetic trace
+    def synth_prepare(self, n_linear, n_quad=0, synth_seed=1, generated_at=0, encoding_seed=None):
+        import hashlib
+        job = SynthJob()
+        job.n_linear, job.n_quad, job.generated_at = n_linear, n_quad, generated_at
+        es = bytes(range(32)) if encoding_seed is None else bytes(encoding_seed)
+        wk = hashlib.sha256(b"lig-synth" + int(synth_seed).to_bytes(8, "little")).digest()
+        for i in range(32):
+            job.encoding_seed[i] = es[i]
+            job.witness_key[i] = wk[i]
+            job.program_hash[i] = 0
+        job.version = b"1.5.0"
+        t = C.c_void_p()
+        self.check(self.L.lig_synth_prepare(self.h, C.byref(job), C.byref(t)))
+        return t
+
+    def synth_prove(self, trace):
+        proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
+        self.check(self.L.lig_synth_prove(trace, C.byref(proof), C.byref(ln), C.byref(info)))
+        data = C.string_at(proof, ln.value)
+        self.L.lig_proof_free(proof)
+        return data, info
+
+    def trace_destroy(self, trace):
+        self.L.lig_trace_destroy(trace)
 
     def profile_enable(self, on=True):
         self.check(self.L.lig_profile_enable(self.h, int(on)))

@@ -99,6 +99,43 @@ __global__ void k_rng_fill(const uint32_t* __restrict__ rk_g, uint64_t first_ele
     }
 }
 
+// Row-structured fill: out[r*row_stride + col_off + i*elem_stride] = stream element (first + r*stream_stride + i),
+// r < rows, i < per_row.  One launch forms the k-l pad columns of a whole row batch, a dense randomness row
+// batch, or the (0, r, 0, r, ...) pattern of a mask row (elem_stride = 2).
+__global__ void k_rng_fill_rows(const uint32_t* __restrict__ rk_g, uint64_t first, fr* __restrict__ out, size_t rows,
+                                uint32_t per_row, size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
+    __shared__ uint32_t te0[256];
+    __shared__ uint32_t sb[256];
+    __shared__ uint32_t rk[60];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { te0[i] = g_te0[i]; sb[i] = g_sbox[i]; }
+    if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
+    __syncthreads();
+    const size_t total = rows * per_row;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / per_row;
+        const uint32_t i = (uint32_t)(e - r * per_row);
+        const uint64_t blk = 2 * (first + r * stream_stride + i);
+        uint32_t o[8];
+        aes256_block(rk, te0, sb, blk, o);
+        aes256_block(rk, te0, sb, blk + 1, o + 4);
+        fr v;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v.v[w] = __builtin_bswap32(o[w]);
+#pragma unroll
+        for (int w = 0; w < 8; w++) v.v[w] = (v.v[w] >> 2) | (w < 7 ? (v.v[w + 1] << 30) : 0u);
+        fr_store(out + r * row_stride + col_off + (size_t)i * elem_stride, fr_reduce_once(v));
+    }
+}
+void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,
+                          size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
+    const size_t total = rows * per_row;
+    if (!total) return;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_rng_fill_rows, dim3((uint32_t)blocks), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride,
+                       col_off, elem_stride, stream_stride);
+}
+
 // per-device table upload, called from lig_ctx_create
 void aes_upload_tables() {
     const AesTables& T = host_tables();

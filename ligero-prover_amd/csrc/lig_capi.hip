@@ -14,40 +14,13 @@
 #include "host_field.hpp"
 #include "kernels.hpp"
 #include "fr29.hpp"
+#include "ctx_internal.hpp"
 
 namespace lig {
 void aes_upload_tables();
 }
 
-using lig::fr;
 namespace H = lig::host;
-
-struct lig_ctx {
-    int device = 0;
-    uint32_t l = 0, k = 0, n = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    lig::NttPlan plan[3];
-    lig::EncodePlan ep;
-    bool fast = false;
-    std::vector<void*> owned;                 // device tables freed at destroy
-    fr* scratch_y = nullptr; fr* scratch_z = nullptr; size_t scratch_rows = 0;
-    std::unordered_map<void*, std::pair<size_t, uint64_t>> sha;   // state ptr -> (n_inst, rows absorbed)
-    uint32_t* sample_idx = nullptr; size_t sample_count = 0;
-    uint32_t* rk_dev = nullptr;               // 60 AES round-key words
-    fr* small_dev = nullptr;                  // staging for per-call scalars (rc/rq/tables)
-    size_t small_cap = 0;
-    uint32_t* tri_dev = nullptr; size_t tri_cap = 0;
-    // optional per-kernel timing (lig_profile_*): HIP events recorded on the ctx stream around the dominant kernel
-    bool prof_on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-    size_t prof_used = 0;
-    uint64_t prof_rows = 0;
-};
-
-#define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; } while (0)
-#define HIP_TRY(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); return LIG_E_HIP; } } while (0)
-#define FAIL(c, code, msg) do { (c)->err = (msg); return (code); } while (0)
 
 static fr to_dev(const H::Fr& a) {
     fr r;

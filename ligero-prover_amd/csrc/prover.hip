@@ -1,0 +1,483 @@
+// prover.hip -- batched three-stage Ligero prover over a resident witness matrix, host side.
+//
+// MI355X-native counterpart of the orchestration in src/webgpu_prover.cpp:226-494 and the stage contexts of
+// include/zkp/nonbatch_context.hpp (stage 1 :445-558, stage 2 :654-780, stage 3 :924-1000).  The reference
+// streams one row at a time through the executor and re-runs the guest program (and therefore re-encodes every
+// row) three times because a WebGPU device cannot hold the witness matrix.  With 288 GB of HBM the matrix is at
+// rest: every message row is encoded ONCE in stage 1, the codewords (1 MiB per row) stay resident and are re-used
+// by the stage-2 accumulators and the stage-3 column gather; only the dense stage-2 randomness rows need a second
+// encode.  Transcript bytes (seeds, sample indices, Merkle decommitment, protobuf envelope) follow the reference
+// byte for byte, so an unmodified verifier accepts the proof.
+//
+// The guest interpreter / constraint generator is out of scope; rows come from the synthetic
+// constraint stream of BASELINE.md 3: n_linear witness slots + n_quad slots of x*y=z, one dense linear-test
+// coefficient per witness.
+#include <openssl/evp.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctx_internal.hpp"
+#include "fr29.hpp"
+#include "host_field.hpp"
+
+namespace H = lig::host;
+
+namespace lig {
+void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,
+                          size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride);
+void launch_rlc_rows29(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const f29s* rc_dev, fr* code, fr* lin,
+                       fr* part_code, fr* part_lin, uint32_t group_rows);
+void launch_quad_rows29(hipStream_t s, const fr* U, uint32_t n, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
+                        size_t n_triples, fr* quad);
+void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* data_dev, uint32_t k, size_t rows, fr* out);
+}  // namespace lig
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+// ---------------------------------------------------------------- host crypto (OpenSSL, as the reference: hash.hpp:153-214, csprng.hpp)
+struct Sha256 {
+    EVP_MD_CTX* c;
+    Sha256() : c(EVP_MD_CTX_new()) { EVP_DigestInit_ex(c, EVP_sha256(), nullptr); }
+    ~Sha256() { EVP_MD_CTX_free(c); }
+    Sha256& add(const void* p, size_t n) { EVP_DigestUpdate(c, p, n); return *this; }
+    void finish(uint8_t out[32]) { unsigned int l = 32; EVP_DigestFinal_ex(c, out, &l); }
+};
+// keystream element e of the AES-256-CTR stream (IV = 0): blocks 2e, 2e+1  -> field element (finite_field_gmp.hpp:66-78)
+struct FieldStream {
+    EVP_CIPHER_CTX* c;
+    explicit FieldStream(const uint8_t key[32]) : c(EVP_CIPHER_CTX_new()) {
+        const uint8_t iv[16] = {0};
+        EVP_EncryptInit_ex(c, EVP_aes_256_ctr(), nullptr, key, iv);
+    }
+    ~FieldStream() { EVP_CIPHER_CTX_free(c); }
+    // sequential draws (the engine is only ever read front to back on the host)
+    void next(size_t count, std::vector<H::Fr>& out) {
+        std::vector<uint8_t> zero(32 * count, 0), ks(32 * count);
+        int len = 0;
+        EVP_EncryptUpdate(c, ks.data(), &len, zero.data(), (int)zero.size());
+        out.resize(count);
+        for (size_t i = 0; i < count; i++) {
+            H::Fr v;
+            std::memcpy(v.v, ks.data() + 32 * i, 32);
+            for (int w = 0; w < 4; w++) v.v[w] = (v.v[w] >> 2) | (w < 3 ? (v.v[w + 1] << 62) : 0);
+            if (H::geq(v, H::P)) v = H::sub_nored(v, H::P);
+            out[i] = v;
+        }
+    }
+};
+
+// hash_random_engine<sha256> (include/zkp/random.hpp:87-146)
+struct HashRandomEngine {
+    uint8_t seed[32], buf[32];
+    uint64_t state = 0;
+    int off = -1;
+    explicit HashRandomEngine(const uint8_t s[32]) { std::memcpy(seed, s, 32); }
+    uint8_t operator()() {
+        if (off < 0) {
+            Sha256 h;
+            if (state) h.add(seed, 32);             // the seed is absorbed only after the first flush
+            uint8_t le[8];
+            for (int i = 0; i < 8; i++) le[i] = (uint8_t)(state >> (8 * i));
+            h.add(le, 8).finish(buf);
+            state++;
+            off = 31;
+        }
+        return buf[off--];
+    }
+};
+// boost::random::detail::generate_uniform_int over an 8-bit engine (Boost is not vendored upstream)
+uint64_t uniform_u64(HashRandomEngine& e, uint64_t range) {
+    if (range == 0) return 0;
+    if (range == 255) return e();
+    if (range < 255) {
+        const uint64_t bucket = 256 / (range + 1);
+        for (;;) { const uint64_t r = e() / bucket; if (r <= range) return r; }
+    }
+    for (;;) {
+        const uint64_t limit = (range + 1) / 256;     // range < 2^64 - 1 always here
+        uint64_t result = 0, mult = 1;
+        bool exact = false;
+        while (mult <= limit) {
+            result += (uint64_t)e() * mult;
+            if (mult * 255 == range - mult + 1) { exact = true; break; }
+            mult *= 256;
+        }
+        if (exact) return result;
+        uint64_t inc = uniform_u64(e, range / mult);
+        if (UINT64_MAX / mult < inc) continue;
+        inc *= mult;
+        result += inc;
+        if (result < inc || result > range) continue;
+        return result;
+    }
+}
+// portable_sample + sort (include/util/portable_sample.hpp:15-33, src/webgpu_prover.cpp:343-351)
+std::vector<uint32_t> sample_columns(const uint8_t seed[32], uint32_t n, uint32_t t) {
+    HashRandomEngine e(seed);
+    std::vector<uint32_t> a(n), out;
+    for (uint32_t i = 0; i < n; i++) a[i] = i;
+    if (t > n) t = n;
+    for (uint32_t i = 0; i < t; i++) {
+        const uint64_t j = i + uniform_u64(e, (uint64_t)(n - 1) - i);
+        std::swap(a[i], a[j]);
+        out.push_back(a[i]);
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+// merkle_tree::decommit + canonical sibling order (merkle_tree.hpp:155-215, proof_serializer.hpp:82-117)
+std::vector<uint8_t> decommit(const std::vector<uint8_t>& nodes, size_t P, const std::vector<uint32_t>& idx) {
+    std::vector<uint8_t> sib;
+    std::vector<uint8_t> known(P, 0), upper(P, 0);
+    for (uint32_t i : idx) known[i] = 1;
+    size_t start = P - 1, end = 2 * P - 1;
+    while (start > 0) {
+        std::fill(upper.begin(), upper.end(), 0);
+        for (size_t i = start; i < end; i += 2) {
+            const size_t ll = i - start;
+            const bool kl = known[ll], kr = known[ll + 1];
+            if (kl && kr) upper[ll / 2] = 1;
+            else if (kr) { sib.insert(sib.end(), nodes.begin() + 32 * i, nodes.begin() + 32 * i + 32); upper[ll / 2] = 1; }
+            else if (kl) { sib.insert(sib.end(), nodes.begin() + 32 * (i + 1), nodes.begin() + 32 * (i + 1) + 32); upper[ll / 2] = 1; }
+        }
+        known.swap(upper);
+        start = (start - 1) / 2; end = (end - 1) / 2;
+    }
+    return sib;
+}
+
+// ---------------------------------------------------------------- protobuf wire writer (proto/ligero_proof.proto, proto/common.proto)
+struct Pb {
+    std::vector<uint8_t> b;
+    void var(uint64_t v) { do { uint8_t c = v & 0x7f; v >>= 7; if (v) c |= 0x80; b.push_back(c); } while (v); }
+    void tag(uint32_t f, uint32_t wt) { var(((uint64_t)f << 3) | wt); }
+    void u(uint32_t f, uint64_t v) { if (v) { tag(f, 0); var(v); } }
+    void bytes(uint32_t f, const void* p, size_t n) { tag(f, 2); var(n); const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); }
+    void msg(uint32_t f, const Pb& m) { bytes(f, m.b.data(), m.b.size()); }
+};
+size_t varlen(uint64_t v) { size_t n = 1; while (v > 0x7f) { v >>= 7; n++; } return n; }
+
+// serialize_proof (include/zkp/proof_serializer.hpp:166-191) + metadata (src/webgpu_prover.cpp:410-427).
+// The four FixedU32Vector payloads are the raw little-endian limb bytes and are appended without re-copying.
+std::vector<uint8_t> serialize_envelope(const char* version, const uint8_t program_hash[32], int64_t generated_at, uint32_t k,
+                                        uint32_t n, uint32_t t, const uint8_t root[32], const std::vector<uint8_t>& siblings,
+                                        const std::vector<uint32_t>& idx, const uint8_t* code, const uint8_t* lin, const uint8_t* quad,
+                                        const uint8_t* samples, size_t sample_bytes) {
+    auto digest = [](const uint8_t d[32]) { Pb m; m.bytes(1, d, 32); return m; };
+    Pb meta;
+    if (version[0]) meta.bytes(1, version, std::strlen(version));
+    meta.u(2, 1); meta.u(3, 1);
+    meta.msg(4, digest(program_hash));
+    { Pb ts; ts.u(1, (uint64_t)generated_at); meta.msg(5, ts); }
+    meta.u(6, k); meta.u(7, n); meta.u(8, t); meta.u(9, 128);
+    Pb md;
+    md.u(1, 1);
+    md.msg(2, digest(root));
+    for (size_t i = 0; i < siblings.size() / 32; i++) md.msg(3, digest(siblings.data() + 32 * i));
+    if (!idx.empty()) { Pb pk; for (uint32_t v : idx) pk.var(v); md.bytes(4, pk.b.data(), pk.b.size()); }
+    const size_t vec = (size_t)n * 32;
+    auto fixed_len = [](size_t nb) { return nb ? 1 + varlen(nb) + nb : 0; };
+    const size_t body_len = 1 + varlen(md.b.size()) + md.b.size() + 3 * (1 + varlen(fixed_len(vec)) + fixed_len(vec)) + 1 +
+                            varlen(fixed_len(sample_bytes)) + fixed_len(sample_bytes);
+    Pb out;
+    out.b.reserve(body_len + meta.b.size() + 32);
+    out.msg(1, meta);
+    out.tag(2, 2); out.var(body_len);
+    out.msg(1, md);
+    auto fixed = [&](uint32_t f, const uint8_t* p, size_t nb) {
+        out.tag(f, 2); out.var(fixed_len(nb));
+        if (nb) out.bytes(1, p, nb);
+    };
+    fixed(2, code, vec); fixed(3, lin, vec); fixed(4, quad, vec); fixed(5, samples, sample_bytes);
+    return out.b;
+}
+
+struct RowDesc { uint8_t kind; uint32_t data; };   // 0 linear, 1 x, 2 y, 3 z
+
+lig::f29s to_f29s_host(const H::Fr& plain, const H::Fr& scale) {
+    const H::Fr m = H::mul(plain, scale);
+    lig::f29s o;
+    std::memset(&o, 0, sizeof o);
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+        uint64_t v = m.v[w] >> sh;
+        if (sh > 35 && w < 3) v |= m.v[w + 1] << (64 - sh);
+        o.v[i] = (uint32_t)(i < 8 ? (v & 0x1FFFFFFFull) : v);
+    }
+    return o;
+}
+const H::Fr R261 = {{0x2fd4e1568fffff57ull, 0x75bba827a494b01aull, 0x5301fa84819caa80ull, 0x0dc83629563d4475ull}};   // 2^261 mod p
+
+}  // namespace
+
+struct lig_trace {
+    lig_ctx* c = nullptr;
+    lig_synth_job job;
+    std::vector<RowDesc> rows;          // committed non-mask rows in commit order
+    size_t R = 0;
+    fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
+    fr* cw = nullptr;                   // (R+3) x n codewords, resident across the stages
+    fr* randb = nullptr;                // chunk x k randomness rows
+    fr* rcw = nullptr;                  // chunk x n their codewords
+    fr* acc = nullptr;                  // code | lin | quad | tmp   (4 x n)
+    fr* parts = nullptr;                // 2 x groups x n partial accumulators
+    fr* dots = nullptr;                 // R inner products
+    fr* samples = nullptr;              // (R+3) x t
+    uint32_t* sha_state = nullptr; uint32_t* leaves = nullptr; uint32_t* nodes = nullptr;
+    uint32_t* data_dev = nullptr; uint32_t* tri_dev = nullptr;
+    lig::f29s* coef_dev = nullptr;      // rc (R) | rq2 (T) | rq1 (T)
+    std::vector<uint32_t> triples;
+    static constexpr size_t CHUNK = 256;
+    static constexpr uint32_t GROUP = 64;
+};
+
+#define TRY(x) do { int rc__ = (x); if (rc__ != LIG_OK) return rc__; } while (0)
+
+extern "C" {
+
+// plan_rows: commit order of witness_manager (witness_manager.hpp:497-503): full linear rows, full quadratic
+// triples, partial linear row, partial quadratic triple
+int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
+    CHECK_CTX(c);
+    if (!job || !out) return LIG_E_ARG;
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
+    if (l >= k || l < 2 || t > n) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l < k and 192 <= n");
+    lig_trace* T = new lig_trace();
+    T->c = c; T->job = *job;
+    const size_t lf = job->n_linear / l, lp = job->n_linear % l, qf = job->n_quad / l, qp = job->n_quad % l;
+    for (size_t i = 0; i < lf; i++) T->rows.push_back({0, l});
+    for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) T->rows.push_back({q, l});
+    if (lp) T->rows.push_back({0, (uint32_t)lp});
+    if (qp) for (uint8_t q = 1; q <= 3; q++) T->rows.push_back({q, (uint32_t)qp});
+    const size_t R = T->R = T->rows.size();
+    for (size_t r = 0; r < R; r++) if (T->rows[r].kind == 3) { T->triples.push_back((uint32_t)r - 2); T->triples.push_back((uint32_t)r - 1); T->triples.push_back((uint32_t)r); }
+    const size_t chunk = lig_trace::CHUNK, groups = (chunk + lig_trace::GROUP - 1) / lig_trace::GROUP;
+    *out = T;
+    auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
+    TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
+    TRY(dm((void**)&T->cw, (R + 3) * (size_t)n * 32));
+    TRY(dm((void**)&T->randb, chunk * (size_t)k * 32));
+    TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
+    TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
+    TRY(dm((void**)&T->parts, 2 * groups * (size_t)n * 32));
+    TRY(dm((void**)&T->dots, (R ? R : 1) * 32));
+    TRY(dm((void**)&T->samples, (R + 3) * (size_t)t * 32));
+    TRY(dm((void**)&T->sha_state, lig_sha_state_bytes(n)));
+    TRY(dm((void**)&T->leaves, (size_t)n * 32));
+    TRY(dm((void**)&T->nodes, lig_merkle_nodes(n) * 32));
+    TRY(dm((void**)&T->data_dev, (R ? R : 1) * sizeof(uint32_t)));
+    TRY(dm((void**)&T->tri_dev, (T->triples.size() ? T->triples.size() : 1) * sizeof(uint32_t)));
+    TRY(dm((void**)&T->coef_dev, (R + 2 * T->triples.size() / 3 + 1) * sizeof(lig::f29s)));
+    {
+        std::vector<uint32_t> d(R);
+        for (size_t r = 0; r < R; r++) d[r] = T->rows[r].data;
+        if (R) HIP_TRY(c, hipMemcpyAsync(T->data_dev, d.data(), R * 4, hipMemcpyHostToDevice, c->stream));
+        if (!T->triples.empty()) HIP_TRY(c, hipMemcpyAsync(T->tri_dev, T->triples.data(), T->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    // witness values: one draw per data slot of every linear / x / y row, in commit order; z = x*y
+    uint32_t rk[60];
+    lig::aes256_expand_host(job->witness_key, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t pos = 0;
+    size_t r = 0;
+    while (r < R) {
+        const RowDesc d = T->rows[r];
+        if (d.kind == 0) {                      // run of linear rows with the same fill
+            size_t run = 1;
+            while (r + run < R && T->rows[r + run].kind == 0 && T->rows[r + run].data == d.data) run++;
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, pos, T->msgs + r * k, run, d.data, k, 0, 1, d.data);
+            pos += (uint64_t)run * d.data; r += run;
+        } else {                                 // x, y, z triple
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, pos, T->msgs + r * k, 2, d.data, k, 0, 1, d.data);
+            pos += 2ull * d.data;
+            lig::launch_eltwise(c->stream, LIG_OP_MUL, T->msgs + r * k, T->msgs + (r + 1) * k, T->msgs + (r + 2) * k, d.data, fr{}, 0);
+            r += 3;
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+void lig_trace_destroy(lig_trace* T) {
+    if (!T) return;
+    (void)hipStreamSynchronize(T->c->stream);
+    T->c->sha.erase(T->sha_state);
+    for (void* p : {(void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
+                    (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
+                    (void*)T->coef_dev})
+        (void)hipFree(p);
+    delete T;
+}
+void lig_proof_free(uint8_t* p) { std::free(p); }
+uint64_t lig_trace_rows(const lig_trace* T) { return T ? T->R + 3 : 0; }
+
+int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
+    if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
+    lig_ctx* c = T->c;
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l;
+    const size_t R = T->R;
+    hipStream_t s = c->stream;
+    std::memset(info, 0, sizeof *info);
+    info->rows = R + 3;
+    const auto t_begin = clk::now();
+    auto t0 = clk::now();
+
+    // ================= stage 1: row forming (pads + masks from the encoding stream), encode, column hash, Merkle root
+    uint32_t rk[60];
+    lig::aes256_expand_host(T->job.encoding_seed, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    uint64_t epos = 0;
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, T->msgs, R, pad, k, l, 1, pad);                 // pad_encoding_random of every row
+    epos += (uint64_t)R * pad;
+    fr* mask = T->cw + R * (size_t)n;                                                               // the 3 mask rows are formed in place
+    HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;               // code mask: l randoms, zeros to k
+    fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, l - 1, 0, 1, 2, 0); epos += l - 1;       // (0, r) x (l-1)
+    {   // last odd slot = -(sum of the others) (witness_manager.hpp:283-297)
+        std::vector<H::Fr> tmp(2 * (size_t)(l - 1));
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), mlin, tmp.size() * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        H::Fr sum = H::from_u64(0);
+        for (size_t i = 1; i < tmp.size(); i += 2) sum = H::add(sum, tmp[i]);
+        sum = H::neg(sum);
+        HIP_TRY(c, hipMemcpyAsync(mlin + 2 * (size_t)(l - 1) + 1, &sum, 32, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, l, 0, 1, 2, 0); epos += l;              // (0, r) x l
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
+
+    TRY(lig_encode_rows(c, T->msgs, T->cw, R));
+    TRY(lig_encode(c, mask));
+    TRY(lig_encode_2k(c, mlin));
+    TRY(lig_encode_2k(c, mquad));
+    TRY(lig_sha_init(c, T->sha_state, n));
+    TRY(lig_sha_update_rows(c, T->sha_state, T->cw, R + 3));
+    TRY(lig_sha_final(c, T->sha_state, T->leaves));
+    TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
+    HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    uint8_t ih[32];
+    {   // instance hash with no public arguments besides arg0 = "Ligero\0" (src/webgpu_prover.cpp:110-168)
+        const uint8_t z[32] = {0};
+        Sha256().add(z, 32).add("Ligero", 7).finish(ih);
+        Sha256().add("LigetronStage1", 15).add(info->root, 32).add(ih, 32).finish(info->stage1_seed);
+    }
+    info->ms_stage1 = ms_since(t0);
+    t0 = clk::now();
+
+    // ================= stage 2: code / linear / quadratic accumulators over the resident codewords
+    const size_t NT = T->triples.size() / 3;
+    {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple (three engines, same key)
+        std::vector<H::Fr> rc, rq;
+        FieldStream code(info->stage1_seed), quad(info->stage1_seed);
+        code.next(R, rc);
+        quad.next(NT, rq);
+        std::vector<lig::f29s> coef(R + 2 * NT + 1);
+        const H::Fr R261sq = H::mul(R261, R261);
+        for (size_t r = 0; r < R; r++) coef[r] = to_f29s_host(rc[r], R261);
+        for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
+        HIP_TRY(c, hipMemcpyAsync(T->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
+        lig::aes256_expand_host(info->stage1_seed, rk);
+        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    fr* code = T->acc; fr* lin = T->acc + n; fr* quad = T->acc + 2 * (size_t)n; fr* tmp = T->acc + 3 * (size_t)n;
+    HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
+    const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
+    uint64_t lpos = 0;
+    for (size_t b = 0; b < R; b += lig_trace::CHUNK) {
+        const size_t nb = std::min(lig_trace::CHUNK, R - b);
+        HIP_TRY(c, hipMemsetAsync(T->randb, 0, nb * (size_t)k * 32, s));
+        for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order
+            size_t run = 1;
+            const uint32_t d = T->rows[b + r].data;
+            while (r + run < nb && T->rows[b + r + run].data == d) run++;
+            lig::launch_rng_fill_rows(s, c->rk_dev, lpos, T->randb + r * k, run, d, k, 0, 1, d);
+            lpos += (uint64_t)run * d; r += run;
+        }
+        lig::launch_dot_rows(s, T->msgs + b * k, T->randb, T->data_dev + b, k, nb, T->dots + b);
+        TRY(lig_encode_rows(c, T->randb, T->rcw, nb));
+        lig::launch_rlc_rows29(s, T->cw + b * n, T->rcw, nb, n, T->coef_dev + b, code, lin, T->parts, T->parts + groups * (size_t)n,
+                               lig_trace::GROUP);
+    }
+    lig::launch_quad_rows29(s, T->cw, n, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);                     // masks (nonbatch_context.hpp:739-753)
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
+    std::vector<uint8_t> enc(3 * (size_t)n * 32);
+    HIP_TRY(c, hipMemcpyAsync(enc.data(), T->acc, enc.size(), hipMemcpyDeviceToHost, s));
+    std::vector<H::Fr> dots(R);
+    if (R) HIP_TRY(c, hipMemcpyAsync(dots.data(), T->dots, R * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        H::Fr sum = H::from_u64(0);
+        for (size_t r = 0; r < R; r++) sum = H::add(sum, dots[r]);
+        sum = H::neg(sum);
+        std::memcpy(info->const_sum, sum.v, 32);
+    }
+    Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc.data(), enc.size()).finish(info->stage2_seed);
+    const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
+    TRY(lig_sample_init(c, idx.data(), idx.size()));
+    std::vector<uint8_t> nodes(lig_merkle_nodes(n) * 32);
+    HIP_TRY(c, hipMemcpyAsync(nodes.data(), T->nodes, nodes.size(), hipMemcpyDeviceToHost, s));
+    // prover self-check (src/webgpu_prover.cpp:355-386,465-469): decode the three accumulators
+    std::vector<H::Fr> dec(n);
+    auto decode_to_host = [&](const fr* src) -> int {
+        HIP_TRY(c, hipMemcpyAsync(tmp, src, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
+        TRY(lig_decode(c, tmp));
+        HIP_TRY(c, hipMemcpyAsync(dec.data(), tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        return LIG_OK;
+    };
+    auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
+    TRY(decode_to_host(code));
+    info->valid_code = 1;
+    for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
+    TRY(decode_to_host(lin));
+    {
+        H::Fr a;
+        std::memcpy(a.v, info->const_sum, 32);
+        for (uint32_t i = 0; i < l; i++) a = H::add(a, dec[i]);
+        info->valid_linear = is_zero(a);
+    }
+    TRY(decode_to_host(quad));
+    info->valid_quad = 1;
+    for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[i])) info->valid_quad = 0;
+    const std::vector<uint8_t> sib = decommit(nodes, (nodes.size() / 32 + 1) / 2, idx);
+    info->ms_stage2 = ms_since(t0);
+    t0 = clk::now();
+
+    // ================= stage 3: open the sampled columns of every committed row, assemble the envelope
+    TRY(lig_gather_rows(c, T->cw, R + 3, T->samples));
+    std::vector<uint8_t> smp((R + 3) * (size_t)t * 32);
+    HIP_TRY(c, hipMemcpyAsync(smp.data(), T->samples, smp.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    char ver[17] = {0};
+    std::memcpy(ver, T->job.version, 16);
+    const std::vector<uint8_t> env = serialize_envelope(ver, T->job.program_hash, T->job.generated_at, k, n, t, info->root, sib, idx,
+                                                        enc.data(), enc.data() + (size_t)n * 32, enc.data() + 2 * (size_t)n * 32,
+                                                        smp.data(), smp.size());
+    *proof = (uint8_t*)std::malloc(env.size());
+    if (!*proof) FAIL(c, LIG_E_NOMEM, "proof allocation failed");
+    std::memcpy(*proof, env.data(), env.size());
+    *proof_len = env.size();
+    info->ms_stage3 = ms_since(t0);
+    info->ms_total = ms_since(t_begin);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+}  // extern "C"

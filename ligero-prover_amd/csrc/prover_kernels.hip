@@ -1,0 +1,131 @@
+// prover_kernels.hip -- device side of the batched three-stage prover (prover.hip): row forming from the AES
+// streams, stage-2 random-linear-combination accumulators on the 29-bit-limb core, witness/randomness inner
+// products.  Counterparts in the reference: witness_manager::pad_encoding_random / process_masks
+// (include/zkp/backend/witness_manager.hpp:271-336, host OpenSSL one element at a time), check_code /
+// check_linear / check_quadratic (include/zkp/nonbatch_context.hpp:756-780: 2-9 full-vector launches per row).
+#include "fr29.hpp"
+#include "kernels.hpp"
+
+namespace lig {
+
+__device__ __forceinline__ f29 f29_zero() {
+    f29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    return r;
+}
+__device__ __forceinline__ f29 f29_const_r2() {
+    return f29{{F29_R2(0), F29_R2(1), F29_R2(2), F29_R2(3), F29_R2(4), F29_R2(5), F29_R2(6), F29_R2(7), F29_R2(8)}};
+}
+
+// ---------------------------------------------------------------------------------------------- stage 2
+// Partial accumulators over one group of rows, one thread per codeword column:
+//   code_part[g][j] = sum_r rc[r] * U[r][j]           (rc given as rc*R' -> plain products)
+//   lin_part[g][j]  = sum_r U[r][j] * R[r][j]
+// Products are added lazily (limbs renormalised every 6 terms, value < 1.2p * group <= 2^261 for group <= 128).
+__global__ void __launch_bounds__(256) k_rlc_partial(const fr* __restrict__ U, const fr* __restrict__ Rn, size_t rows, uint32_t n,
+                                                     const f29s* __restrict__ rc, uint32_t group_rows, fr* __restrict__ code_part,
+                                                     fr* __restrict__ lin_part) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const size_t r0 = (size_t)blockIdx.y * group_rows;
+    const size_t r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
+    f29 ac = f29_zero(), al = f29_zero();
+    int since = 0;
+    for (size_t r = r0; r < r1; r++) {
+        const f29 u = unpack29(fr_load(U + r * n + j));
+        ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));
+        if (Rn != nullptr) al = f29_add(al, f29_montmul(u, unpack29(fr_load(Rn + r * n + j))));
+        if (++since == 6) { ac = f29_qnorm(ac); al = f29_qnorm(al); since = 0; }
+    }
+    fr_store(code_part + (size_t)blockIdx.y * n + j, pack29(f29_reduce_2p(ac)));
+    if (Rn != nullptr) fr_store(lin_part + (size_t)blockIdx.y * n + j, pack29(f29_montmul(f29_qnorm(al), f29_const_r2())));
+}
+
+// acc[j] = (acc[j] + sum_g part[g][j]) mod p, canonical
+__global__ void __launch_bounds__(256) k_rlc_combine(fr* __restrict__ acc, const fr* __restrict__ part, uint32_t groups, uint32_t n) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    f29 a = unpack29(fr_load(acc + j));
+    for (uint32_t g = 0; g < groups; g++) {
+        a = f29_add(a, unpack29(fr_load(part + (size_t)g * n + j)));     // each term < 2p, limbs normalised
+        if ((g & 3) == 3) a = f29_qnorm(a);
+    }
+    fr_store(acc + j, pack29(f29_canon(f29_qnorm(a))));
+}
+
+// quad[j] += sum_t rq[t] * (U[x_t][j] * U[y_t][j] - U[z_t][j]);  rq2 = rq*R'^2, rq1 = rq*R' (both per triple)
+__global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, uint32_t n, const uint32_t* __restrict__ triples,
+                                                   const f29s* __restrict__ rq2, const f29s* __restrict__ rq1, size_t n_triples,
+                                                   fr* __restrict__ quad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    f29 a = unpack29(fr_load(quad + j));
+    for (size_t t = 0; t < n_triples; t++) {
+        const f29 x = unpack29(fr_load(U + (size_t)triples[3 * t] * n + j));
+        const f29 y = unpack29(fr_load(U + (size_t)triples[3 * t + 1] * n + j));
+        const f29 z = unpack29(fr_load(U + (size_t)triples[3 * t + 2] * n + j));
+        const f29 xy = f29_montmul(f29_montmul(x, y), f29_load_tab(rq2 + t));      // x*y*rq  (< 1.2p)
+        const f29 zq = f29_montmul(z, f29_load_tab(rq1 + t));                       // z*rq    (< 1.2p)
+        a = f29_add(a, f29_add(xy, f29_sub_k2(f29_zero(), zq)));                    // + xy + (2p - zq)
+        a = f29_reduce_2p(a);
+    }
+    fr_store(quad + j, pack29(f29_canon(a)));
+}
+
+void launch_rlc_rows29(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const f29s* rc_dev, fr* code, fr* lin,
+                       fr* part_code, fr* part_lin, uint32_t group_rows) {
+    const uint32_t groups = (uint32_t)((rows + group_rows - 1) / group_rows);
+    dim3 g((n + 255) / 256, groups);
+    hipLaunchKernelGGL(k_rlc_partial, g, dim3(256), 0, s, U, Rn, rows, n, rc_dev, group_rows, part_code, part_lin);
+    hipLaunchKernelGGL(k_rlc_combine, dim3((n + 255) / 256), dim3(256), 0, s, code, part_code, groups, n);
+    if (Rn != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((n + 255) / 256), dim3(256), 0, s, lin, part_lin, groups, n);
+}
+void launch_quad_rows29(hipStream_t s, const fr* U, uint32_t n, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
+                        size_t n_triples, fr* quad) {
+    if (!n_triples) return;
+    hipLaunchKernelGGL(k_quad_rows, dim3((n + 255) / 256), dim3(256), 0, s, U, n, triples_dev, rq2, rq1, n_triples, quad);
+}
+
+// ---------------------------------------------------------------------------------------------- inner products
+// out[r] = sum_{i < data[r]} W[r][i] * Rr[r][i]  (canonical), one workgroup per row.  Used for the linear-test
+// constant of the synthetic constraint stream (the reference accumulates it on the host while generating
+// constraints: linear_sums(), src/webgpu_prover.cpp:307).
+__global__ void __launch_bounds__(256) k_dot_rows(const fr* __restrict__ W, const fr* __restrict__ Rr, const uint32_t* __restrict__ data,
+                                                  uint32_t k, fr* __restrict__ out) {
+    __shared__ uint32_t sh[256 * 9];
+    const size_t row = blockIdx.x;
+    const uint32_t cnt = data[row];
+    f29 a = f29_zero();
+    int since = 0;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        a = f29_add(a, f29_montmul(unpack29(fr_load(W + row * k + i)), unpack29(fr_load(Rr + row * k + i))));
+        if (++since == 6) { a = f29_qnorm(a); since = 0; }
+    }
+    a = f29_reduce_2p(a);
+#pragma unroll
+    for (int i = 0; i < 9; i++) sh[i * 256 + threadIdx.x] = a.v[i];
+    __syncthreads();
+    for (int half = 128; half >= 1; half >>= 1) {
+        if ((int)threadIdx.x < half) {
+            f29 x, y;
+#pragma unroll
+            for (int i = 0; i < 9; i++) { x.v[i] = sh[i * 256 + threadIdx.x]; y.v[i] = sh[i * 256 + threadIdx.x + half]; }
+            x = f29_reduce_2p(f29_add(x, y));
+#pragma unroll
+            for (int i = 0; i < 9; i++) sh[i * 256 + threadIdx.x] = x.v[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        f29 x;
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.v[i] = sh[i * 256];
+        fr_store(out + row, pack29(f29_canon(f29_montmul(x, f29_const_r2()))));
+    }
+}
+void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* data_dev, uint32_t k, size_t rows, fr* out) {
+    if (rows) hipLaunchKernelGGL(k_dot_rows, dim3((uint32_t)rows), dim3(256), 0, s, W, Rr, data_dev, k, out);
+}
+
+}  // namespace lig

@@ -300,3 +300,40 @@ def test_rlc_and_gather_vs_oracle(ctx512):
     assert np.array_equal(c.download(out, (t, 8), offset=2 * t * 32), U[3, idx])
     with pytest.raises(Exception):
         c.sample_init(np.array([n], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("l,k,n,n_linear,n_quad", [
+    (320, 512, 2048, 700, 0), (320, 512, 2048, 640, 330), (320, 512, 2048, 100, 700), (320, 512, 2048, 1, 0),
+    (8000, 8192, 32768, 3 * 8000 + 123, 8000 + 5),
+])
+def test_batched_prover_equals_reference_structured_oracle(amd, l, k, n, n_linear, n_quad):
+    """the whole three-stage flow: proof envelope bytes, root, seeds and the linear constant of the HIP prover
+    (rows encoded once, codewords resident) equal the oracle's reference-structured prover (every row re-encoded
+    per stage, one executor call per row); the restated verifier accepts the HIP proof."""
+    c = amd.Context(l, k, n)
+    try:
+        tr = c.synth_prepare(n_linear, n_quad, generated_at=1234567)
+        proof, info = c.synth_prove(tr)
+        proof2, info2 = c.synth_prove(tr)            # proving twice from the same resident witness is deterministic
+        c.trace_destroy(tr)
+    finally:
+        c.close()
+    assert proof == proof2 and bytes(info.root) == bytes(info2.root)
+    job = ol.make_job(l, k, n, 192, n_linear, n_quad, generated_at=1234567, threads=8)
+    pr = ol.Proof()
+    assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) == 0
+    try:
+        assert info.rows == pr.rows
+        assert bytes(info.root) == bytes(pr.root)
+        assert bytes(info.stage1_seed) == bytes(pr.stage1_seed)
+        assert bytes(info.stage2_seed) == bytes(pr.stage2_seed)
+        assert bytes(info.const_sum) == bytes(pr.const_sum)
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        want = bytes(pr.proof[:pr.proof_len])
+        assert len(proof) == len(want)
+        assert proof == want
+        cs = (C.c_uint64 * 4)(*pr.const_sum)
+        buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+        assert ol.lib().lo_verify(C.byref(job), cs, buf, len(proof)) == 1
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
