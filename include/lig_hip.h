@@ -146,11 +146,11 @@ typedef struct {
 /* untimed: plans the rows, allocates the resident buffers, generates the witness matrix on the GPU */
 int  lig_synth_prepare(lig_ctx *ctx, const lig_synth_job *job, lig_trace **out);
 /* the hot path: stage 1 (pads, masks, encode, column hash, Merkle), stage 2 (randomness rows, accumulators,
- * seeds, sampling, self-check), stage 3 (column gather, envelope).  *proof is malloc'ed: lig_proof_free. */
-int  lig_synth_prove(lig_trace *trace, uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+ * seeds, sampling, self-check), stage 3 (column gather, envelope).  *proof points into pinned host memory owned
+ * by the trace: valid until the next lig_synth_prove on it or lig_trace_destroy. */
+int  lig_synth_prove(lig_trace *trace, const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
 uint64_t lig_trace_rows(const lig_trace *trace);
 void lig_trace_destroy(lig_trace *trace);
-void lig_proof_free(uint8_t *proof);
 
 /* Measurement hook (no reference counterpart): while enabled, every lig_encode_rows launch group records HIP
  * events on the context stream immediately around the dominant kernel (encode_mid).  lig_profile_read syncs

@@ -27,7 +27,7 @@ EXPORTS = [
     "lig_powmod", "lig_sha_state_bytes", "lig_sha_init", "lig_sha_update", "lig_sha_final", "lig_sample_init",
     "lig_sample_gather", "lig_encode_rows", "lig_sha_update_rows", "lig_merkle_nodes", "lig_merkle_build",
     "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
-    "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy", "lig_proof_free",
+    "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
 ]
 
 
@@ -105,8 +105,6 @@ def load_library():
     L.lig_trace_rows.restype = u64
     L.lig_trace_destroy.argtypes = [vp]
     L.lig_trace_destroy.restype = None
-    L.lig_proof_free.argtypes = [C.POINTER(C.c_uint8)]
-    L.lig_proof_free.restype = None
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -245,12 +243,13 @@ class Context:
         self.check(self.L.lig_synth_prepare(self.h, C.byref(job), C.byref(t)))
         return t
 
-    def synth_prove(self, trace):
+    def synth_prove(self, trace, copy=True):
+        """-> (proof bytes, ProofInfo); copy=False returns (address, length) of the trace-owned pinned buffer"""
         proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
         self.check(self.L.lig_synth_prove(trace, C.byref(proof), C.byref(ln), C.byref(info)))
-        data = C.string_at(proof, ln.value)
-        self.L.lig_proof_free(proof)
-        return data, info
+        if not copy:
+            return (C.addressof(proof.contents), ln.value), info
+        return C.string_at(proof, ln.value), info
 
     def trace_destroy(self, trace):
         self.L.lig_trace_destroy(trace)

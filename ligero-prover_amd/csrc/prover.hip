@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -133,7 +135,7 @@ std::vector<uint32_t> sample_columns(const uint8_t seed[32], uint32_t n, uint32_
     return out;
 }
 // merkle_tree::decommit + canonical sibling order (merkle_tree.hpp:155-215, proof_serializer.hpp:82-117)
-std::vector<uint8_t> decommit(const std::vector<uint8_t>& nodes, size_t P, const std::vector<uint32_t>& idx) {
+std::vector<uint8_t> decommit(const uint8_t* nodes, size_t P, const std::vector<uint32_t>& idx) {
     std::vector<uint8_t> sib;
     std::vector<uint8_t> known(P, 0), upper(P, 0);
     for (uint32_t i : idx) known[i] = 1;
@@ -144,8 +146,8 @@ std::vector<uint8_t> decommit(const std::vector<uint8_t>& nodes, size_t P, const
             const size_t ll = i - start;
             const bool kl = known[ll], kr = known[ll + 1];
             if (kl && kr) upper[ll / 2] = 1;
-            else if (kr) { sib.insert(sib.end(), nodes.begin() + 32 * i, nodes.begin() + 32 * i + 32); upper[ll / 2] = 1; }
-            else if (kl) { sib.insert(sib.end(), nodes.begin() + 32 * (i + 1), nodes.begin() + 32 * (i + 1) + 32); upper[ll / 2] = 1; }
+            else if (kr) { sib.insert(sib.end(), nodes + 32 * i, nodes + 32 * i + 32); upper[ll / 2] = 1; }
+            else if (kl) { sib.insert(sib.end(), nodes + 32 * (i + 1), nodes + 32 * (i + 1) + 32); upper[ll / 2] = 1; }
         }
         known.swap(upper);
         start = (start - 1) / 2; end = (end - 1) / 2;
@@ -164,12 +166,14 @@ struct Pb {
 };
 size_t varlen(uint64_t v) { size_t n = 1; while (v > 0x7f) { v >>= 7; n++; } return n; }
 
-// serialize_proof (include/zkp/proof_serializer.hpp:166-191) + metadata (src/webgpu_prover.cpp:410-427).
-// The four FixedU32Vector payloads are the raw little-endian limb bytes and are appended without re-copying.
-std::vector<uint8_t> serialize_envelope(const char* version, const uint8_t program_hash[32], int64_t generated_at, uint32_t k,
-                                        uint32_t n, uint32_t t, const uint8_t root[32], const std::vector<uint8_t>& siblings,
-                                        const std::vector<uint32_t>& idx, const uint8_t* code, const uint8_t* lin, const uint8_t* quad,
-                                        const uint8_t* samples, size_t sample_bytes) {
+// serialize_proof (include/zkp/proof_serializer.hpp:166-191) + metadata (src/webgpu_prover.cpp:410-427), written
+// straight into a caller-provided (pinned) buffer.  The four FixedU32Vector payloads are raw little-endian limb
+// bytes: the three accumulators are copied in, the position of the sample payload is returned so that the
+// device->host copy of the opened columns lands directly inside the envelope.
+struct EnvelopeLayout { size_t total = 0, samples_off = 0; };
+EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, const uint8_t program_hash[32], int64_t generated_at,
+                              uint32_t k, uint32_t n, uint32_t t, const uint8_t root[32], const std::vector<uint8_t>& siblings,
+                              const std::vector<uint32_t>& idx, const uint8_t* enc3, size_t sample_bytes) {
     auto digest = [](const uint8_t d[32]) { Pb m; m.bytes(1, d, 32); return m; };
     Pb meta;
     if (version[0]) meta.bytes(1, version, std::strlen(version));
@@ -186,17 +190,25 @@ std::vector<uint8_t> serialize_envelope(const char* version, const uint8_t progr
     auto fixed_len = [](size_t nb) { return nb ? 1 + varlen(nb) + nb : 0; };
     const size_t body_len = 1 + varlen(md.b.size()) + md.b.size() + 3 * (1 + varlen(fixed_len(vec)) + fixed_len(vec)) + 1 +
                             varlen(fixed_len(sample_bytes)) + fixed_len(sample_bytes);
-    Pb out;
-    out.b.reserve(body_len + meta.b.size() + 32);
-    out.msg(1, meta);
-    out.tag(2, 2); out.var(body_len);
-    out.msg(1, md);
-    auto fixed = [&](uint32_t f, const uint8_t* p, size_t nb) {
-        out.tag(f, 2); out.var(fixed_len(nb));
-        if (nb) out.bytes(1, p, nb);
-    };
-    fixed(2, code, vec); fixed(3, lin, vec); fixed(4, quad, vec); fixed(5, samples, sample_bytes);
-    return out.b;
+    Pb head;
+    head.msg(1, meta);
+    head.tag(2, 2); head.var(body_len);
+    head.msg(1, md);
+    EnvelopeLayout L;
+    size_t pos = 0;
+    auto put = [&](const void* p, size_t nb) { if (pos + nb <= cap) std::memcpy(dst + pos, p, nb); pos += nb; };
+    put(head.b.data(), head.b.size());
+    for (uint32_t f = 2; f <= 5; f++) {
+        const size_t nb = f < 5 ? vec : sample_bytes;
+        Pb h;
+        h.tag(f, 2); h.var(fixed_len(nb));
+        if (nb) { h.tag(1, 2); h.var(nb); }
+        put(h.b.data(), h.b.size());
+        if (f < 5) put(enc3 + (size_t)(f - 2) * vec, nb);
+        else { L.samples_off = pos; pos += nb; }
+    }
+    L.total = pos;
+    return L;
 }
 
 struct RowDesc { uint8_t kind; uint32_t data; };   // 0 linear, 1 x, 2 y, 3 z
@@ -234,6 +246,10 @@ struct lig_trace {
     uint32_t* data_dev = nullptr; uint32_t* tri_dev = nullptr;
     lig::f29s* coef_dev = nullptr;      // rc (R) | rq2 (T) | rq1 (T)
     std::vector<uint32_t> triples;
+    uint8_t* h_proof = nullptr; size_t h_proof_cap = 0;   // pinned: the envelope is assembled here (owned by the trace)
+    uint8_t* h_enc = nullptr;                              // pinned: 3 x n accumulators
+    uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
+    uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
     static constexpr size_t CHUNK = 256;
     static constexpr uint32_t GROUP = 64;
 };
@@ -275,6 +291,12 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     TRY(dm((void**)&T->data_dev, (R ? R : 1) * sizeof(uint32_t)));
     TRY(dm((void**)&T->tri_dev, (T->triples.size() ? T->triples.size() : 1) * sizeof(uint32_t)));
     TRY(dm((void**)&T->coef_dev, (R + 2 * T->triples.size() / 3 + 1) * sizeof(lig::f29s)));
+    T->h_proof_cap = (size_t)1 << 19;
+    T->h_proof_cap += 3 * (size_t)n * 32 + (R + 3) * (size_t)t * 32;
+    HIP_TRY(c, hipHostMalloc((void**)&T->h_proof, T->h_proof_cap, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&T->h_enc, 3 * (size_t)n * 32, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&T->h_nodes, lig_merkle_nodes(n) * 32, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&T->h_small, ((R ? R : 1) + 2 * (size_t)l + n) * 32, hipHostMallocDefault));
     {
         std::vector<uint32_t> d(R);
         for (size_t r = 0; r < R; r++) d[r] = T->rows[r].data;
@@ -316,12 +338,12 @@ void lig_trace_destroy(lig_trace* T) {
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);
+    (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
     delete T;
 }
-void lig_proof_free(uint8_t* p) { std::free(p); }
 uint64_t lig_trace_rows(const lig_trace* T) { return T ? T->R + 3 : 0; }
 
-int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
+int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
     if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = T->c;
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l;
@@ -331,6 +353,15 @@ int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_
     info->rows = R + 3;
     const auto t_begin = clk::now();
     auto t0 = clk::now();
+    // LIG_TRACE=1: print a synchronised timeline of the prove call to stderr (debug aid, off by default)
+    const bool trace_on = std::getenv("LIG_TRACE") != nullptr;
+    auto t_mark = clk::now();
+    auto mark = [&](const char* what) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(s);
+        std::fprintf(stderr, "[lig_trace] %-28s %8.3f ms\n", what, ms_since(t_mark));
+        t_mark = clk::now();
+    };
 
     // ================= stage 1: row forming (pads + masks from the encoding stream), encode, column hash, Merkle root
     uint32_t rk[60];
@@ -340,31 +371,39 @@ int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_
     uint64_t epos = 0;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, T->msgs, R, pad, k, l, 1, pad);                 // pad_encoding_random of every row
     epos += (uint64_t)R * pad;
+    mark("  pads");
     fr* mask = T->cw + R * (size_t)n;                                                               // the 3 mask rows are formed in place
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;               // code mask: l randoms, zeros to k
     fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, l - 1, 0, 1, 2, 0); epos += l - 1;       // (0, r) x (l-1)
+    mark("  mask fills a");
     {   // last odd slot = -(sum of the others) (witness_manager.hpp:283-297)
-        std::vector<H::Fr> tmp(2 * (size_t)(l - 1));
-        HIP_TRY(c, hipMemcpyAsync(tmp.data(), mlin, tmp.size() * 32, hipMemcpyDeviceToHost, s));
+        H::Fr* tmp = reinterpret_cast<H::Fr*>(T->h_small + (R ? R : 1) * 32);
+        const size_t cnt = 2 * (size_t)(l - 1);
+        HIP_TRY(c, hipMemcpyAsync(tmp, mlin, cnt * 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         H::Fr sum = H::from_u64(0);
-        for (size_t i = 1; i < tmp.size(); i += 2) sum = H::add(sum, tmp[i]);
+        for (size_t i = 1; i < cnt; i += 2) sum = H::add(sum, tmp[i]);
         sum = H::neg(sum);
         HIP_TRY(c, hipMemcpyAsync(mlin + 2 * (size_t)(l - 1) + 1, &sum, 32, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
+    mark("  mask sum on host");
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, l, 0, 1, 2, 0); epos += l;              // (0, r) x l
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
 
+    mark("row forming (pads, masks)");
     TRY(lig_encode_rows(c, T->msgs, T->cw, R));
+    mark("encode message rows");
     TRY(lig_encode(c, mask));
     TRY(lig_encode_2k(c, mlin));
     TRY(lig_encode_2k(c, mquad));
+    mark("encode mask rows");
     TRY(lig_sha_init(c, T->sha_state, n));
     TRY(lig_sha_update_rows(c, T->sha_state, T->cw, R + 3));
+    mark("column sha");
     TRY(lig_sha_final(c, T->sha_state, T->leaves));
     TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
@@ -375,6 +414,7 @@ int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_
         Sha256().add(z, 32).add("Ligero", 7).finish(ih);
         Sha256().add("LigetronStage1", 15).add(info->root, 32).add(ih, 32).finish(info->stage1_seed);
     }
+    mark("merkle + seed");
     info->ms_stage1 = ms_since(t0);
     t0 = clk::now();
 
@@ -413,14 +453,16 @@ int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_
         lig::launch_rlc_rows29(s, T->cw + b * n, T->rcw, nb, n, T->coef_dev + b, code, lin, T->parts, T->parts + groups * (size_t)n,
                                lig_trace::GROUP);
     }
+    mark("stage2 rows (rng+dot+encode+rlc)");
     lig::launch_quad_rows29(s, T->cw, n, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);                     // masks (nonbatch_context.hpp:739-753)
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
-    std::vector<uint8_t> enc(3 * (size_t)n * 32);
-    HIP_TRY(c, hipMemcpyAsync(enc.data(), T->acc, enc.size(), hipMemcpyDeviceToHost, s));
-    std::vector<H::Fr> dots(R);
-    if (R) HIP_TRY(c, hipMemcpyAsync(dots.data(), T->dots, R * 32, hipMemcpyDeviceToHost, s));
+    uint8_t* enc = T->h_enc;
+    const size_t enc_bytes = 3 * (size_t)n * 32;
+    HIP_TRY(c, hipMemcpyAsync(enc, T->acc, enc_bytes, hipMemcpyDeviceToHost, s));
+    const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
+    if (R) HIP_TRY(c, hipMemcpyAsync(T->h_small, T->dots, R * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     {
         H::Fr sum = H::from_u64(0);
@@ -428,17 +470,20 @@ int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_
         sum = H::neg(sum);
         std::memcpy(info->const_sum, sum.v, 32);
     }
-    Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc.data(), enc.size()).finish(info->stage2_seed);
+    mark("masks + accumulators to host");
+    Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
+    mark("stage2 seed hash");
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     TRY(lig_sample_init(c, idx.data(), idx.size()));
-    std::vector<uint8_t> nodes(lig_merkle_nodes(n) * 32);
-    HIP_TRY(c, hipMemcpyAsync(nodes.data(), T->nodes, nodes.size(), hipMemcpyDeviceToHost, s));
+    const size_t n_nodes = lig_merkle_nodes(n);
+    HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
+    mark("sampling + nodes to host");
     // prover self-check (src/webgpu_prover.cpp:355-386,465-469): decode the three accumulators
-    std::vector<H::Fr> dec(n);
+    H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + ((R ? R : 1) + 2 * (size_t)l) * 32);
     auto decode_to_host = [&](const fr* src) -> int {
         HIP_TRY(c, hipMemcpyAsync(tmp, src, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
         TRY(lig_decode(c, tmp));
-        HIP_TRY(c, hipMemcpyAsync(dec.data(), tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(dec, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         return LIG_OK;
     };
@@ -456,24 +501,25 @@ int lig_synth_prove(lig_trace* T, uint8_t** proof, size_t* proof_len, lig_proof_
     TRY(decode_to_host(quad));
     info->valid_quad = 1;
     for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[i])) info->valid_quad = 0;
-    const std::vector<uint8_t> sib = decommit(nodes, (nodes.size() / 32 + 1) / 2, idx);
+    mark("self-check decodes");
+    const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
+    mark("decommit");
     info->ms_stage2 = ms_since(t0);
     t0 = clk::now();
 
     // ================= stage 3: open the sampled columns of every committed row, assemble the envelope
     TRY(lig_gather_rows(c, T->cw, R + 3, T->samples));
-    std::vector<uint8_t> smp((R + 3) * (size_t)t * 32);
-    HIP_TRY(c, hipMemcpyAsync(smp.data(), T->samples, smp.size(), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
     char ver[17] = {0};
     std::memcpy(ver, T->job.version, 16);
-    const std::vector<uint8_t> env = serialize_envelope(ver, T->job.program_hash, T->job.generated_at, k, n, t, info->root, sib, idx,
-                                                        enc.data(), enc.data() + (size_t)n * 32, enc.data() + 2 * (size_t)n * 32,
-                                                        smp.data(), smp.size());
-    *proof = (uint8_t*)std::malloc(env.size());
-    if (!*proof) FAIL(c, LIG_E_NOMEM, "proof allocation failed");
-    std::memcpy(*proof, env.data(), env.size());
-    *proof_len = env.size();
+    const size_t smp_bytes = (R + 3) * (size_t)t * 32;
+    const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, ver, T->job.program_hash, T->job.generated_at, k, n, t,
+                                              info->root, sib, idx, enc, smp_bytes);
+    if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
+    HIP_TRY(c, hipMemcpyAsync(T->h_proof + lay.samples_off, T->samples, smp_bytes, hipMemcpyDeviceToHost, s));   // opened columns land in place
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *proof = T->h_proof;
+    *proof_len = lay.total;
+    mark("serialize");
     info->ms_stage3 = ms_since(t0);
     info->ms_total = ms_since(t_begin);
     HIP_TRY(c, hipGetLastError());

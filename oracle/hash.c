@@ -77,8 +77,12 @@ size_t lo_sizeof_sha256(void) { return sizeof(lo_sha256); }
  * byte first, limbs in least-significant-first order.  sha256_final (:180-228) writes the eight
  * state words as native u32 => the stored leaf is the digest with every 4-byte word little-endian. */
 void lo_colsha_init(lo_sha256 *st, size_t ncols) { for (size_t j = 0; j < ncols; j++) lo_sha256_init(&st[j]); }
+extern int lo_omp_threads;
 void lo_colsha_update(lo_sha256 *st, const lo_fr *row, size_t ncols) {
-    for (size_t j = 0; j < ncols; j++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (ncols >= 4096 && lo_omp_threads > 1) num_threads(lo_omp_threads)
+#endif
+    for (long j = 0; j < (long)ncols; j++) {
         const uint32_t *limb = (const uint32_t *)row[j].v;
         uint8_t b[32];
         for (int i = 0; i < 8; i++) { b[4*i] = limb[i] >> 24; b[4*i+1] = limb[i] >> 16; b[4*i+2] = limb[i] >> 8; b[4*i+3] = limb[i]; }

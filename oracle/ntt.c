@@ -20,6 +20,8 @@
 #include <omp.h>
 #endif
 
+int lo_omp_threads = 1;     /* threads for the column-parallel loops (set by lo_prove from job.threads) */
+
 typedef struct {
     uint32_t N, log2N;
     lo_fr *w;      /* w^i * R mod p, i < N/2      (engine.cpp:1391-1401) */
@@ -152,7 +154,10 @@ void lo_encode_rows(const lo_ctx *c, const lo_fr *msgs, lo_fr *codewords, size_t
 /* eltwise kernels (shader/kernels.wgsl.in:326-510) */
 void lo_eltwise(int op, const lo_fr *x, const lo_fr *y, lo_fr *out, size_t count,
                 const lo_fr *scalar, uint32_t bit) {
-    for (size_t i = 0; i < count; i++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (count >= 4096 && lo_omp_threads > 1) num_threads(lo_omp_threads)
+#endif
+    for (long i = 0; i < (long)count; i++) {
         lo_fr t;
         switch (op) {
         case LO_OP_ADD:        lo_fr_add(&out[i], &x[i], &y[i]); break;                 /* :326 */

@@ -22,6 +22,7 @@
 #include <omp.h>
 #endif
 
+extern int lo_omp_threads;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 void lo_synth_key(uint64_t seed, uint8_t key[32]) {
@@ -163,6 +164,7 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     memset(P, 0, sizeof *P);
     const uint32_t l = j->l, k = j->k, n = j->n, t = j->t;
     const int T = j->threads > 0 ? j->threads : 1;
+    lo_omp_threads = T;
     lo_ctx *c = lo_ctx_new(l, k, n);
     if (!c) return -1;
     rowdesc *d; size_t R = plan_rows(j, &d);
@@ -170,7 +172,7 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     lo_fr *rows = malloc(sizeof(lo_fr) * (R ? R : 1) * k);
     lo_fr *mc = malloc(sizeof(lo_fr) * k), *ml = malloc(sizeof(lo_fr) * 2 * k), *mq = malloc(sizeof(lo_fr) * 2 * k);
     lo_form_rows(j, rows, mc, ml, mq);
-    const size_t B = 64;                      /* rows encoded per parallel batch */
+    const size_t B = T > 64 ? (size_t)T : 64; /* rows encoded per parallel batch */
     lo_fr *cws = malloc(sizeof(lo_fr) * B * n), *rws = malloc(sizeof(lo_fr) * B * n);
     lo_fr *m3 = malloc(sizeof(lo_fr) * 3 * n);
 
@@ -181,7 +183,14 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     for (size_t b = 0; b < R; b += B) {
         size_t nb = R - b < B ? R - b : B;
         lo_encode_rows(c, rows + b * k, cws, nb, T);
-        for (size_t r = 0; r < nb; r++) lo_colsha_update(st, cws + r * n, n);
+        /* per-row sha256_digest_update calls, run column-block parallel across the batch for the timing run */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(T)
+#endif
+        for (long jb = 0; jb < (long)n; jb += 256) {
+            size_t blk = n - jb < 256 ? n - jb : 256;
+            for (size_t r = 0; r < nb; r++) lo_colsha_update(st + jb, cws + r * n + jb, blk);
+        }
     }
     encode_row(c, m3, mc, k, n); encode_mask2k(c, m3 + n, ml, k, n); encode_mask2k(c, m3 + 2 * (size_t)n, mq, k, n);
     for (int r = 0; r < 3; r++) lo_colsha_update(st, m3 + (size_t)r * n, n);
@@ -202,24 +211,45 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     lo_fr csum; lo_fr_from_u64(&csum, 0);
     for (size_t b = 0, nb; b < R; b += nb) {
         nb = batch_len(d, b, R, B);
-        for (size_t r = 0; r < nb; r++) {
-            rand_row(&lin_rng, rrows + r * k, d[b + r].data, k);
+        /* dense randomness rows: positions in the linear stream are prefix sums, so rows are independent */
+        uint64_t *lpos = malloc(sizeof(uint64_t) * nb);
+        lo_fr *psum = malloc(sizeof(lo_fr) * nb), *rcs = malloc(sizeof(lo_fr) * nb), *rqs = malloc(sizeof(lo_fr) * nb);
+        for (size_t r = 0; r < nb; r++) { lpos[r] = lin_rng.pos; lin_rng.pos += d[b + r].data; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T)
+#endif
+        for (long r = 0; r < (long)nb; r++) {
+            lo_rng lr = lin_rng; lr.pos = lpos[r];
+            rand_row(&lr, rrows + r * k, d[b + r].data, k);
             const lo_fr *w = rows + (b + r) * k, *rr = rrows + r * k;
-            for (uint32_t i = 0; i < d[b + r].data; i++) { lo_fr pr; lo_fr_mul(&pr, &w[i], &rr[i]); lo_fr_add(&csum, &csum, &pr); }
+            lo_fr acc; lo_fr_from_u64(&acc, 0);
+            for (uint32_t i = 0; i < d[b + r].data; i++) { lo_fr pr; lo_fr_mul(&pr, &w[i], &rr[i]); lo_fr_add(&acc, &acc, &pr); }
+            psum[r] = acc;
         }
+        for (size_t r = 0; r < nb; r++) lo_fr_add(&csum, &csum, &psum[r]);
         lo_encode_rows(c, rows + b * k, cws, nb, T);
         lo_encode_rows(c, rrows, rws, nb, T);
-        for (size_t r = 0; r < nb; r++) {
-            lo_fr rc; lo_rng_next(&code_rng, &rc);                                        /* check_code */
-            lo_eltwise(LO_OP_FMA_CONST, cws + r * n, NULL, P->code, n, &rc, 0);
-            lo_eltwise(LO_OP_FMA, cws + r * n, rws + r * n, P->lin, n, NULL, 0);          /* check_linear */
-            if (d[b + r].kind == 3) {                                                     /* check_quadratic */
-                lo_fr rq; lo_rng_next(&quad_rng, &rq);
-                lo_eltwise(LO_OP_MUL, cws + (r - 2) * n, cws + (r - 1) * n, tmp1, n, NULL, 0);
-                lo_eltwise(LO_OP_SUB, tmp1, cws + r * n, tmp2, n, NULL, 0);
-                lo_eltwise(LO_OP_FMA_CONST, tmp2, NULL, P->quad, n, &rq, 0);
+        for (size_t r = 0; r < nb; r++) {                       /* coefficient draws in call order */
+            lo_rng_next(&code_rng, &rcs[r]);
+            if (d[b + r].kind == 3) lo_rng_next(&quad_rng, &rqs[r]);
+        }
+        /* the per-row executor calls of check_code / check_linear / check_quadratic, column-block parallel */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(T)
+#endif
+        for (long jb = 0; jb < (long)n; jb += 256) {
+            size_t blk = n - jb < 256 ? n - jb : 256;
+            for (size_t r = 0; r < nb; r++) {
+                lo_eltwise(LO_OP_FMA_CONST, cws + r * n + jb, NULL, P->code + jb, blk, &rcs[r], 0);
+                lo_eltwise(LO_OP_FMA, cws + r * n + jb, rws + r * n + jb, P->lin + jb, blk, NULL, 0);
+                if (d[b + r].kind == 3) {
+                    lo_eltwise(LO_OP_MUL, cws + (r - 2) * n + jb, cws + (r - 1) * n + jb, tmp1 + jb, blk, NULL, 0);
+                    lo_eltwise(LO_OP_SUB, tmp1 + jb, cws + r * n + jb, tmp2 + jb, blk, NULL, 0);
+                    lo_eltwise(LO_OP_FMA_CONST, tmp2 + jb, NULL, P->quad + jb, blk, &rqs[r], 0);
+                }
             }
         }
+        free(lpos); free(psum); free(rcs); free(rqs);
     }
     lo_eltwise(LO_OP_ADD_ASSIGN, m3, NULL, P->code, n, NULL, 0);
     lo_eltwise(LO_OP_ADD_ASSIGN, m3 + n, NULL, P->lin, n, NULL, 0);
