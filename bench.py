@@ -166,19 +166,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     pkg = load_pkg()
+    spec = importlib.util.spec_from_file_location("lig_dist", os.path.join(ROOT, "ligero-prover_amd", "dist.py"))
+    lig_dist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lig_dist)
+    group = lig_dist.Group("nccl")          # RCCL over xGMI; a no-op object when WORLD_SIZE == 1
+    dist = group.dist
+
     ctx = pkg.Context(L_, K_, N_, device=local_rank)
     wl = (FullWorkload if a.workload == "full" else EncodeWorkload)(ctx, 1 << log2c)
 
     def fence():
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -192,10 +191,7 @@ def main():
     dt = time.perf_counter() - t0
     launches, prows, kms = ctx.profile_read()
     ctx.profile_enable(False)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = group.max_over_ranks(dt)
 
     if rank == 0:
         total_constraints = wl.constraints * a.steps * world
@@ -224,9 +220,7 @@ def main():
         print(json.dumps(out))
     wl.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

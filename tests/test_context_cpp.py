@@ -1,0 +1,43 @@
+"""The C++ mirror of the reference executor (include/lig_hip_context.hpp) compiles against a driver written
+like nonbatch_stage1_context (CPU test: syntax + link), and on the GPU produces the oracle's leaves."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import hip_lib
+import oracle_lib as ol
+
+ROOT = hip_lib.ROOT
+SRC = os.path.join(ROOT, "tests", "cpp", "stage1_rows.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "stage1_rows")
+
+
+def build_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), SRC,
+                           "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip",
+                           "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-o", EXE])
+    return EXE
+
+
+def test_hip_context_header_compiles_and_links():
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only", SRC])
+    assert os.path.exists(build_exe())
+
+
+@pytest.mark.gpu
+def test_hip_context_stage1_rows_match_oracle():
+    exe = build_exe()
+    rows, k, n = 3, 512, 2048
+    out = subprocess.check_output([exe, str(rows)]).decode().strip()
+    msgs = np.zeros((rows, k, 8), dtype=np.uint32)
+    for r in range(rows):
+        vals = 1000003 * (r + 1) + np.arange(k, dtype=np.uint64)
+        msgs[r, :, 0] = (vals & 0xFFFFFFFF).astype(np.uint32)
+        msgs[r, :, 1] = (vals >> 32).astype(np.uint32)
+    cws = ol.Ctx(320, k, n).encode_rows(msgs, threads=2)
+    assert out == ol.colsha(cws).tobytes().hex()

@@ -1,0 +1,63 @@
+"""world_size-2 gloo test (CPU) of the N>1 plumbing used by bench.py: job dealing, barrier, MAX/SUM reductions,
+digest exchange.  The per-rank compute is HIP-only and is covered by the -m gpu tests."""
+import hashlib
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import hashlib, importlib.util, json, os, sys, time
+    root = sys.argv[1]
+    spec = importlib.util.spec_from_file_location("lig_dist", os.path.join(root, "ligero-prover_amd", "dist.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    g = m.Group("gloo")
+    jobs = g.my_jobs(7)
+    g.barrier()
+    t = 0.010 * (g.rank + 1)                       # rank 1 is the slow one
+    worst = g.max_over_ranks(t)
+    total = g.sum_over_ranks(len(jobs) * 1000)
+    digs = g.gather_digests(hashlib.sha256(bytes([g.rank])).digest())
+    print(json.dumps({"rank": g.rank, "world": g.world, "jobs": jobs, "worst": worst, "total": total,
+                      "digests": [d.hex() for d in digs]}))
+    g.close()
+''')
+
+
+def test_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        o, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err.decode()[-2000:]
+        outs.append(__import__("json").loads(o.decode().strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert [o["world"] for o in outs] == [2, 2]
+    assert outs[0]["jobs"] == [0, 2, 4, 6] and outs[1]["jobs"] == [1, 3, 5]            # every job exactly once
+    assert all(abs(o["worst"] - 0.020) < 1e-12 for o in outs)                          # MAX over ranks
+    assert all(o["total"] == 7000 for o in outs)                                       # whole-job units
+    want = [hashlib.sha256(bytes([r])).hexdigest() for r in range(2)]
+    assert all(o["digests"] == want for o in outs)
+
+
+def test_single_process_group_is_a_noop():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lig_dist", os.path.join(ROOT, "ligero-prover_amd", "dist.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    try:
+        g = m.Group()
+        assert (g.rank, g.world) == (0, 1) and g.my_jobs(3) == [0, 1, 2]
+        assert g.max_over_ranks(1.5) == 1.5 and g.sum_over_ranks(4) == 4
+        g.barrier(); g.close()
+    finally:
+        os.environ.update(env)
