@@ -14,6 +14,9 @@ struct lig_ctx {
     int device = 0;
     uint32_t l = 0, k = 0, n = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: column hashing / row forming overlapped with encodes
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    lig::NttPlan plan_half;                   // size 2k, root w_n^2
     std::string err;
     lig::NttPlan plan[3];
     lig::EncodePlan ep;
@@ -32,6 +35,9 @@ struct lig_ctx {
     size_t prof_used = 0;
     uint64_t prof_rows = 0;
 };
+
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half);
+int lig_internal_extend_2k(lig_ctx* c, void* buf);
 
 #define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; } while (0)
 #define HIP_TRY(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); return LIG_E_HIP; } } while (0)

@@ -70,6 +70,13 @@ __device__ __forceinline__ fr pack29(const f29& x) {
 }
 
 __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// p[0] = 2^28 + 1: hipcc strength-reduces m * p[0] + acc into two 64-bit shift-adds (2 half-rate ops + moves);
+// keeping the constant opaque in an SGPR leaves it as one v_mad_u64_u32.
+__device__ __forceinline__ uint32_t f29_p0_opaque() {
+    uint32_t p0 = F29_P(0);
+    asm volatile("" : "+s"(p0));
+    return p0;
+}
 
 // Montgomery product a*b/2^261 mod p.  a: lazy, limbs < 1.25 * 2^31 (top limb < 2^31); b: normalised, < p.
 // Result: normalised limbs, value < a*p/2^261 + p  (< 1.2 p for value(a) < 32 p).
@@ -79,6 +86,7 @@ __device__ __forceinline__ f29 f29_montmul(const f29& a, const f29& b) {
     uint32_t m[9];
     f29 t;
     uint64_t acc = 0;
+    const uint32_t p0 = f29_p0_opaque();
 #pragma unroll
     for (int c = 0; c < 9; c++) {
 #pragma unroll
@@ -86,7 +94,7 @@ __device__ __forceinline__ f29 f29_montmul(const f29& a, const f29& b) {
 #pragma unroll
         for (int i = 0; i < c; i++) acc = mad64(m[i], F29_P(c - i), acc);
         m[c] = ((uint32_t)acc * F29_N0) & F29_MASK;
-        acc = mad64(m[c], F29_P(0), acc);
+        acc = mad64(m[c], p0, acc);
         acc >>= 29;
     }
 #pragma unroll

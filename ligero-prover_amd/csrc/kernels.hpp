@@ -39,8 +39,9 @@ void ntt_generic_fold(hipStream_t s, fr* buf, uint32_t half, size_t rows, size_t
 // ---- ntt_encode.hip
 bool encode_fast_supported(uint32_t k);
 // ev0/ev1 (optional): HIP events recorded on `s` immediately before/after the dominant kernel (encode_mid)
-void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* codewords, fr* scratch_y,
-                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1);
+// half: produce only the 2k evaluations on the subgroup <w_n^2> (out[m] = P(w_n^(2m)), rows x 2k) instead of the codeword
+void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y,
+                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, bool half = false);
 
 // ---- eltwise.hip
 void launch_eltwise(hipStream_t s, int op, const fr* x, const fr* y, fr* out, size_t count, fr scalar, uint32_t bit);

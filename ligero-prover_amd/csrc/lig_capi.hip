@@ -164,6 +164,10 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     if ((rc = make_plan(c, c->plan[LIG_SIZE_K], k, wk)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan[LIG_SIZE_2K], 2 * k, w2k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
+    if ((rc = make_plan(c, c->plan_half, 2 * k, H::mul(w4k, w4k))) != LIG_OK) return rc;     // the subgroup <w_n^2>, order 2k
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->fast = lig::encode_fast_supported(k);
     if (c->fast && (rc = make_encode_plan(c, wk, w4k)) != LIG_OK) return rc;
     HIP_TRY(c, hipMalloc((void**)&c->rk_dev, 60 * sizeof(uint32_t)));
@@ -180,6 +184,9 @@ void lig_ctx_destroy(lig_ctx* c) {
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z); (void)hipFree(c->sample_idx);
     (void)hipFree(c->rk_dev); (void)hipFree(c->small_dev); (void)hipFree(c->tri_dev);
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -245,12 +252,14 @@ static int ensure_scratch(lig_ctx* c, size_t rows) {
     return LIG_OK;
 }
 
-int lig_encode_rows(lig_ctx* c, const void* msgs, void* codewords, size_t rows) {
-    CHECK_CTX(c);
-    if (!rows) return LIG_OK;
-    if (!msgs || !codewords) return LIG_E_ARG;
+}  // extern "C"
+
+// shared by lig_encode_rows and the batched prover.  half = false: out = rows x n codewords.
+// half = true: out = rows x 2k, out[m] = P(w_n^(2m)) (the evaluations on the order-2k subgroup only).
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half) {
+    const size_t out_stride = half ? 2 * (size_t)c->k : (size_t)c->n;
     if (c->fast) {
-        const size_t chunk = 256;     // rows per launch group: keeps the Y/Z scratch (1.25 MiB/row) inside the 256 MiB L3
+        const size_t chunk = 256;     // rows per launch group: keeps the Y/C/Z scratch (1.5 MiB/row) inside the 256 MiB L3
         int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
         if (rc != LIG_OK) return rc;
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {
@@ -263,21 +272,37 @@ int lig_encode_rows(lig_ctx* c, const void* msgs, void* codewords, size_t rows) 
                     c->prof_events.push_back({a, b});
                 }
                 e0 = c->prof_events[c->prof_used].first; e1 = c->prof_events[c->prof_used].second;
-                c->prof_used++; c->prof_rows += nr;
+                c->prof_used++; c->prof_rows += half ? (nr + 1) / 2 : nr;     // a half encode is half a row of K2b work
             }
-            lig::encode_rows_fast(c->stream, c->ep, (const fr*)msgs + r0 * c->k, (fr*)codewords + r0 * c->n, c->scratch_y,
-                                  c->scratch_z, nr, e0, e1);
+            lig::encode_rows_fast(c->stream, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
+                                  c->scratch_z, nr, e0, e1, half);
         }
     } else {
-        // generic path: copy + zero-pad each row, then INTT_k and NTT_n with the radix-2 kernels
-        HIP_TRY(c, hipMemsetAsync(codewords, 0, rows * (size_t)c->n * sizeof(fr), c->stream));
-        HIP_TRY(c, hipMemcpy2DAsync(codewords, (size_t)c->n * sizeof(fr), msgs, (size_t)c->k * sizeof(fr), (size_t)c->k * sizeof(fr),
+        // generic path: copy + zero-pad each row, INTT_k, then NTT_n (or NTT_2k on <w_n^2>) with the radix-2 kernels
+        HIP_TRY(c, hipMemsetAsync(out, 0, rows * out_stride * sizeof(fr), c->stream));
+        HIP_TRY(c, hipMemcpy2DAsync(out, out_stride * sizeof(fr), msgs, (size_t)c->k * sizeof(fr), (size_t)c->k * sizeof(fr),
                                     rows, hipMemcpyDeviceToDevice, c->stream));
-        lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)codewords, rows, c->n);
-        lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)codewords, rows, c->n);
+        lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)out, rows, out_stride);
+        lig::ntt_generic_forward(c->stream, half ? c->plan_half : c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
     }
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
+}
+// values of a degree-<2k polynomial on <w_n^2> (buf[0..2k), rest of the n-buffer zero) -> its values on all n points
+int lig_internal_extend_2k(lig_ctx* c, void* buf) {
+    lig::ntt_generic_inverse(c->stream, c->plan_half, (fr*)buf, 1, c->n);
+    lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+extern "C" {
+
+int lig_encode_rows(lig_ctx* c, const void* msgs, void* codewords, size_t rows) {
+    CHECK_CTX(c);
+    if (!rows) return LIG_OK;
+    if (!msgs || !codewords) return LIG_E_ARG;
+    return lig_internal_encode_rows(c, msgs, codewords, rows, false);
 }
 
 int lig_encode(lig_ctx* c, void* buf) {

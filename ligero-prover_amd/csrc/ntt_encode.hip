@@ -181,15 +181,19 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_coef(const fr* __re
 }
 
 // ---------------------------------------------------------------------------------------------------- K2b
-template <int LOG2B>
+// NC = number of cosets produced: 4 = the full codeword (r = 0..3); 2 = only r in {0, 2}, i.e. the evaluations on
+// the order-2k subgroup <w_n^2> -- enough for a stage-2 randomness row, whose codeword is only ever multiplied
+// point-wise into a degree-<2k accumulator (prover.hip).
+template <int LOG2B, int NC>
 __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __restrict__ Cc, fr* __restrict__ Z,
                                                                  const f29s* __restrict__ tw_fwd, const f29s* __restrict__ twist,
                                                                  const f29s* __restrict__ seam_fwd) {
     constexpr uint32_t B = 1u << LOG2B, T = B / 4;
     __shared__ TileLds<LOG2B> L;
     const uint32_t t = threadIdx.x;
-    const uint32_t r = blockIdx.x & 3u, j1 = (blockIdx.x >> 2) & 7u;
-    const size_t row = blockIdx.x >> 5;
+    const uint32_t ci = blockIdx.x % NC, j1 = (blockIdx.x / NC) & 7u;      // coset slot, tile
+    const uint32_t r = NC == 4 ? ci : 2 * ci;                              // coset number
+    const size_t row = blockIdx.x / (8 * NC);
     const fr* c = Cc + (row * 8 + j1) * (size_t)B;
     f29 x[4];
 #pragma unroll
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __res
         if (r != 0) x[q] = f29_montmul(x[q], f29_load_tab(twist + ((size_t)(r - 1) * 8 + j1) * B + pos));   // w_n^(r*(j1 + 8*pos))
     }
     tile_dft<LOG2B>(x, tw_fwd, L, t);
-    fr* z = Z + ((row * 4 + r) * 8 + j1) * (size_t)B;
+    fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
     if (j1 != 0) {
         const f29s* sf = seam_fwd + (size_t)j1 * B;
 #pragma unroll
@@ -211,27 +215,29 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __res
 }
 
 // ---------------------------------------------------------------------------------------------------- K3
-template <int LOG2B>
+// out row = NC*k elements: element NC*(q2 + B*q1) + ci  (NC = 4: the codeword; NC = 2: index m of w_n^(2m))
+template <int LOG2B, int NC>
 __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
+    constexpr int LOGNC = NC == 4 ? 2 : 1;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t row = gid >> (LOG2B + 2);
+    const size_t row = gid >> (LOG2B + LOGNC);
     if (row >= rows) return;
-    const uint32_t r = (uint32_t)gid & 3u;
-    const uint32_t q2 = ((uint32_t)gid >> 2) & (B - 1);
-    const fr* z = Z + ((row * 4 + r) * 8) * (size_t)B + q2;
+    const uint32_t ci = (uint32_t)gid & (NC - 1);
+    const uint32_t q2 = ((uint32_t)gid >> LOGNC) & (B - 1);
+    const fr* z = Z + ((row * NC + ci) * 8) * (size_t)B + q2;
     f29 a[8];
 #pragma unroll
     for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
     radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
-    fr* out = cw + row * (4 * (size_t)K);
+    fr* out = cw + row * (NC * (size_t)K);
 #pragma unroll
-    for (int q1 = 0; q1 < 8; q1++) fr_store(out + 4 * ((size_t)q2 + (size_t)B * q1) + r, pack29(f29_canon(a[q1])));
+    for (int q1 = 0; q1 < 8; q1++) fr_store(out + NC * ((size_t)q2 + (size_t)B * q1) + ci, pack29(f29_canon(a[q1])));
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 2048 || k == 8192; }
 
-template <int LOG2B>
+template <int LOG2B, int NC>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
                           hipEvent_t ev0, hipEvent_t ev1) {
     constexpr uint32_t B = 1u << LOG2B;
@@ -240,18 +246,22 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL(k_encode_mid<LOG2B>, dim3((uint32_t)(rows * 32)), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
+    hipLaunchKernelGGL((k_encode_mid<LOG2B, NC>), dim3((uint32_t)(rows * 8 * NC)), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
     if (ev1) (void)hipEventRecord(ev1, s);
-    const size_t th3 = rows * B * 4;
-    hipLaunchKernelGGL(k_encode_out<LOG2B>, dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, rows);
+    const size_t th3 = rows * B * NC;
+    hipLaunchKernelGGL((k_encode_out<LOG2B, NC>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, rows);
 }
 
-void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* codewords, fr* scratch_y, fr* scratch_z, size_t rows,
-                      hipEvent_t ev0, hipEvent_t ev1) {
-    switch (ep.log2B) {
-        case 6: encode_rows_t<6>(s, ep, msgs, codewords, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 8: encode_rows_t<8>(s, ep, msgs, codewords, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 10: encode_rows_t<10>(s, ep, msgs, codewords, scratch_y, scratch_z, rows, ev0, ev1); break;
+// half = false: codewords (rows x n).  half = true: rows x 2k values on the order-2k subgroup, out[m] = P(w_n^(2m)).
+void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
+                      hipEvent_t ev0, hipEvent_t ev1, bool half) {
+    switch (ep.log2B * 2 + (half ? 1 : 0)) {
+        case 12: encode_rows_t<6, 4>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 13: encode_rows_t<6, 2>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 16: encode_rows_t<8, 4>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 17: encode_rows_t<8, 2>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 20: encode_rows_t<10, 4>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 21: encode_rows_t<10, 2>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
         default: break;
     }
 }

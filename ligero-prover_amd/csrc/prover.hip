@@ -31,10 +31,10 @@ namespace H = lig::host;
 namespace lig {
 void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,
                           size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride);
-void launch_rlc_rows29(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const f29s* rc_dev, fr* code, fr* lin,
-                       fr* part_code, fr* part_lin, uint32_t group_rows);
-void launch_quad_rows29(hipStream_t s, const fr* U, uint32_t n, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
-                        size_t n_triples, fr* quad);
+void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
+                       const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows);
+void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
+                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
 void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* data_dev, uint32_t k, size_t rows, fr* out);
 }  // namespace lig
 
@@ -249,6 +249,7 @@ struct lig_trace {
     uint8_t* h_proof = nullptr; size_t h_proof_cap = 0;   // pinned: the envelope is assembled here (owned by the trace)
     uint8_t* h_enc = nullptr;                              // pinned: 3 x n accumulators
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
     uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
     static constexpr size_t CHUNK = 256;
     static constexpr uint32_t GROUP = 64;
@@ -279,7 +280,7 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
     TRY(dm((void**)&T->cw, (R + 3) * (size_t)n * 32));
-    TRY(dm((void**)&T->randb, chunk * (size_t)k * 32));
+    TRY(dm((void**)&T->randb, 2 * chunk * (size_t)k * 32));          // double-buffered
     TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
     TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
     TRY(dm((void**)&T->parts, 2 * groups * (size_t)n * 32));
@@ -296,7 +297,11 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     HIP_TRY(c, hipHostMalloc((void**)&T->h_proof, T->h_proof_cap, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&T->h_enc, 3 * (size_t)n * 32, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&T->h_nodes, lig_merkle_nodes(n) * 32, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void**)&T->h_small, ((R ? R : 1) + 2 * (size_t)l + n) * 32, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&T->h_small, ((R ? R : 1) + 2 * (size_t)l + 3 * (size_t)n) * 32, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&T->ev_ready[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&T->ev_used[i], hipEventDisableTiming));
+    }
     {
         std::vector<uint32_t> d(R);
         for (size_t r = 0; r < R; r++) d[r] = T->rows[r].data;
@@ -338,6 +343,7 @@ void lig_trace_destroy(lig_trace* T) {
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);
+    for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
     (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
     delete T;
 }
@@ -395,15 +401,34 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
 
     mark("row forming (pads, masks)");
-    TRY(lig_encode_rows(c, T->msgs, T->cw, R));
+    // Encode chunk by chunk on the main stream; the column hash of chunk b runs on the side stream while chunk
+    // b+1 is being encoded (the hash has only n = 32768 lanes of parallelism -- 512 waves -- and would otherwise
+    // leave most of the chip idle for its whole duration).  Row order = hash order is preserved by stream order.
+    hipStream_t s2 = c->stream2;
+    TRY(lig_sha_init(c, T->sha_state, n));
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    uint64_t absorbed = 0;
+    for (size_t b = 0; b < R; b += lig_trace::CHUNK) {
+        const size_t nb = std::min(lig_trace::CHUNK, R - b);
+        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false));
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+        lig::launch_sha_update_rows(s2, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
+        absorbed += nb;
+    }
     mark("encode message rows");
     TRY(lig_encode(c, mask));
     TRY(lig_encode_2k(c, mlin));
     TRY(lig_encode_2k(c, mquad));
-    mark("encode mask rows");
-    TRY(lig_sha_init(c, T->sha_state, n));
-    TRY(lig_sha_update_rows(c, T->sha_state, T->cw, R + 3));
-    mark("column sha");
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    lig::launch_sha_update_rows(s2, T->sha_state, n, mask, n, 3, absorbed);
+    absorbed += 3;
+    c->sha[T->sha_state].second = absorbed;
+    HIP_TRY(c, hipEventRecord(c->ev_join, s2));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    mark("encode mask rows + column sha tail");
     TRY(lig_sha_final(c, T->sha_state, T->leaves));
     TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
@@ -434,27 +459,63 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
+    // Accumulators.  All three tests are sums of low-degree polynomials, so they are accumulated where they are
+    // cheapest and extended to the n evaluation points once per proof (exact field arithmetic => same values as the
+    // reference's per-row n-point updates, nonbatch_context.hpp:756-780):
+    //   code  = sum_r rc_r * U_r          degree < k : combine the MESSAGE rows (k values per row), encode once;
+    //   lin   = sum_r U_r o R_r           degree < 2k: accumulate on the order-2k subgroup <w_n^2> (the even codeword
+    //   quad  = sum_t rq_t (X o Y - Z)                 positions), then INTT_2k + NTT_n once.  The randomness rows are
+    //                                                  therefore evaluated on <w_n^2> only (2 of the 4 cosets).
     fr* code = T->acc; fr* lin = T->acc + n; fr* quad = T->acc + 2 * (size_t)n; fr* tmp = T->acc + 3 * (size_t)n;
     HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
     const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
-    uint64_t lpos = 0;
-    for (size_t b = 0; b < R; b += lig_trace::CHUNK) {
-        const size_t nb = std::min(lig_trace::CHUNK, R - b);
-        HIP_TRY(c, hipMemsetAsync(T->randb, 0, nb * (size_t)k * 32, s));
+    fr* rhalf = T->rcw;                                   // chunk x 2k
+    // The randomness rows of chunk b+1 (AES sampling: LDS-bound) and their inner products with the witness rows are
+    // formed on the side stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
+    const size_t n_chunks = (R + lig_trace::CHUNK - 1) / lig_trace::CHUNK;
+    std::vector<uint64_t> chunk_pos(n_chunks + 1, 0);
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+        uint64_t cnt = 0;
+        for (size_t r = ci * lig_trace::CHUNK; r < std::min(R, (ci + 1) * lig_trace::CHUNK); r++) cnt += T->rows[r].data;
+        chunk_pos[ci + 1] = chunk_pos[ci] + cnt;
+    }
+    auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
+        const size_t b = ci * lig_trace::CHUNK, nb = std::min(lig_trace::CHUNK, R - b);
+        fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
+        if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
+        HIP_TRY(c, hipMemsetAsync(rb, 0, nb * (size_t)k * 32, s2));
+        uint64_t lpos = chunk_pos[ci];
         for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order
             size_t run = 1;
             const uint32_t d = T->rows[b + r].data;
             while (r + run < nb && T->rows[b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows(s, c->rk_dev, lpos, T->randb + r * k, run, d, k, 0, 1, d);
+            lig::launch_rng_fill_rows(s2, c->rk_dev, lpos, rb + r * k, run, d, k, 0, 1, d);
             lpos += (uint64_t)run * d; r += run;
         }
-        lig::launch_dot_rows(s, T->msgs + b * k, T->randb, T->data_dev + b, k, nb, T->dots + b);
-        TRY(lig_encode_rows(c, T->randb, T->rcw, nb));
-        lig::launch_rlc_rows29(s, T->cw + b * n, T->rcw, nb, n, T->coef_dev + b, code, lin, T->parts, T->parts + groups * (size_t)n,
-                               lig_trace::GROUP);
+        lig::launch_dot_rows(s2, T->msgs + b * k, rb, T->data_dev + b, k, nb, T->dots + b);
+        HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2));
+        return LIG_OK;
+    };
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));            // the side stream starts after the key upload / memset above
+    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    if (n_chunks) TRY(form_rand_chunk(0));
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+        const size_t b = ci * lig_trace::CHUNK, nb = std::min(lig_trace::CHUNK, R - b);
+        fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
+        if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
+        HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
+        TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
+        HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
+        lig::launch_rlc_rows29(s, T->cw + b * n, n, 2, rhalf, 2 * (size_t)k, nb, 2 * k, nullptr, nullptr, lin, T->parts,
+                               T->parts + groups * (size_t)n, lig_trace::GROUP);
+        lig::launch_rlc_rows29(s, T->msgs + b * k, k, 1, nullptr, 0, nb, k, T->coef_dev + b, code, nullptr, T->parts,
+                               T->parts + groups * (size_t)n, lig_trace::GROUP);
     }
     mark("stage2 rows (rng+dot+encode+rlc)");
-    lig::launch_quad_rows29(s, T->cw, n, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
+    lig::launch_quad_rows29(s, T->cw, n, 2, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
+    TRY(lig_encode(c, code));
+    TRY(lig_internal_extend_2k(c, lin));
+    TRY(lig_internal_extend_2k(c, quad));
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);                     // masks (nonbatch_context.hpp:739-753)
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
@@ -463,44 +524,41 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(enc, T->acc, enc_bytes, hipMemcpyDeviceToHost, s));
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
     if (R) HIP_TRY(c, hipMemcpyAsync(T->h_small, T->dots, R * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventRecord(c->ev_join, s));
+    // prover self-check (src/webgpu_prover.cpp:355-386,465-469): the three decodes and the Merkle-node download are
+    // queued now and run on the GPU while the host hashes the 3 MiB of accumulators for the stage-2 seed
+    H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + ((R ? R : 1) + 2 * (size_t)l) * 32);    // 3 x n
+    const fr* accs[3] = {code, lin, quad};
+    for (int a3 = 0; a3 < 3; a3++) {
+        HIP_TRY(c, hipMemcpyAsync(tmp, accs[a3], (size_t)n * 32, hipMemcpyDeviceToDevice, s));
+        TRY(lig_decode(c, tmp));
+        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    }
+    const size_t n_nodes = lig_merkle_nodes(n);
+    HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventSynchronize(c->ev_join));          // accumulators + inner products are on the host
     {
         H::Fr sum = H::from_u64(0);
         for (size_t r = 0; r < R; r++) sum = H::add(sum, dots[r]);
         sum = H::neg(sum);
         std::memcpy(info->const_sum, sum.v, 32);
     }
-    mark("masks + accumulators to host");
     Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
-    mark("stage2 seed hash");
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
+    mark("accumulators to host, seed hash, sampling, decodes");
     TRY(lig_sample_init(c, idx.data(), idx.size()));
-    const size_t n_nodes = lig_merkle_nodes(n);
-    HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
-    mark("sampling + nodes to host");
-    // prover self-check (src/webgpu_prover.cpp:355-386,465-469): decode the three accumulators
-    H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + ((R ? R : 1) + 2 * (size_t)l) * 32);
-    auto decode_to_host = [&](const fr* src) -> int {
-        HIP_TRY(c, hipMemcpyAsync(tmp, src, (size_t)n * 32, hipMemcpyDeviceToDevice, s));
-        TRY(lig_decode(c, tmp));
-        HIP_TRY(c, hipMemcpyAsync(dec, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        return LIG_OK;
-    };
+    HIP_TRY(c, hipStreamSynchronize(s));
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
-    TRY(decode_to_host(code));
     info->valid_code = 1;
     for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
-    TRY(decode_to_host(lin));
     {
         H::Fr a;
         std::memcpy(a.v, info->const_sum, 32);
-        for (uint32_t i = 0; i < l; i++) a = H::add(a, dec[i]);
+        for (uint32_t i = 0; i < l; i++) a = H::add(a, dec[(size_t)n + i]);
         info->valid_linear = is_zero(a);
     }
-    TRY(decode_to_host(quad));
     info->valid_quad = 1;
-    for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[i])) info->valid_quad = 0;
+    for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[2 * (size_t)n + i])) info->valid_quad = 0;
     mark("self-check decodes");
     const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
     mark("decommit");

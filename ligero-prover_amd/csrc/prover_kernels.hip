@@ -19,27 +19,29 @@ __device__ __forceinline__ f29 f29_const_r2() {
 }
 
 // ---------------------------------------------------------------------------------------------- stage 2
-// Partial accumulators over one group of rows, one thread per codeword column:
-//   code_part[g][j] = sum_r rc[r] * U[r][j]           (rc given as rc*R' -> plain products)
-//   lin_part[g][j]  = sum_r U[r][j] * R[r][j]
-// Products are added lazily (limbs renormalised every 6 terms, value < 1.2p * group <= 2^261 for group <= 128).
-__global__ void __launch_bounds__(256) k_rlc_partial(const fr* __restrict__ U, const fr* __restrict__ Rn, size_t rows, uint32_t n,
-                                                     const f29s* __restrict__ rc, uint32_t group_rows, fr* __restrict__ code_part,
-                                                     fr* __restrict__ lin_part) {
+// Partial accumulators over one group of rows, one thread per position j < count:
+//   code_part[g][j] = sum_r rc[r] * U[r][j*ues]        (rc given as rc*R' -> plain products)      if rc  != null
+//   lin_part[g][j]  = sum_r U[r][j*ues] * Rn[r][j]                                                if Rn  != null
+// U rows are urs elements apart and read with element stride ues (ues = 2 picks the codeword values on the
+// order-2k subgroup <w_n^2>), Rn rows are rrs elements apart.  Products are added lazily (limbs renormalised every
+// 6 terms, value < 1.2p * group <= 2^261 for group <= 128).
+__global__ void __launch_bounds__(256) k_rlc_partial(const fr* __restrict__ U, size_t urs, uint32_t ues, const fr* __restrict__ Rn,
+                                                     size_t rrs, size_t rows, uint32_t count, const f29s* __restrict__ rc,
+                                                     uint32_t group_rows, fr* __restrict__ code_part, fr* __restrict__ lin_part) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    if (j >= count) return;
     const size_t r0 = (size_t)blockIdx.y * group_rows;
     const size_t r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
     f29 ac = f29_zero(), al = f29_zero();
     int since = 0;
     for (size_t r = r0; r < r1; r++) {
-        const f29 u = unpack29(fr_load(U + r * n + j));
-        ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));
-        if (Rn != nullptr) al = f29_add(al, f29_montmul(u, unpack29(fr_load(Rn + r * n + j))));
+        const f29 u = unpack29(fr_load(U + r * urs + (size_t)j * ues));
+        if (rc != nullptr) ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));
+        if (Rn != nullptr) al = f29_add(al, f29_montmul(u, unpack29(fr_load(Rn + r * rrs + j))));
         if (++since == 6) { ac = f29_qnorm(ac); al = f29_qnorm(al); since = 0; }
     }
-    fr_store(code_part + (size_t)blockIdx.y * n + j, pack29(f29_reduce_2p(ac)));
-    if (Rn != nullptr) fr_store(lin_part + (size_t)blockIdx.y * n + j, pack29(f29_montmul(f29_qnorm(al), f29_const_r2())));
+    if (rc != nullptr) fr_store(code_part + (size_t)blockIdx.y * count + j, pack29(f29_reduce_2p(ac)));
+    if (Rn != nullptr) fr_store(lin_part + (size_t)blockIdx.y * count + j, pack29(f29_montmul(f29_qnorm(al), f29_const_r2())));
 }
 
 // acc[j] = (acc[j] + sum_g part[g][j]) mod p, canonical
@@ -54,17 +56,17 @@ __global__ void __launch_bounds__(256) k_rlc_combine(fr* __restrict__ acc, const
     fr_store(acc + j, pack29(f29_canon(f29_qnorm(a))));
 }
 
-// quad[j] += sum_t rq[t] * (U[x_t][j] * U[y_t][j] - U[z_t][j]);  rq2 = rq*R'^2, rq1 = rq*R' (both per triple)
-__global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, uint32_t n, const uint32_t* __restrict__ triples,
-                                                   const f29s* __restrict__ rq2, const f29s* __restrict__ rq1, size_t n_triples,
-                                                   fr* __restrict__ quad) {
+// quad[j] += sum_t rq[t] * (U[x_t][j*ues] * U[y_t][j*ues] - U[z_t][j*ues]);  rq2 = rq*R'^2, rq1 = rq*R' (per triple)
+__global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, size_t urs, uint32_t ues, uint32_t count,
+                                                   const uint32_t* __restrict__ triples, const f29s* __restrict__ rq2,
+                                                   const f29s* __restrict__ rq1, size_t n_triples, fr* __restrict__ quad) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    if (j >= count) return;
     f29 a = unpack29(fr_load(quad + j));
     for (size_t t = 0; t < n_triples; t++) {
-        const f29 x = unpack29(fr_load(U + (size_t)triples[3 * t] * n + j));
-        const f29 y = unpack29(fr_load(U + (size_t)triples[3 * t + 1] * n + j));
-        const f29 z = unpack29(fr_load(U + (size_t)triples[3 * t + 2] * n + j));
+        const f29 x = unpack29(fr_load(U + (size_t)triples[3 * t] * urs + (size_t)j * ues));
+        const f29 y = unpack29(fr_load(U + (size_t)triples[3 * t + 1] * urs + (size_t)j * ues));
+        const f29 z = unpack29(fr_load(U + (size_t)triples[3 * t + 2] * urs + (size_t)j * ues));
         const f29 xy = f29_montmul(f29_montmul(x, y), f29_load_tab(rq2 + t));      // x*y*rq  (< 1.2p)
         const f29 zq = f29_montmul(z, f29_load_tab(rq1 + t));                       // z*rq    (< 1.2p)
         a = f29_add(a, f29_add(xy, f29_sub_k2(f29_zero(), zq)));                    // + xy + (2p - zq)
@@ -73,18 +75,20 @@ __global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, uin
     fr_store(quad + j, pack29(f29_canon(a)));
 }
 
-void launch_rlc_rows29(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const f29s* rc_dev, fr* code, fr* lin,
-                       fr* part_code, fr* part_lin, uint32_t group_rows) {
+// one group-partial pass + combine.  Either rc_dev (code-type: acc_code += sum rc*U) or Rn (linear-type:
+// acc_lin += sum U*Rn) or both.
+void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
+                       const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows) {
     const uint32_t groups = (uint32_t)((rows + group_rows - 1) / group_rows);
-    dim3 g((n + 255) / 256, groups);
-    hipLaunchKernelGGL(k_rlc_partial, g, dim3(256), 0, s, U, Rn, rows, n, rc_dev, group_rows, part_code, part_lin);
-    hipLaunchKernelGGL(k_rlc_combine, dim3((n + 255) / 256), dim3(256), 0, s, code, part_code, groups, n);
-    if (Rn != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((n + 255) / 256), dim3(256), 0, s, lin, part_lin, groups, n);
+    dim3 g((count + 255) / 256, groups);
+    hipLaunchKernelGGL(k_rlc_partial, g, dim3(256), 0, s, U, urs, ues, Rn, rrs, rows, count, rc_dev, group_rows, part_code, part_lin);
+    if (rc_dev != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, code, part_code, groups, count);
+    if (Rn != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, lin, part_lin, groups, count);
 }
-void launch_quad_rows29(hipStream_t s, const fr* U, uint32_t n, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
-                        size_t n_triples, fr* quad) {
+void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
+                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad) {
     if (!n_triples) return;
-    hipLaunchKernelGGL(k_quad_rows, dim3((n + 255) / 256), dim3(256), 0, s, U, n, triples_dev, rq2, rq1, n_triples, quad);
+    hipLaunchKernelGGL(k_quad_rows, dim3((count + 255) / 256), dim3(256), 0, s, U, urs, ues, count, triples_dev, rq2, rq1, n_triples, quad);
 }
 
 // ---------------------------------------------------------------------------------------------- inner products
