@@ -14,7 +14,11 @@ struct lig_ctx {
     int device = 0;
     uint32_t l = 0, k = 0, n = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // side stream: column hashing / row forming overlapped with encodes
+    hipStream_t stream2 = nullptr;            // side stream: randomness-row forming overlapped with encodes
+    // CU-partitioned pair for stage 1: the column hash is a latency-bound chain with only n/64 waves; it gets its own
+    // 32 CUs (4 waves per SIMD there) while the row encodes run on the other 224 CUs -- co-residing the two kernels
+    // on the same CUs was measured slower than running them back to back (instruction cache + issue contention).
+    hipStream_t stream_sha = nullptr, stream_enc = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2
     std::string err;
@@ -36,7 +40,7 @@ struct lig_ctx {
     uint64_t prof_rows = 0;
 };
 
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half);
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on = nullptr);
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
 
 #define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; } while (0)

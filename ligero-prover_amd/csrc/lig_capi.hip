@@ -166,6 +166,24 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan_half, 2 * k, H::mul(w4k, w4k))) != LIG_OK) return rc;     // the subgroup <w_n^2>, order 2k
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {   // Optional CU partition for stage 1 (LIG_SHA_CUS_EVERY=e: every e-th CU runs the column hash, the rest the encodes).
+        // OFF by default: measured on MI355X (profiles/r01_overlap_experiments.md) the proof time is the same with the hash
+        // on 32/64 dedicated CUs, co-resident, or merely stream-overlapped -- the chip is at its power/VALU-issue limit, so
+        // the total instruction count, not the placement, sets the time.
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, device));
+        const int cus = prop.multiProcessorCount;
+        const char* e = std::getenv("LIG_SHA_CUS_EVERY");
+        const int every = e ? std::atoi(e) : 0;
+        std::vector<uint32_t> m_sha((cus + 31) / 32, 0), m_enc((cus + 31) / 32, 0);
+        for (int i = 0; i < cus; i++) ((every > 0 && i % every == every - 1) ? m_sha : m_enc)[i / 32] |= 1u << (i % 32);
+        if (every <= 0 || hipExtStreamCreateWithCUMask(&c->stream_sha, (uint32_t)m_sha.size(), m_sha.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&c->stream_enc, (uint32_t)m_enc.size(), m_enc.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->stream_sha) { (void)hipStreamDestroy(c->stream_sha); c->stream_sha = nullptr; }
+            c->stream_enc = nullptr;      // fall back: hash on the side stream, encodes on the main stream
+        }
+    }
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->fast = lig::encode_fast_supported(k);
@@ -186,6 +204,8 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream_sha) (void)hipStreamDestroy(c->stream_sha);
+    if (c->stream_enc) (void)hipStreamDestroy(c->stream_enc);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -256,10 +276,13 @@ static int ensure_scratch(lig_ctx* c, size_t rows) {
 
 // shared by lig_encode_rows and the batched prover.  half = false: out = rows x n codewords.
 // half = true: out = rows x 2k, out[m] = P(w_n^(2m)) (the evaluations on the order-2k subgroup only).
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half) {
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on) {
     const size_t out_stride = half ? 2 * (size_t)c->k : (size_t)c->n;
+    hipStream_t st = on ? on : c->stream;
     if (c->fast) {
-        const size_t chunk = 256;     // rows per launch group: keeps the Y/C/Z scratch (1.5 MiB/row) inside the 256 MiB L3
+        // rows per launch group: the Y/C/Z scratch (1.5 MiB/row) should stay inside the 256 MiB L3 so that K3's
+        // re-read of Z does not go to HBM.  LIG_ENCODE_CHUNK overrides for experiments.
+        static const size_t chunk = [] { const char* e = std::getenv("LIG_ENCODE_CHUNK"); size_t v = e ? (size_t)std::atoi(e) : 0; return v ? v : (size_t)512; }();
         int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
         if (rc != LIG_OK) return rc;
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {
@@ -274,16 +297,16 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                 e0 = c->prof_events[c->prof_used].first; e1 = c->prof_events[c->prof_used].second;
                 c->prof_used++; c->prof_rows += half ? (nr + 1) / 2 : nr;     // a half encode is half a row of K2b work
             }
-            lig::encode_rows_fast(c->stream, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
+            lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
                                   c->scratch_z, nr, e0, e1, half);
         }
     } else {
         // generic path: copy + zero-pad each row, INTT_k, then NTT_n (or NTT_2k on <w_n^2>) with the radix-2 kernels
-        HIP_TRY(c, hipMemsetAsync(out, 0, rows * out_stride * sizeof(fr), c->stream));
+        HIP_TRY(c, hipMemsetAsync(out, 0, rows * out_stride * sizeof(fr), st));
         HIP_TRY(c, hipMemcpy2DAsync(out, out_stride * sizeof(fr), msgs, (size_t)c->k * sizeof(fr), (size_t)c->k * sizeof(fr),
-                                    rows, hipMemcpyDeviceToDevice, c->stream));
-        lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)out, rows, out_stride);
-        lig::ntt_generic_forward(c->stream, half ? c->plan_half : c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
+                                    rows, hipMemcpyDeviceToDevice, st));
+        lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], (fr*)out, rows, out_stride);
+        lig::ntt_generic_forward(st, half ? c->plan_half : c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
     }
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;

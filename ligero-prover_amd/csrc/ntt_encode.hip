@@ -69,7 +69,7 @@ __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const f29& w1, const f29
 
 // ---------------------------------------------------------------------------------------------------- K1
 template <int LOG2B>
-__global__ void __launch_bounds__(256) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29s* __restrict__ seam_inv,
+__global__ void __launch_bounds__(256, 2) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29s* __restrict__ seam_inv,
                                                    const f29s* __restrict__ w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,9 +83,10 @@ __global__ void __launch_bounds__(256) k_encode_in(const fr* __restrict__ msgs, 
     radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
     fr* y = Y + row * K;
     fr_store(y + i2, pack29(f29_reduce_2p(a[0])));
-#pragma unroll
-    for (int j1 = 1; j1 < 8; j1++)
-        fr_store(y + (size_t)j1 * B + i2, pack29(f29_montmul(a[j1], f29_load_tab(seam_inv + (size_t)j1 * B + i2))));
+    // explicit unrolling: hipcc leaves a `#pragma unroll` loop over 7 Montgomery products rolled and then keeps a[] in scratch
+#define LIG_SEAM(J1) fr_store(y + (size_t)(J1) * B + i2, pack29(f29_montmul(a[J1], f29_load_tab(seam_inv + (size_t)(J1) * B + i2))))
+    LIG_SEAM(1); LIG_SEAM(2); LIG_SEAM(3); LIG_SEAM(4); LIG_SEAM(5); LIG_SEAM(6); LIG_SEAM(7);
+#undef LIG_SEAM
 }
 
 // ---------------------------------------------------------------------------------------------------- tile transform
@@ -191,7 +192,10 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __res
     constexpr uint32_t B = 1u << LOG2B, T = B / 4;
     __shared__ TileLds<LOG2B> L;
     const uint32_t t = threadIdx.x;
-    const uint32_t ci = blockIdx.x % NC, j1 = (blockIdx.x / NC) & 7u;      // coset slot, tile
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with a private L2.  The NC
+    // coset workgroups of one tile read the same 32 KiB of coefficients, so they get block ids 8 apart (same XCD)
+    // and the tile index is the fastest-varying part: per group of 8*NC blocks, b = j1 + 8*ci.
+    const uint32_t j1 = blockIdx.x & 7u, ci = (blockIdx.x >> 3) % NC;      // tile, coset slot
     const uint32_t r = NC == 4 ? ci : 2 * ci;                              // coset number
     const size_t row = blockIdx.x / (8 * NC);
     const fr* c = Cc + (row * 8 + j1) * (size_t)B;

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ctx_internal.hpp"
@@ -213,6 +214,19 @@ EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, con
 
 struct RowDesc { uint8_t kind; uint32_t data; };   // 0 linear, 1 x, 2 y, 3 z
 
+// Row-chunk schedule [begin, end) pairs.  Chunks are `big` rows except that the exposed end of a two-stream pipeline
+// is kept short: `head` rows first (stage 2: the encode stream waits for the first randomness rows) and/or a short
+// last chunk of `tail` rows (stage 1: the column hash of the last chunk runs after the last encode).
+std::vector<std::pair<size_t, size_t>> chunk_schedule(size_t R, size_t big, size_t head, size_t tail) {
+    std::vector<std::pair<size_t, size_t>> out;
+    size_t b = 0;
+    if (head && R > head + tail) { out.push_back({0, head}); b = head; }
+    const size_t stop = (tail && R > b + tail) ? R - tail : R;
+    while (b < stop) { const size_t e = std::min(stop, b + big); out.push_back({b, e}); b = e; }
+    if (b < R) out.push_back({b, R});
+    return out;
+}
+
 lig::f29s to_f29s_host(const H::Fr& plain, const H::Fr& scale) {
     const H::Fr m = H::mul(plain, scale);
     lig::f29s o;
@@ -251,7 +265,7 @@ struct lig_trace {
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
     uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
-    static constexpr size_t CHUNK = 256;
+    static constexpr size_t CHUNK = 512;
     static constexpr uint32_t GROUP = 64;
 };
 
@@ -405,28 +419,35 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     // b+1 is being encoded (the hash has only n = 32768 lanes of parallelism -- 512 waves -- and would otherwise
     // leave most of the chip idle for its whole duration).  Row order = hash order is preserved by stream order.
     hipStream_t s2 = c->stream2;
+    hipStream_t s_sha = c->stream_sha ? c->stream_sha : c->stream2;      // 32 CUs of their own when CU masks are available
+    hipStream_t s_enc = c->stream_enc ? c->stream_enc : s;               // the other 224 CUs
     TRY(lig_sha_init(c, T->sha_state, n));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
+    if (s_enc != s) HIP_TRY(c, hipStreamWaitEvent(s_enc, c->ev_fork, 0));
     uint64_t absorbed = 0;
-    for (size_t b = 0; b < R; b += lig_trace::CHUNK) {
-        const size_t nb = std::min(lig_trace::CHUNK, R - b);
-        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false));
-        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-        HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
-        lig::launch_sha_update_rows(s2, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
+    for (const auto& ch : chunk_schedule(R, lig_trace::CHUNK, 0, 96)) {
+        const size_t b = ch.first, nb = ch.second - ch.first;
+        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc));
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
+        HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
+        lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
         absorbed += nb;
+    }
+    if (s_enc != s) {                       // the main stream continues after the last encode
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     }
     mark("encode message rows");
     TRY(lig_encode(c, mask));
     TRY(lig_encode_2k(c, mlin));
     TRY(lig_encode_2k(c, mquad));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
-    lig::launch_sha_update_rows(s2, T->sha_state, n, mask, n, 3, absorbed);
+    HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
+    lig::launch_sha_update_rows(s_sha, T->sha_state, n, mask, n, 3, absorbed);
     absorbed += 3;
     c->sha[T->sha_state].second = absorbed;
-    HIP_TRY(c, hipEventRecord(c->ev_join, s2));
+    HIP_TRY(c, hipEventRecord(c->ev_join, s_sha));
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     mark("encode mask rows + column sha tail");
     TRY(lig_sha_final(c, T->sha_state, T->leaves));
@@ -472,15 +493,16 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     fr* rhalf = T->rcw;                                   // chunk x 2k
     // The randomness rows of chunk b+1 (AES sampling: LDS-bound) and their inner products with the witness rows are
     // formed on the side stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
-    const size_t n_chunks = (R + lig_trace::CHUNK - 1) / lig_trace::CHUNK;
+    const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_trace::CHUNK, 96, 0);
+    const size_t n_chunks = sched2.size();
     std::vector<uint64_t> chunk_pos(n_chunks + 1, 0);
     for (size_t ci = 0; ci < n_chunks; ci++) {
         uint64_t cnt = 0;
-        for (size_t r = ci * lig_trace::CHUNK; r < std::min(R, (ci + 1) * lig_trace::CHUNK); r++) cnt += T->rows[r].data;
+        for (size_t r = sched2[ci].first; r < sched2[ci].second; r++) cnt += T->rows[r].data;
         chunk_pos[ci + 1] = chunk_pos[ci] + cnt;
     }
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
-        const size_t b = ci * lig_trace::CHUNK, nb = std::min(lig_trace::CHUNK, R - b);
+        const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
         HIP_TRY(c, hipMemsetAsync(rb, 0, nb * (size_t)k * 32, s2));
@@ -500,7 +522,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
     if (n_chunks) TRY(form_rand_chunk(0));
     for (size_t ci = 0; ci < n_chunks; ci++) {
-        const size_t b = ci * lig_trace::CHUNK, nb = std::min(lig_trace::CHUNK, R - b);
+        const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));

@@ -60,31 +60,40 @@ __global__ void k_sha_init(uint32_t* __restrict__ st, size_t n_inst) {
 // absorb nrows rows (row r at rows + r*row_stride, element j = column j); rows_before = rows absorbed so far
 __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, const fr* __restrict__ rows, size_t row_stride,
                                   size_t nrows, uint64_t rows_before) {
+    // The column chain is sequential in rows: this kernel is latency-bound with only n_inst/64 waves and usually runs
+    // next to an encode kernel on the side stream.  Highest wave priority lets it issue whenever it is ready, so its
+    // critical path stays close to the stand-alone one while the encode waves fill the remaining issue slots.
+    // (s_setprio(3) measured: no gain stand-alone, slower when co-resident with the encode kernels)
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_inst) return;
     uint32_t h[8], w[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] = st[(size_t)i * n_inst + j];
-    size_t r = 0;
-    if (rows_before & 1) {   // complete the pending half block with the first new row
+    // virtual element sequence: the pending half block (if any) followed by the new rows; one compression per pair
+    const size_t pend = (size_t)(rows_before & 1);
+    const size_t total = nrows + pend;
+    for (size_t v = 0; v + 1 < total; v += 2) {
+        if (v == 0 && pend) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = st[(size_t)(8 + i) * n_inst + j];
-        fr e = fr_load(rows + j);
+            for (int i = 0; i < 8; i++) w[i] = st[(size_t)(8 + i) * n_inst + j];
+        } else {
+            const fr e0 = fr_load(rows + (v - pend) * row_stride + j);
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[8 + i] = e.v[i];
+            for (int i = 0; i < 8; i++) w[i] = e0.v[i];
+        }
+        const fr e1 = fr_load(rows + (v + 1 - pend) * row_stride + j);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[8 + i] = e1.v[i];
         sha256_compress(h, w);
-        r = 1;
     }
-    for (; r + 1 < nrows; r += 2) {
-        fr e0 = fr_load(rows + r * row_stride + j), e1 = fr_load(rows + (r + 1) * row_stride + j);
+    if (total & 1) {         // odd tail: keep the element for the next call / final
+        if (total == 1 && pend) {
+            // nothing new absorbed (nrows == 0 is filtered by the launcher); unreachable, kept for clarity
+        } else {
+            const fr e = fr_load(rows + (total - 1 - pend) * row_stride + j);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { w[i] = e0.v[i]; w[8 + i] = e1.v[i]; }
-        sha256_compress(h, w);
-    }
-    if (r < nrows) {         // odd tail: keep the element for the next call / final
-        fr e = fr_load(rows + r * row_stride + j);
-#pragma unroll
-        for (int i = 0; i < 8; i++) st[(size_t)(8 + i) * n_inst + j] = e.v[i];
+            for (int i = 0; i < 8; i++) st[(size_t)(8 + i) * n_inst + j] = e.v[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) st[(size_t)i * n_inst + j] = h[i];
