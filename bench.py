@@ -106,6 +106,40 @@ class FullWorkload:
         self.ctx.trace_destroy(self.trace)
 
 
+class ShardedWorkload:
+    """configs[3]-style: ONE C-constraint trace sharded over all ranks (row blocks per GPU, column-partitioned hash
+    after one all-to-all, all-gathered leaves / partial accumulators / opened columns).  Strong scaling."""
+    name = "sharded"
+
+    def __init__(self, ctx, constraints, group, pkg):
+        self.ctx, self.constraints, self.group = ctx, constraints, group
+        self.job = pkg.Context.make_job(constraints, 0, synth_seed=1, generated_at=0)
+        self.comm = group.make_comm(pkg, ctx)
+        self.shard = ctx.shard_prepare(self.job, group.rank, group.world, self.comm)
+        self.rows = -(-constraints // L_)
+        self.last = None
+        ctx.sync()
+
+    def step(self):
+        (addr, length), info = self.ctx.shard_prove(self.shard, copy=False)
+        if not (info.valid_code and info.valid_linear and info.valid_quad):
+            raise SystemExit("prover self-check failed")
+        self.last = (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3)
+
+    def describe(self):
+        d = {"workload": "configs[3]-style: ONE 2^%d-constraint trace row-sharded over the GPUs, full proof"
+                         % (self.constraints.bit_length() - 1),
+             "rows": self.rows + 3, "l": L_, "k": K_, "n": N_, "sample_size": T_}
+        if self.last:
+            proof = C.string_at(self.last[0], self.last[1])
+            d.update(proof_bytes=len(proof), proof_sha256=hashlib.sha256(proof).hexdigest(),
+                     stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]})
+        return d
+
+    def close(self):
+        self.ctx.shard_destroy(self.shard)
+
+
 def cpu_baseline(workload_name, budget_s=20.0):
     """the oracle (CPU restatement of the reference algorithm: radix-2 stages + bit reversal as in
     src/webgpu/engine.cpp:844-968, every row re-encoded in each of the three stages as in
@@ -153,11 +187,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="full", choices=["full", "encode"])
+    ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded"])
     ap.add_argument("--log2-constraints", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
-    log2c = a.log2_constraints if a.log2_constraints is not None else (24 if a.workload == "full" else 20)
+    log2c = a.log2_constraints if a.log2_constraints is not None else (20 if a.workload == "encode" else 24)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +208,10 @@ def main():
     dist = group.dist
 
     ctx = pkg.Context(L_, K_, N_, device=local_rank)
-    wl = (FullWorkload if a.workload == "full" else EncodeWorkload)(ctx, 1 << log2c)
+    if a.workload == "sharded":
+        wl = ShardedWorkload(ctx, 1 << log2c, group, pkg)
+    else:
+        wl = (FullWorkload if a.workload == "full" else EncodeWorkload)(ctx, 1 << log2c)
 
     def fence():
         group.barrier()
@@ -194,22 +231,36 @@ def main():
     dt = group.max_over_ranks(dt)
 
     if rank == 0:
-        total_constraints = wl.constraints * a.steps * world
+        sharded = a.workload == "sharded"
+        total_constraints = wl.constraints * a.steps * (1 if sharded else world)
         # dominant kernel = k_encode_mid (K2b).  Per encoded row it must read the k coefficients and write the n coset
         # values: (k + n) * 32 B = 1,310,720 B -- the SURVEY.md 8(d) encode figure (read k*32 + write n*32).
         alg_bytes_per_row = (K_ + N_) * 32
         avg_launch_s = (kms / max(launches, 1)) * 1e-3
         rows_per_launch = prows / max(launches, 1)
         achieved = rows_per_launch * alg_bytes_per_row / max(avg_launch_s, 1e-12) / 1e9
+        # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of this same command, FETCH_SIZE doubled per the gfx950 note of the microarch guide), per launch
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)["k_encode_mid<10,4>"]
+            traffic = pmc["hbm_bytes_per_row"] * rows_per_launch
+            traffic_src = "profiles/pmc_traffic.json (%.0f B/row measured on %d-row launches)" % (pmc["hbm_bytes_per_row"], pmc["rows_in_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "prover constraints/sec", "value": total_constraints / dt, "unit": "constraints/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u32 limbs (BN254 Fr: 256-bit modular integers, 9x29-bit limbs in registers; SHA-256 words)",
-            "data": "synthetic", "config": dict(wl.describe(), parallelism="1 trace per GPU (independent traces, no collective)"),
-            "proof_wall_ms": 1e3 * dt / a.steps if a.workload == "full" else None,
+            "data": "synthetic",
+            "config": dict(wl.describe(), parallelism=("1 trace sharded over %d GPUs: all-to-all of codeword column slices + all-gathers" % world)
+                           if sharded else "1 trace per GPU (independent traces, no collective)"),
+            "proof_wall_ms": 1e3 * dt / a.steps if a.workload != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": "k_encode_mid", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": rows_per_launch * alg_bytes_per_row,
                          "avg_launch_ms": 1e3 * avg_launch_s, "rows_per_launch": rows_per_launch, "launches": launches,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
                          "note": "integer-VALU-bound kernel (~193k 256-bit Montgomery products per row in this kernel, "
@@ -217,10 +268,15 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl.name)
-        print(json.dumps(out))
+        result = json.dumps(out)
+    else:
+        result = None
     wl.close()
     ctx.close()
     group.close()
+    if result is not None:          # printed last and flushed: RCCL / the runtime may print their own lines earlier
+        sys.stdout.flush()
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

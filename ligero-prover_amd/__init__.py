@@ -28,7 +28,14 @@ EXPORTS = [
     "lig_sample_gather", "lig_encode_rows", "lig_sha_update_rows", "lig_merkle_nodes", "lig_merkle_build",
     "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
     "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
+    "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy",
 ]
+
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Comm(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN), ("all_gather_host", A2A_FN)]
 
 
 class SynthJob(C.Structure):
@@ -105,6 +112,10 @@ def load_library():
     L.lig_trace_rows.restype = u64
     L.lig_trace_destroy.argtypes = [vp]
     L.lig_trace_destroy.restype = None
+    L.lig_shard_prepare.argtypes = [vp, C.POINTER(SynthJob), u32, u32, C.POINTER(Comm), C.POINTER(vp)]
+    L.lig_shard_prove.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
+    L.lig_shard_destroy.argtypes = [vp]
+    L.lig_shard_destroy.restype = None
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -228,6 +239,36 @@ class Context:
         self.check(self.L.lig_rlc_rows(self.h, U, Rn, rows, _hptr(rcb), code, lin, _hptr(tri), _hptr(rqb), nt, quad))
 
     # ---- batched prover over a synthetic trace
+    @staticmethod
+    def make_job(n_linear, n_quad=0, synth_seed=1, generated_at=0, encoding_seed=None):
+        import hashlib
+        job = SynthJob()
+        job.n_linear, job.n_quad, job.generated_at = n_linear, n_quad, generated_at
+        es = bytes(range(32)) if encoding_seed is None else bytes(encoding_seed)
+        wk = hashlib.sha256(b"lig-synth" + int(synth_seed).to_bytes(8, "little")).digest()
+        for i in range(32):
+            job.encoding_seed[i] = es[i]
+            job.witness_key[i] = wk[i]
+            job.program_hash[i] = 0
+        job.version = b"1.5.0"
+        return job
+
+    # ---- one trace sharded over ranks (comm: a Comm built by dist.Group.make_comm)
+    def shard_prepare(self, job, rank, world, comm):
+        t = C.c_void_p()
+        self.check(self.L.lig_shard_prepare(self.h, C.byref(job), rank, world, C.byref(comm), C.byref(t)))
+        return t
+
+    def shard_prove(self, shard, copy=True):
+        proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
+        self.check(self.L.lig_shard_prove(shard, C.byref(proof), C.byref(ln), C.byref(info)))
+        if not copy:
+            return (C.addressof(proof.contents), ln.value), info
+        return C.string_at(proof, ln.value), info
+
+    def shard_destroy(self, shard):
+        self.L.lig_shard_destroy(shard)
+
     def synth_prepare(self, n_linear, n_quad=0, synth_seed=1, generated_at=0, encoding_seed=None):
         import hashlib
         job = SynthJob()

@@ -288,14 +288,14 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {
             const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->prof_on) {
+            if (c->prof_on && !half) {      // only the full 4-coset launches of the dominant kernel are bracketed
                 if (c->prof_used == c->prof_events.size()) {
                     hipEvent_t a, b;
                     HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
                     c->prof_events.push_back({a, b});
                 }
                 e0 = c->prof_events[c->prof_used].first; e1 = c->prof_events[c->prof_used].second;
-                c->prof_used++; c->prof_rows += half ? (nr + 1) / 2 : nr;     // a half encode is half a row of K2b work
+                c->prof_used++; c->prof_rows += nr;
             }
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
                                   c->scratch_z, nr, e0, e1, half);

@@ -85,6 +85,10 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
     if (rc_dev != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, code, part_code, groups, count);
     if (Rn != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, lin, part_lin, groups, count);
 }
+// acc[j] = (acc[j] + sum_g part[g*count + j]) mod p  (used to add the all-gathered per-GPU partial accumulators)
+void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count) {
+    hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, acc, part, groups, count);
+}
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad) {
     if (!n_triples) return;

@@ -6,13 +6,13 @@ import os
 
 
 class Group:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force_init=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.backend = backend
-        if self.world > 1:
+        if self.world > 1 or force_init:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -61,6 +61,89 @@ class Group:
         out = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(out, mine)
         return [bytes(o.cpu().tolist()) for o in out]
+
+    # ---- collectives for the sharded prover (include/lig_hip.h: lig_comm).  The C side hands over raw pointers after
+    # synchronising its stream; the callbacks return once the received data is in place.
+    def make_comm(self, pkg, ctx):
+        """pkg = the ligero_prover_amd module, ctx = its Context on this rank's GPU.  nccl: the device pointers are
+        wrapped as torch tensors (zero copy) and exchanged over RCCL/xGMI; gloo (tests): staged through host memory."""
+        import ctypes as C
+        import numpy as np
+        import torch
+        g = self
+
+        class _Dev:
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+        def dev_tensor(ptr, nbytes):
+            return torch.as_tensor(_Dev(ptr, nbytes), device="cuda")
+
+        def host_of(ptr, nbytes):        # device -> host numpy copy through the library's own stream
+            return ctx.download(C.c_void_p(ptr), (nbytes,), dtype=np.uint8)
+
+        def all_to_all(user, send, recv, block):
+            try:
+                total = block * g.world
+                if g.dist is None:
+                    ctx.check(ctx.L.lig_copy(ctx.h, C.c_void_p(recv), C.c_void_p(send), total)); ctx.sync()
+                elif g.backend == "nccl":
+                    src, dst = dev_tensor(send, total), dev_tensor(recv, total)
+                    g.dist.all_to_all_single(dst, src)
+                    torch.cuda.synchronize()
+                else:                      # gloo has no all_to_all: gather everything, keep the blocks addressed to me
+                    mine = torch.from_numpy(host_of(send, total))
+                    parts = [torch.empty_like(mine) for _ in range(g.world)]
+                    g.dist.all_gather(parts, mine)
+                    out = torch.cat([p[g.rank * block:(g.rank + 1) * block] for p in parts]).numpy()
+                    ctx.write(C.c_void_p(recv), out)
+                return 0
+            except Exception as e:           # never let an exception cross the C boundary
+                print("lig comm all_to_all failed:", repr(e), flush=True)
+                return 1
+
+        def all_gather(user, send, recv, nbytes):
+            try:
+                if g.dist is None:
+                    ctx.check(ctx.L.lig_copy(ctx.h, C.c_void_p(recv), C.c_void_p(send), nbytes)); ctx.sync()
+                elif g.backend == "nccl":
+                    src, dst = dev_tensor(send, nbytes), dev_tensor(recv, nbytes * g.world)
+                    g.dist.all_gather_into_tensor(dst, src)
+                    torch.cuda.synchronize()
+                else:
+                    mine = torch.from_numpy(host_of(send, nbytes))
+                    parts = [torch.empty_like(mine) for _ in range(g.world)]
+                    g.dist.all_gather(parts, mine)
+                    ctx.write(C.c_void_p(recv), torch.cat(parts).numpy())
+                return 0
+            except Exception as e:
+                print("lig comm all_gather failed:", repr(e), flush=True)
+                return 1
+
+        def all_gather_host(user, send, recv, nbytes):
+            try:
+                mine = torch.from_numpy(np.frombuffer(C.string_at(send, nbytes), dtype=np.uint8).copy())
+                if g.dist is None:
+                    parts = [mine]
+                else:
+                    dev = "cuda" if g.backend == "nccl" else "cpu"
+                    m = mine.to(dev)
+                    parts = [torch.empty_like(m) for _ in range(g.world)]
+                    g.dist.all_gather(parts, m)
+                    parts = [p.cpu() for p in parts]
+                C.memmove(recv, torch.cat(parts).numpy().tobytes(), nbytes * g.world)
+                return 0
+            except Exception as e:
+                print("lig comm all_gather_host failed:", repr(e), flush=True)
+                return 1
+
+        comm = pkg.Comm()
+        comm.user = None
+        comm.all_to_all = pkg.A2A_FN(all_to_all)
+        comm.all_gather = pkg.A2A_FN(all_gather)
+        comm.all_gather_host = pkg.A2A_FN(all_gather_host)
+        self._keepalive = (all_to_all, all_gather, all_gather_host, comm)
+        return comm
 
     def close(self):
         if self.dist is not None:

@@ -1,0 +1,107 @@
+"""Single trace sharded over W ranks (BASELINE.json configs[3]) -- run as W processes that share the one GPU of the
+test box, with gloo carrying the collectives (the same callbacks use RCCL when the backend is nccl).  Every rank's
+envelope must be byte-identical to the unsharded prover's (which the parity tests tie to the oracle)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent('''
+    import hashlib, importlib.util, json, os, sys
+    root, l, k, n, n_lin, n_quad = sys.argv[1], *map(int, sys.argv[2:7])
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
+        m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+    pkg = load("ligero_prover_amd", "__init__.py")
+    dist = load("lig_dist", "dist.py")
+    g = dist.Group("gloo")
+    ctx = pkg.Context(l, k, n, device=0)
+    job = pkg.Context.make_job(n_lin, n_quad, generated_at=77)
+    comm = g.make_comm(pkg, ctx)
+    sh = ctx.shard_prepare(job, g.rank, g.world, comm)
+    proof, info = ctx.shard_prove(sh)
+    proof2, _ = ctx.shard_prove(sh)
+    ctx.shard_destroy(sh)
+    ref = None
+    if g.rank == 0:                      # the unsharded prover on the same job
+        tr = ctx.synth_prepare(n_lin, n_quad, generated_at=77)
+        ref, rinfo = ctx.synth_prove(tr)
+        ctx.trace_destroy(tr)
+    digs = g.gather_digests(hashlib.sha256(proof).digest())
+    print(json.dumps({"rank": g.rank, "len": len(proof), "sha": hashlib.sha256(proof).hexdigest(), "again": proof == proof2,
+                      "valid": [info.valid_code, info.valid_linear, info.valid_quad], "rows": info.rows,
+                      "ref_sha": hashlib.sha256(ref).hexdigest() if ref is not None else None,
+                      "all_equal": len(set(digs)) == 1}))
+    ctx.close()
+    g.close()
+''')
+
+
+def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port):
+    script = tmp_path / "shard_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        o, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+        outs.append(json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1]))
+    return sorted(outs, key=lambda d: d["rank"])
+
+
+@pytest.mark.parametrize("world,l,k,n,n_lin,n_quad", [
+    (2, 320, 512, 2048, 2000, 900),       # 7 + 9 rows: linear block, quadratic triples, partial rows
+    (4, 320, 512, 2048, 700, 0),          # 3 rows on 4 ranks: one rank owns no row
+    (2, 8000, 8192, 32768, 5 * 8000 + 17, 8000),
+])
+def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, n_quad):
+    outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, 29741 + world)
+    assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
+    assert len({o["sha"] for o in outs}) == 1
+    assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
+
+
+NCCL_WORKER = textwrap.dedent('''
+    import hashlib, importlib.util, json, os, sys
+    root = sys.argv[1]
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
+        m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+    import torch
+    torch.cuda.set_device(0)
+    pkg = load("ligero_prover_amd", "__init__.py")
+    dist = load("lig_dist", "dist.py")
+    g = dist.Group("nccl", force_init=True)          # a 1-rank RCCL communicator: exercises the device-pointer tensor path
+    ctx = pkg.Context(320, 512, 2048, device=0)
+    job = pkg.Context.make_job(2000, 900, generated_at=77)
+    sh = ctx.shard_prepare(job, g.rank, g.world, g.make_comm(pkg, ctx))
+    proof, info = ctx.shard_prove(sh)
+    ctx.shard_destroy(sh)
+    tr = ctx.synth_prepare(2000, 900, generated_at=77)
+    ref, _ = ctx.synth_prove(tr)
+    ctx.trace_destroy(tr)
+    print(json.dumps({"equal": proof == ref, "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
+    ctx.close(); g.close()
+''')
+
+
+def test_rccl_device_pointer_collectives_one_rank(tmp_path):
+    """the nccl branch of the callbacks (device pointers wrapped as torch tensors, RCCL all_to_all_single /
+    all_gather_into_tensor) on a 1-rank communicator -- all that a 1-GPU box can exercise of the RCCL path"""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29761", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])     # RCCL prints its own lines
+    assert out == {"equal": True, "valid": [1, 1, 1]}
