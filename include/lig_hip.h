@@ -152,6 +152,17 @@ int  lig_synth_prove(lig_trace *trace, const uint8_t **proof, size_t *proof_len,
 uint64_t lig_trace_rows(const lig_trace *trace);
 void lig_trace_destroy(lig_trace *trace);
 
+/* ==== verifier for the same synthetic stream (src/webgpu_verifier.cpp:263-452, nonbatch_verifier_context): returns
+ * LIG_OK with out->accept = 1 iff the reference's seven predicates hold; a malformed envelope gives accept = 0
+ * (parsed = 0), not an error.  const_sum is the public constant of the linear test (linear_sums upstream). ==== */
+typedef struct {
+    int32_t parsed, indices_match;
+    int32_t valid_merkle, valid_code, valid_linear, valid_quad, code_equal, linear_equal, quad_equal;   /* webgpu_verifier.cpp:412-442 */
+    int32_t accept;
+} lig_verify_info;
+int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t const_sum[32], const uint8_t *proof, size_t proof_len,
+                     lig_verify_info *out);
+
 /* ==== one trace sharded over the GPUs of a node (configs[3]).  Rows are dealt to ranks in contiguous
  * blocks; the column hash is column-partitioned after ONE all-to-all of codeword column slices; leaves, partial
  * stage-2 sums (k + 2k + 2k values per rank, added mod p locally) and opened columns are all-gathered.  The collectives

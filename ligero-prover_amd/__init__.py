@@ -28,8 +28,13 @@ EXPORTS = [
     "lig_sample_gather", "lig_encode_rows", "lig_sha_update_rows", "lig_merkle_nodes", "lig_merkle_build",
     "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
     "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
-    "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy",
+    "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify",
 ]
+
+
+class VerifyInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("parsed", "indices_match", "valid_merkle", "valid_code", "valid_linear", "valid_quad",
+                                          "code_equal", "linear_equal", "quad_equal", "accept")]
 
 A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -112,6 +117,7 @@ def load_library():
     L.lig_trace_rows.restype = u64
     L.lig_trace_destroy.argtypes = [vp]
     L.lig_trace_destroy.restype = None
+    L.lig_synth_verify.argtypes = [vp, C.POINTER(SynthJob), vp, vp, sz, C.POINTER(VerifyInfo)]
     L.lig_shard_prepare.argtypes = [vp, C.POINTER(SynthJob), u32, u32, C.POINTER(Comm), C.POINTER(vp)]
     L.lig_shard_prove.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_shard_destroy.argtypes = [vp]
@@ -291,6 +297,14 @@ class Context:
         if not copy:
             return (C.addressof(proof.contents), ln.value), info
         return C.string_at(proof, ln.value), info
+
+    def synth_verify(self, job, const_sum, proof):
+        """-> VerifyInfo (accept = 1 iff the reference's seven verifier predicates hold)"""
+        info = VerifyInfo()
+        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy()
+        pb = np.frombuffer(bytes(proof), dtype=np.uint8).copy()
+        self.check(self.L.lig_synth_verify(self.h, C.byref(job), _hptr(cs), _hptr(pb), len(pb), C.byref(info)))
+        return info
 
     def trace_destroy(self, trace):
         self.L.lig_trace_destroy(trace)

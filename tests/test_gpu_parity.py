@@ -338,3 +338,65 @@ def test_batched_prover_equals_reference_structured_oracle(amd, l, k, n, n_linea
         assert ol.lib().lo_verify(C.byref(job), cs, buf, len(proof)) == 1
     finally:
         ol.lib().lo_proof_free(C.byref(pr))
+
+
+@pytest.mark.parametrize("l,k,n,n_linear,n_quad", [
+    (320, 512, 2048, 640, 330), (832, 1024, 4096, 2000, 900), (8000, 8192, 32768, 2 * 8000 + 123, 8000 + 5),
+])
+def test_hip_verifier_agrees_with_restated_verifier(amd, l, k, n, n_linear, n_quad):
+    """lig_synth_verify (verifier context on the 192 opened columns, recommit, decode, seven predicates) accepts the
+    prover's envelope and rejects exactly what the oracle's restated verifier rejects: a flipped opened element, a
+    flipped accumulator element, a flipped sibling hash, a wrong public constant, a truncated envelope."""
+    c = amd.Context(l, k, n)
+    job_o = ol.make_job(l, k, n, 192, n_linear, n_quad, generated_at=99, threads=8)
+
+    def oracle_accepts(p, const_sum):
+        cs = (C.c_uint64 * 4).from_buffer_copy(bytes(const_sum))
+        buf = (C.c_uint8 * len(p)).from_buffer_copy(p)
+        return ol.lib().lo_verify(C.byref(job_o), cs, buf, len(p))
+
+    try:
+        job = amd.Context.make_job(n_linear, n_quad, generated_at=99)
+        tr = c.synth_prepare(n_linear, n_quad, generated_at=99)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        cs = bytes(info.const_sum)
+        v = c.synth_verify(job, cs, proof)
+        assert [v.parsed, v.indices_match, v.valid_merkle, v.valid_code, v.valid_linear, v.valid_quad, v.code_equal,
+                v.linear_equal, v.quad_equal, v.accept] == [1] * 10
+        assert oracle_accepts(proof, cs) == 1
+        rows = info.rows
+        smp_off = len(proof) - (rows + 3) * 192 * 32          # the opened columns are the last field of the envelope
+        acc_off = proof.index(bytes(info.root)) + 32
+        cases = {
+            "opened element": (smp_off + 32 * 5 + 1, "valid_merkle"),
+            "opened mask element": (len(proof) - 32 * 100 + 2, "valid_merkle"),
+        }
+        for name, (pos, flag) in cases.items():
+            bad = bytearray(proof)
+            bad[pos] ^= 1
+            vb = c.synth_verify(job, cs, bytes(bad))
+            assert vb.accept == 0 and getattr(vb, flag) == 0, name
+            assert oracle_accepts(bytes(bad), cs) == 0, name
+        # a flipped byte inside the encoded code-test polynomial changes the stage-2 seed -> other columns are sampled
+        bad = bytearray(proof)
+        pos = smp_off - 2 * n * 32 - 1000
+        bad[pos] ^= 1
+        vb = c.synth_verify(job, cs, bytes(bad))
+        assert vb.accept == 0
+        assert oracle_accepts(bytes(bad), cs) == 0
+        # wrong public constant: only the linear predicate fails
+        wrong = (int.from_bytes(cs, "little") + 1) % ol.P
+        vb = c.synth_verify(job, wrong.to_bytes(32, "little"), proof)
+        assert (vb.accept, vb.valid_linear, vb.valid_merkle, vb.valid_code, vb.valid_quad, vb.code_equal, vb.linear_equal,
+                vb.quad_equal) == (0, 0, 1, 1, 1, 1, 1, 1)
+        assert oracle_accepts(proof, wrong.to_bytes(32, "little")) == 0
+        # truncated / empty envelopes are rejected, not errors
+        for cut in (0, 10, len(proof) // 2, len(proof) - 1):
+            vb = c.synth_verify(job, cs, proof[:cut])
+            assert vb.accept == 0
+        # a different statement (one more linear constraint) does not verify
+        job2 = amd.Context.make_job(n_linear + l, n_quad, generated_at=99)
+        assert c.synth_verify(job2, cs, proof).accept == 0
+    finally:
+        c.close()
