@@ -274,10 +274,11 @@ static int ensure_scratch(lig_ctx* c, size_t rows) {
 
 }  // extern "C"
 
-// shared by lig_encode_rows and the batched prover.  half = false: out = rows x n codewords.
-// half = true: out = rows x 2k, out[m] = P(w_n^(2m)) (the evaluations on the order-2k subgroup only).
+// shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
+// codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
+// (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on) {
-    const size_t out_stride = half ? 2 * (size_t)c->k : (size_t)c->n;
+    const size_t out_stride = half ? (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
     if (c->fast) {
         // rows per launch group: the Y/C/Z scratch (1.5 MiB/row) should stay inside the 256 MiB L3 so that K3's
@@ -288,7 +289,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {
             const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->prof_on && !half) {      // only the full 4-coset launches of the dominant kernel are bracketed
+            if (c->prof_on && !half) {      // only the full (3 computed cosets) launches of the dominant kernel are bracketed
                 if (c->prof_used == c->prof_events.size()) {
                     hipEvent_t a, b;
                     HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
@@ -300,13 +301,29 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
                                   c->scratch_z, nr, e0, e1, half);
         }
-    } else {
-        // generic path: copy + zero-pad each row, INTT_k, then NTT_n (or NTT_2k on <w_n^2>) with the radix-2 kernels
+    } else if (!half) {
+        // generic path: copy + zero-pad each row, INTT_k, then NTT_n with the radix-2 kernels
         HIP_TRY(c, hipMemsetAsync(out, 0, rows * out_stride * sizeof(fr), st));
         HIP_TRY(c, hipMemcpy2DAsync(out, out_stride * sizeof(fr), msgs, (size_t)c->k * sizeof(fr), (size_t)c->k * sizeof(fr),
                                     rows, hipMemcpyDeviceToDevice, st));
         lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], (fr*)out, rows, out_stride);
-        lig::ntt_generic_forward(st, half ? c->plan_half : c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
+        lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
+    } else {
+        // generic path, half: NTT_2k on <w_n^2> into the Z scratch (2k per row), then keep the odd points
+        const size_t k2 = 2 * (size_t)c->k, chunk = 64;
+        int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
+        if (rc != LIG_OK) return rc;
+        for (size_t r0 = 0; r0 < rows; r0 += chunk) {
+            const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+            fr* z = c->scratch_z;
+            HIP_TRY(c, hipMemsetAsync(z, 0, nr * k2 * sizeof(fr), st));
+            HIP_TRY(c, hipMemcpy2DAsync(z, k2 * sizeof(fr), (const fr*)msgs + r0 * c->k, (size_t)c->k * sizeof(fr), (size_t)c->k * sizeof(fr),
+                                        nr, hipMemcpyDeviceToDevice, st));
+            lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], z, nr, k2);
+            lig::ntt_generic_forward(st, c->plan_half, z, nr, k2);
+            HIP_TRY(c, hipMemcpy2DAsync((fr*)out + r0 * c->k, sizeof(fr), z + 1, 2 * sizeof(fr), sizeof(fr), nr * (size_t)c->k,
+                                        hipMemcpyDeviceToDevice, st));
+        }
     }
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
@@ -332,10 +349,13 @@ int lig_encode(lig_ctx* c, void* buf) {
     CHECK_CTX(c);
     if (!buf) return LIG_E_ARG;
     if (c->fast) {
-        // in place: the message occupies buf[0..k); K1 reads it completely into Y before K3 writes the codeword
+        // in place: K3 copies coset 0 of the codeword straight from the message row while it overwrites buf, so the
+        // message is first moved to the unused tail of the Z scratch (one row of Z holds 3 cosets, the buffer has room for 4)
         int rc = ensure_scratch(c, 1);
         if (rc != LIG_OK) return rc;
-        lig::encode_rows_fast(c->stream, c->ep, (const fr*)buf, (fr*)buf, c->scratch_y, c->scratch_z, 1, nullptr, nullptr);
+        fr* mcopy = c->scratch_z + 3 * (size_t)c->k;
+        HIP_TRY(c, hipMemcpyAsync(mcopy, buf, (size_t)c->k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream));
+        lig::encode_rows_fast(c->stream, c->ep, mcopy, (fr*)buf, c->scratch_y, c->scratch_z, 1, nullptr, nullptr);
     } else {
         lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
         lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);

@@ -182,29 +182,30 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_coef(const fr* __re
 }
 
 // ---------------------------------------------------------------------------------------------------- K2b
-// NC = number of cosets produced: 4 = the full codeword (r = 0..3); 2 = only r in {0, 2}, i.e. the evaluations on
-// the order-2k subgroup <w_n^2> -- enough for a stage-2 randomness row, whose codeword is only ever multiplied
-// point-wise into a degree-<2k accumulator (prover.hip).
-template <int LOG2B, int NC>
+// Coset 0 of the codeword needs no arithmetic: w_4k comes from root2 = root1^(2^61 - 1) (src/bn254.cpp:36-43), so
+// w_4k^4 = w_k^(2^61 - 1) = w_k^(-1) and codeword[4q] = P(w_k^(-q)) = msg[(k - q) mod k] -- a reversed copy of the message.
+// FULL = true : cosets r = 1, 2, 3 are computed here (3 workgroups per tile), K3 copies coset 0 from the message row.
+// FULL = false: only coset r = 2 (the odd points of the order-2k subgroup <w_n^2>) -- all a stage-2 randomness row
+//               needs: its values on the even points are the row itself (prover.hip).
+template <int LOG2B, bool FULL>
 __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __restrict__ Cc, fr* __restrict__ Z,
                                                                  const f29s* __restrict__ tw_fwd, const f29s* __restrict__ twist,
                                                                  const f29s* __restrict__ seam_fwd) {
-    constexpr uint32_t B = 1u << LOG2B, T = B / 4;
+    constexpr uint32_t B = 1u << LOG2B, T = B / 4, NC = FULL ? 3 : 1;
     __shared__ TileLds<LOG2B> L;
     const uint32_t t = threadIdx.x;
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with a private L2.  The NC
     // coset workgroups of one tile read the same 32 KiB of coefficients, so they get block ids 8 apart (same XCD)
     // and the tile index is the fastest-varying part: per group of 8*NC blocks, b = j1 + 8*ci.
     const uint32_t j1 = blockIdx.x & 7u, ci = (blockIdx.x >> 3) % NC;      // tile, coset slot
-    const uint32_t r = NC == 4 ? ci : 2 * ci;                              // coset number
+    const uint32_t r = FULL ? ci + 1 : 2;                                  // coset number
     const size_t row = blockIdx.x / (8 * NC);
     const fr* c = Cc + (row * 8 + j1) * (size_t)B;
     f29 x[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t pos = __brev(4 * t + q) >> (32 - LOG2B);
-        x[q] = unpack29(fr_load(c + pos));
-        if (r != 0) x[q] = f29_montmul(x[q], f29_load_tab(twist + ((size_t)(r - 1) * 8 + j1) * B + pos));   // w_n^(r*(j1 + 8*pos))
+        x[q] = f29_montmul(unpack29(fr_load(c + pos)), f29_load_tab(twist + ((size_t)(r - 1) * 8 + j1) * B + pos));   // w_n^(r*(j1 + 8*pos))
     }
     tile_dft<LOG2B>(x, tw_fwd, L, t);
     fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
@@ -219,29 +220,43 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __res
 }
 
 // ---------------------------------------------------------------------------------------------------- K3
-// out row = NC*k elements: element NC*(q2 + B*q1) + ci  (NC = 4: the codeword; NC = 2: index m of w_n^(2m))
-template <int LOG2B, int NC>
-__global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8, size_t rows) {
+// FULL : out row = the codeword, element 4*(q2 + B*q1) + r; the lanes with r = 0 copy the reversed message instead of
+//        running the radix-8 step, so every 128-byte line of the codeword is still written by four adjacent lanes.
+// !FULL: out row = k elements, element q = q2 + B*q1 is P(w_n^(4q + 2)).
+template <int LOG2B, bool FULL>
+__global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8,
+                                                    const fr* __restrict__ msgs, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
-    constexpr int LOGNC = NC == 4 ? 2 : 1;
+    constexpr int LOGNC = FULL ? 2 : 0;
+    constexpr uint32_t NC = FULL ? 3 : 1, OS = FULL ? 4 : 1;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = gid >> (LOG2B + LOGNC);
     if (row >= rows) return;
-    const uint32_t ci = (uint32_t)gid & (NC - 1);
+    const uint32_t r = FULL ? (uint32_t)gid & 3u : 0u;
     const uint32_t q2 = ((uint32_t)gid >> LOGNC) & (B - 1);
+    fr* out = cw + row * (OS * (size_t)K);
+    if (FULL && r == 0) {
+        const fr* m = msgs + row * (size_t)K;
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) {
+            const uint32_t q = q2 + B * q1;
+            fr_store(out + 4 * (size_t)q, fr_load(m + ((K - q) & (K - 1))));
+        }
+        return;
+    }
+    const uint32_t ci = FULL ? r - 1 : 0;
     const fr* z = Z + ((row * NC + ci) * 8) * (size_t)B + q2;
     f29 a[8];
 #pragma unroll
     for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
     radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
-    fr* out = cw + row * (NC * (size_t)K);
 #pragma unroll
-    for (int q1 = 0; q1 < 8; q1++) fr_store(out + NC * ((size_t)q2 + (size_t)B * q1) + ci, pack29(f29_canon(a[q1])));
+    for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, pack29(f29_canon(a[q1])));
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 2048 || k == 8192; }
 
-template <int LOG2B, int NC>
+template <int LOG2B, bool FULL>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
                           hipEvent_t ev0, hipEvent_t ev1) {
     constexpr uint32_t B = 1u << LOG2B;
@@ -250,22 +265,22 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((k_encode_mid<LOG2B, NC>), dim3((uint32_t)(rows * 8 * NC)), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
+    hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
     if (ev1) (void)hipEventRecord(ev1, s);
-    const size_t th3 = rows * B * NC;
-    hipLaunchKernelGGL((k_encode_out<LOG2B, NC>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, rows);
+    const size_t th3 = rows * B * (FULL ? 4 : 1);
+    hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
 }
 
-// half = false: codewords (rows x n).  half = true: rows x 2k values on the order-2k subgroup, out[m] = P(w_n^(2m)).
+// half = false: codewords (rows x n).  half = true: rows x k values on the coset w_n^2 <w_n^4>, out[q] = P(w_n^(4q + 2)).
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
                       hipEvent_t ev0, hipEvent_t ev1, bool half) {
     switch (ep.log2B * 2 + (half ? 1 : 0)) {
-        case 12: encode_rows_t<6, 4>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 13: encode_rows_t<6, 2>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 16: encode_rows_t<8, 4>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 17: encode_rows_t<8, 2>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 20: encode_rows_t<10, 4>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 21: encode_rows_t<10, 2>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 12: encode_rows_t<6, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 13: encode_rows_t<6, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 16: encode_rows_t<8, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 17: encode_rows_t<8, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 20: encode_rows_t<10, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 21: encode_rows_t<10, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
         default: break;
     }
 }

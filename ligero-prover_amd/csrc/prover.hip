@@ -37,6 +37,7 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
 void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* data_dev, uint32_t k, size_t rows, fr* out);
+void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
 }  // namespace lig
 
@@ -486,9 +487,13 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     // reference's per-row n-point updates, nonbatch_context.hpp:756-780):
     //   code  = sum_r rc_r * U_r          degree < k : combine the MESSAGE rows (k values per row), encode once;
     //   lin   = sum_r U_r o R_r           degree < 2k: accumulate on the order-2k subgroup <w_n^2> (the even codeword
-    //   quad  = sum_t rq_t (X o Y - Z)                 positions), then INTT_2k + NTT_n once.  The randomness rows are
-    //                                                  therefore evaluated on <w_n^2> only (2 of the 4 cosets).
+    //   quad  = sum_t rq_t (X o Y - Z)                 positions), then INTT_2k + NTT_n once.
+    // Half of <w_n^2> is the message domain itself (w_n^4 = w_k^-1), where U_r and R_r are the message and randomness rows
+    // as given; so a randomness row is only ever evaluated on ONE extra coset (w_n^2 <w_n^4>, k points): linH accumulates
+    // msg_r o rand_r in message order (fused with the code test, same pass over the message rows), linC accumulates
+    // codeword coset 2 against the coset-2 values of the randomness rows, and the two are interleaved once per proof.
     fr* code = T->acc; fr* lin = T->acc + n; fr* quad = T->acc + 2 * (size_t)n; fr* tmp = T->acc + 3 * (size_t)n;
+    fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
     HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
     const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
     fr* rhalf = T->rcw;                                   // chunk x 2k
@@ -528,13 +533,15 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
+        lig::launch_rlc_rows29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, linC, T->parts,
+                               T->parts + groups * (size_t)n, lig_trace::GROUP);
+        lig::launch_rlc_rows29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, code, linH, T->parts,
+                               T->parts + groups * (size_t)n, lig_trace::GROUP);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
-        lig::launch_rlc_rows29(s, T->cw + b * n, n, 2, rhalf, 2 * (size_t)k, nb, 2 * k, nullptr, nullptr, lin, T->parts,
-                               T->parts + groups * (size_t)n, lig_trace::GROUP);
-        lig::launch_rlc_rows29(s, T->msgs + b * k, k, 1, nullptr, 0, nb, k, T->coef_dev + b, code, nullptr, T->parts,
-                               T->parts + groups * (size_t)n, lig_trace::GROUP);
     }
     mark("stage2 rows (rng+dot+encode+rlc)");
+    lig::launch_lin_interleave(s, lin, linH, linC, k);
+    HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));
     lig::launch_quad_rows29(s, T->cw, n, 2, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
     TRY(lig_encode(c, code));
     TRY(lig_internal_extend_2k(c, lin));
@@ -831,6 +838,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     fr* code = S->acc; fr* lin = S->acc + n; fr* quad = S->acc + 2 * (size_t)n; fr* tmp = S->acc + 3 * (size_t)n;
+    fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
     HIP_TRY(c, hipMemsetAsync(S->acc, 0, 3 * (size_t)n * 32, s));
     const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
     for (size_t b = 0; b < Rl; b += lig_trace::CHUNK) {
@@ -845,11 +853,12 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         }
         lig::launch_dot_rows(s, S->msgs + b * k, S->randb, S->data_dev + b, k, nb, S->dots + b);
         TRY(lig_internal_encode_rows(c, S->randb, S->rhalf, nb, true));
-        lig::launch_rlc_rows29(s, S->cw + b * n, n, 2, S->rhalf, 2 * (size_t)k, nb, 2 * k, nullptr, nullptr, lin, S->parts,
+        lig::launch_rlc_rows29(s, S->cw + b * n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, linC, S->parts,
                                S->parts + groups * (size_t)n, lig_trace::GROUP);
-        lig::launch_rlc_rows29(s, S->msgs + b * k, k, 1, nullptr, 0, nb, k, S->coef_dev + b, code, nullptr, S->parts,
+        lig::launch_rlc_rows29(s, S->msgs + b * k, k, 1, S->randb, k, nb, k, S->coef_dev + b, code, linH, S->parts,
                                S->parts + groups * (size_t)n, lig_trace::GROUP);
     }
+    lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
     // partial sums [code (k) | lin (2k) | quad (2k)] -> every rank -> added mod p
     HIP_TRY(c, hipMemcpyAsync(S->accp, code, (size_t)k * 32, hipMemcpyDeviceToDevice, s));

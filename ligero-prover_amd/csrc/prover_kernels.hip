@@ -136,4 +136,18 @@ void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* d
     if (rows) hipLaunchKernelGGL(k_dot_rows, dim3((uint32_t)rows), dim3(256), 0, s, W, Rr, data_dev, k, out);
 }
 
+// The linear-test accumulator lives on the order-2k subgroup <w_n^2> (index m <-> w_n^(2m)).  Its even points w_n^(4q) =
+// w_k^(-q) are message positions, where it is accumulated in message order (accH, straight from the message and
+// randomness rows, no transform); its odd points are accumulated from codeword coset 2 (accC).  out[2q] = accH[(k - q) % k],
+// out[2q + 1] = accC[q].
+__global__ void k_lin_interleave(fr* __restrict__ out, const fr* __restrict__ accH, const fr* __restrict__ accC, uint32_t k) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= 2 * k) return;
+    const uint32_t q = m >> 1;
+    fr_store(out + m, (m & 1) ? fr_load(accC + q) : fr_load(accH + ((k - q) & (k - 1))));
+}
+void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k) {
+    hipLaunchKernelGGL(k_lin_interleave, dim3((2 * k + 255) / 256), dim3(256), 0, s, out, accH, accC, k);
+}
+
 }  // namespace lig

@@ -175,6 +175,9 @@ def test_encode_by_definition_fresh_random():
     for which, size in ((0, k), (1, 2 * k), (2, n)):
         x = ol.rand_field(rng, size)
         assert np.array_equal(ctx.ntt(which, True, ctx.ntt(which, False, x)), x)
+    # w_4k is derived from root2 = root1^(2^61 - 1), so w_4k^4 = w_k^-1: coset 0 of the codeword is the message reversed
+    # (the HIP encoder copies it instead of computing it)
+    assert np.array_equal(cw[0::4], msg[(k - np.arange(k)) % k])
     # linearity of the code
     m2 = ol.rand_field(rng, k)
     s = ol.to_limbs([(a + b) % P for a, b in zip(ol.from_limbs(msg), ol.from_limbs(m2))])
