@@ -165,7 +165,13 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     if ((rc = make_plan(c, c->plan[LIG_SIZE_2K], 2 * k, w2k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan_half, 2 * k, H::mul(w4k, w4k))) != LIG_OK) return rc;     // the subgroup <w_n^2>, order 2k
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+        const char* e = std::getenv("LIG_SIDE_PRIO");
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e && std::atoi(e)) HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+        else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    }
     {   // Optional CU partition for stage 1 (LIG_SHA_CUS_EVERY=e: every e-th CU runs the column hash, the rest the encodes).
         // OFF by default: measured on MI355X (profiles/r01_overlap_experiments.md) the proof time is the same with the hash
         // on 32/64 dedicated CUs, co-resident, or merely stream-overlapped -- the chip is at its power/VALU-issue limit, so

@@ -31,6 +31,7 @@
 //   whose limbs dominate the subtrahend's limbs and whose value dominates its value.
 #include "fr29.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace lig {
 
@@ -235,23 +236,24 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
     const uint32_t r = FULL ? (uint32_t)gid & 3u : 0u;
     const uint32_t q2 = ((uint32_t)gid >> LOGNC) & (B - 1);
     fr* out = cw + row * (OS * (size_t)K);
+    fr v[8];
     if (FULL && r == 0) {
+        // loads only: the stores below are shared with the other three lanes of the 128-byte line (one full-line write)
         const fr* m = msgs + row * (size_t)K;
 #pragma unroll
-        for (int q1 = 0; q1 < 8; q1++) {
-            const uint32_t q = q2 + B * q1;
-            fr_store(out + 4 * (size_t)q, fr_load(m + ((K - q) & (K - 1))));
-        }
-        return;
+        for (int q1 = 0; q1 < 8; q1++) v[q1] = fr_load(m + ((K - (q2 + B * q1)) & (K - 1)));
+    } else {
+        const uint32_t ci = FULL ? r - 1 : 0;
+        const fr* z = Z + ((row * NC + ci) * 8) * (size_t)B + q2;
+        f29 a[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
+        radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) v[q1] = pack29(f29_canon(a[q1]));
     }
-    const uint32_t ci = FULL ? r - 1 : 0;
-    const fr* z = Z + ((row * NC + ci) * 8) * (size_t)B + q2;
-    f29 a[8];
 #pragma unroll
-    for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
-    radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
-#pragma unroll
-    for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, pack29(f29_canon(a[q1])));
+    for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, v[q1]);
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 2048 || k == 8192; }
@@ -262,13 +264,14 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     constexpr uint32_t B = 1u << LOG2B;
     fr* Cc = Y + rows * (size_t)(8 * B);      // second half of the Y scratch (2 * rows * k elements)
     const size_t th1 = rows * B;
-    hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
-    hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
+    static const int kmask = [] { const char* e = std::getenv("LIG_ENCODE_KMASK"); return e ? std::atoi(e) : 15; }();   // experiments only
+    if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
+    if (kmask & 2) hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
+    if (kmask & 4) hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
     if (ev1) (void)hipEventRecord(ev1, s);
     const size_t th3 = rows * B * (FULL ? 4 : 1);
-    hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    if (kmask & 8) hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
 }
 
 // half = false: codewords (rows x n).  half = true: rows x k values on the coset w_n^2 <w_n^4>, out[q] = P(w_n^(4q + 2)).

@@ -266,6 +266,7 @@ struct lig_trace {
     uint8_t* h_enc = nullptr;                              // pinned: 3 x n accumulators
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
+    hipEvent_t ev_gate = nullptr;
     uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
     static constexpr size_t CHUNK = 512;
     static constexpr uint32_t GROUP = 64;
@@ -317,6 +318,7 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     for (int i = 0; i < 2; i++) {
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_ready[i], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_used[i], hipEventDisableTiming));
+        if (!T->ev_gate) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
     }
     {
         std::vector<uint32_t> d(R);
@@ -360,6 +362,7 @@ void lig_trace_destroy(lig_trace* T) {
                     (void*)T->coef_dev})
         (void)hipFree(p);
     for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
+    if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
     (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
     delete T;
 }
@@ -433,7 +436,17 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
-        lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
+        static const int gate = [] { const char* e = std::getenv("LIG_SHA_GATE"); return e ? std::atoi(e) : 1; }();
+        if (gate && nb > 4) {
+            // the hash waves must be placed while the chip is idle (one per SIMD, evenly): hash the first two rows, let the
+            // encode stream wait for that, and queue the rest of the chunk right behind it on the hash stream
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, 2, absorbed);
+            HIP_TRY(c, hipEventRecord(T->ev_gate, s_sha));
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + (b + 2) * n, n, nb - 2, absorbed + 2);
+            HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_gate, 0));
+        } else {
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
+        }
         absorbed += nb;
     }
     if (s_enc != s) {                       // the main stream continues after the last encode

@@ -13,6 +13,7 @@
 // least-significant first, so the 16 message words of a block are exactly the 8 limbs of row 2q followed by
 // the 8 limbs of row 2q+1.  The leaf is the 8 state words stored as native u32 (:226-228).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace lig {
 
@@ -27,6 +28,12 @@ __device__ __constant__ static const uint32_t SHA_K[64] = {
     0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
 __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+// gfx950 v_bitop3_b32: any 3-input boolean function in one instruction (truth table over a = 0xF0, b = 0xCC, c = 0xAA).
+// The compiler does not form it for x ^ y ^ z by itself; a lone hash wave is issue-latency bound (~5 cycles per
+// instruction whatever its rate, tools/ubench_halfwave.hip), so instruction count is what the column chain pays for.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 
 // one compression; w[16] is consumed (rolling schedule in registers)
 __device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
@@ -37,13 +44,13 @@ __device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
         if (i < 16) wi = w[i];
         else {
             const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-            const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
-            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+            const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+            wi = (w[i & 15] + s0 + w[(i - 7) & 15]) + s1;
             w[i & 15] = wi;
         }
-        const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + wi;
-        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        const uint32_t t1 = (hh + xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25)) + ch(e, f, g)) + (SHA_K[i] + wi);
+        const uint32_t t2 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22)) + maj(a, b, c);
         hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
@@ -130,7 +137,12 @@ void launch_sha_init(hipStream_t s, uint32_t* state, size_t n_inst) {
 void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const fr* rows, size_t row_stride, size_t nrows,
                             uint64_t rows_before) {
     if (!nrows) return;
-    hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + 63) / 64)), dim3(64), 0, s, state, n_inst, rows, row_stride,
+    // 256-thread workgroups = one hash wave on each of the 4 SIMDs of a CU: a hash wave keeps ~65% of its SIMD's VALU busy,
+    // and the encode workgroups that share the chip finish with their slowest wave, so the hash load has to be the same
+    // on all SIMDs of a CU (measured: encode kernels 2-3x slower next to 64-thread hash workgroups, 1.1-1.8x next to
+    // 256-thread ones; tools/corun_bench.py).  LIG_SHA_BLOCK overrides for experiments.
+    static const uint32_t bs = [] { const char* e = std::getenv("LIG_SHA_BLOCK"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t)v : 256u; }();
+    hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + bs - 1) / bs)), dim3(bs), 0, s, state, n_inst, rows, row_stride,
                        nrows, rows_before);
 }
 void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests) {
