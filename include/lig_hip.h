@@ -166,7 +166,7 @@ int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t const
 /* ==== one trace sharded over the GPUs of a node (configs[3]).  Rows are dealt to ranks in contiguous
  * blocks; the column hash is column-partitioned after ONE all-to-all of codeword column slices; leaves, partial
  * stage-2 sums (k + 2k + 2k values per rank, added mod p locally) and opened columns are all-gathered.  The collectives
- * are callbacks on device / host pointers supplied by the caller (torch.distributed over RCCL in
+ * are callbacks on device pointers supplied by the caller (torch.distributed over RCCL in
  * ligero-prover_amd/dist.py); they must return 0 once the data is in place.  Every rank obtains the same envelope,
  * byte-identical to lig_synth_prove of the same job. ==== */
 typedef struct lig_shard lig_shard;
@@ -176,7 +176,6 @@ typedef struct {
     int (*all_to_all)(void *user, const void *send_dev, void *recv_dev, size_t block_bytes);
     /* `recv` = world blocks of `bytes` in rank order */
     int (*all_gather)(void *user, const void *send_dev, void *recv_dev, size_t bytes);
-    int (*all_gather_host)(void *user, const void *send_host, void *recv_host, size_t bytes);
 } lig_comm;
 int  lig_shard_prepare(lig_ctx *ctx, const lig_synth_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
 int  lig_shard_prove(lig_shard *shard, const uint8_t **proof, size_t *proof_len, lig_proof_info *info);

@@ -40,7 +40,7 @@ A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class Comm(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN), ("all_gather_host", A2A_FN)]
+    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN)]
 
 
 class SynthJob(C.Structure):

@@ -36,7 +36,7 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
                        const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
-void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* data_dev, uint32_t k, size_t rows, fr* out);
+void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out);
 void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
 }  // namespace lig
@@ -533,7 +533,6 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
             lig::launch_rng_fill_rows(s2, c->rk_dev, lpos, rb + r * k, run, d, k, 0, 1, d);
             lpos += (uint64_t)run * d; r += run;
         }
-        lig::launch_dot_rows(s2, T->msgs + b * k, rb, T->data_dev + b, k, nb, T->dots + b);
         HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2));
         return LIG_OK;
     };
@@ -546,13 +545,15 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
+        // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
         lig::launch_rlc_rows29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, linC, T->parts,
-                               T->parts + groups * (size_t)n, lig_trace::GROUP);
+                               T->parts + groups * (size_t)n, lig_trace::GROUP / 4);
         lig::launch_rlc_rows29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, code, linH, T->parts,
-                               T->parts + groups * (size_t)n, lig_trace::GROUP);
+                               T->parts + groups * (size_t)n, lig_trace::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
     mark("stage2 rows (rng+dot+encode+rlc)");
+    lig::launch_sum_elems(s, linH, k, 1, T->dots);       // the linear-test constant is minus this sum (prover_kernels.hip)
     lig::launch_lin_interleave(s, lin, linH, linC, k);
     HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));
     lig::launch_quad_rows29(s, T->cw, n, 2, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
@@ -566,7 +567,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     const size_t enc_bytes = 3 * (size_t)n * 32;
     HIP_TRY(c, hipMemcpyAsync(enc, T->acc, enc_bytes, hipMemcpyDeviceToHost, s));
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
-    if (R) HIP_TRY(c, hipMemcpyAsync(T->h_small, T->dots, R * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(T->h_small, T->dots, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(c->ev_join, s));
     // prover self-check (src/webgpu_prover.cpp:355-386,465-469): the three decodes and the Merkle-node download are
     // queued now and run on the GPU while the host hashes the 3 MiB of accumulators for the stage-2 seed
@@ -581,9 +582,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventSynchronize(c->ev_join));          // accumulators + inner products are on the host
     {
-        H::Fr sum = H::from_u64(0);
-        for (size_t r = 0; r < R; r++) sum = H::add(sum, dots[r]);
-        sum = H::neg(sum);
+        const H::Fr sum = H::neg(dots[0]);
         std::memcpy(info->const_sum, sum.v, 32);
     }
     Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
@@ -864,12 +863,11 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
             lig::launch_rng_fill_rows(s, c->rk_dev, S->lin_pos[r0 + b + r], S->randb + r * k, run, d, k, 0, 1, d);
             r += run;
         }
-        lig::launch_dot_rows(s, S->msgs + b * k, S->randb, S->data_dev + b, k, nb, S->dots + b);
         TRY(lig_internal_encode_rows(c, S->randb, S->rhalf, nb, true));
         lig::launch_rlc_rows29(s, S->cw + b * n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, linC, S->parts,
-                               S->parts + groups * (size_t)n, lig_trace::GROUP);
+                               S->parts + groups * (size_t)n, lig_trace::GROUP / 4);
         lig::launch_rlc_rows29(s, S->msgs + b * k, k, 1, S->randb, k, nb, k, S->coef_dev + b, code, linH, S->parts,
-                               S->parts + groups * (size_t)n, lig_trace::GROUP);
+                               S->parts + groups * (size_t)n, lig_trace::GROUP / 4);
     }
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
@@ -878,7 +876,6 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(S->accp + k, lin, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->accp + 3 * (size_t)k, quad, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     H::Fr* dots = reinterpret_cast<H::Fr*>(S->h_small);
-    if (Rl) HIP_TRY(c, hipMemcpyAsync(dots, S->dots, Rl * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (int rc = S->comm.all_gather(S->comm.user, S->accp, S->accg, 5 * (size_t)k * 32)) return comm_fail(rc, "all_gather(partial accumulators)");
     HIP_TRY(c, hipMemsetAsync(S->accp, 0, 5 * (size_t)k * 32, s));
@@ -887,16 +884,11 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(code, S->accp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(lin, S->accp + k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(quad, S->accp + 3 * (size_t)k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    {
-        H::Fr part = H::from_u64(0);
-        for (size_t r = 0; r < Rl; r++) part = H::add(part, dots[r]);
-        H::Fr* mine = reinterpret_cast<H::Fr*>(S->h_small + ((Rl ? Rl : 1) + 2 * (size_t)l + 3 * (size_t)n) * 32);
-        H::Fr* all = mine + 1;
-        *mine = part;
-        if (int rc = S->comm.all_gather_host(S->comm.user, mine, all, 32)) return comm_fail(rc, "all_gather_host(inner products)");
-        H::Fr sum = H::from_u64(0);
-        for (uint32_t g = 0; g < W; g++) sum = H::add(sum, all[g]);
-        sum = H::neg(sum);
+    {   // linear-test constant = -(sum of the message-domain half of the combined accumulator: its even points)
+        lig::launch_sum_elems(s, lin, k, 2, S->dots);
+        HIP_TRY(c, hipMemcpyAsync(dots, S->dots, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const H::Fr sum = H::neg(dots[0]);
         std::memcpy(info->const_sum, sum.v, 32);
     }
     TRY(lig_encode(c, code));

@@ -95,22 +95,21 @@ void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, ui
     hipLaunchKernelGGL(k_quad_rows, dim3((count + 255) / 256), dim3(256), 0, s, U, urs, ues, count, triples_dev, rq2, rq1, n_triples, quad);
 }
 
-// ---------------------------------------------------------------------------------------------- inner products
-// out[r] = sum_{i < data[r]} W[r][i] * Rr[r][i]  (canonical), one workgroup per row.  Used for the linear-test
-// constant of the synthetic constraint stream (the reference accumulates it on the host while generating
-// constraints: linear_sums(), src/webgpu_prover.cpp:307).
-__global__ void __launch_bounds__(256) k_dot_rows(const fr* __restrict__ W, const fr* __restrict__ Rr, const uint32_t* __restrict__ data,
-                                                  uint32_t k, fr* __restrict__ out) {
+// ---------------------------------------------------------------------------------------------- linear-test constant
+// out[0] = sum_{i < count} in[i * stride]  (canonical), one workgroup.  The constant of the linear test of the synthetic
+// constraint stream is minus the sum of all inner products <witness row, randomness row> (the reference accumulates
+// it on the host while generating constraints: linear_sums(), src/webgpu_prover.cpp:307).  Randomness rows are zero
+// outside their data slots, so that double sum is just the sum of the message-domain accumulator sum_r msg_r o rand_r
+// over its k positions -- no per-row inner products are needed.
+__global__ void __launch_bounds__(256) k_sum_elems(const fr* __restrict__ in, uint32_t count, uint32_t stride, fr* __restrict__ out) {
     __shared__ uint32_t sh[256 * 9];
-    const size_t row = blockIdx.x;
-    const uint32_t cnt = data[row];
     f29 a = f29_zero();
     int since = 0;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        a = f29_add(a, f29_montmul(unpack29(fr_load(W + row * k + i)), unpack29(fr_load(Rr + row * k + i))));
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+        a = f29_add(a, unpack29(fr_load(in + (size_t)i * stride)));
         if (++since == 6) { a = f29_qnorm(a); since = 0; }
     }
-    a = f29_reduce_2p(a);
+    a = f29_reduce_2p(f29_qnorm(a));
 #pragma unroll
     for (int i = 0; i < 9; i++) sh[i * 256 + threadIdx.x] = a.v[i];
     __syncthreads();
@@ -129,11 +128,11 @@ __global__ void __launch_bounds__(256) k_dot_rows(const fr* __restrict__ W, cons
         f29 x;
 #pragma unroll
         for (int i = 0; i < 9; i++) x.v[i] = sh[i * 256];
-        fr_store(out + row, pack29(f29_canon(f29_montmul(x, f29_const_r2()))));
+        fr_store(out, pack29(f29_canon(x)));
     }
 }
-void launch_dot_rows(hipStream_t s, const fr* W, const fr* Rr, const uint32_t* data_dev, uint32_t k, size_t rows, fr* out) {
-    if (rows) hipLaunchKernelGGL(k_dot_rows, dim3((uint32_t)rows), dim3(256), 0, s, W, Rr, data_dev, k, out);
+void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out) {
+    hipLaunchKernelGGL(k_sum_elems, dim3(1), dim3(256), 0, s, in, count, stride, out);
 }
 
 // The linear-test accumulator lives on the order-2k subgroup <w_n^2> (index m <-> w_n^(2m)).  Its even points w_n^(4q) =

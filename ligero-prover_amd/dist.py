@@ -120,29 +120,11 @@ class Group:
                 print("lig comm all_gather failed:", repr(e), flush=True)
                 return 1
 
-        def all_gather_host(user, send, recv, nbytes):
-            try:
-                mine = torch.from_numpy(np.frombuffer(C.string_at(send, nbytes), dtype=np.uint8).copy())
-                if g.dist is None:
-                    parts = [mine]
-                else:
-                    dev = "cuda" if g.backend == "nccl" else "cpu"
-                    m = mine.to(dev)
-                    parts = [torch.empty_like(m) for _ in range(g.world)]
-                    g.dist.all_gather(parts, m)
-                    parts = [p.cpu() for p in parts]
-                C.memmove(recv, torch.cat(parts).numpy().tobytes(), nbytes * g.world)
-                return 0
-            except Exception as e:
-                print("lig comm all_gather_host failed:", repr(e), flush=True)
-                return 1
-
         comm = pkg.Comm()
         comm.user = None
         comm.all_to_all = pkg.A2A_FN(all_to_all)
         comm.all_gather = pkg.A2A_FN(all_gather)
-        comm.all_gather_host = pkg.A2A_FN(all_gather_host)
-        self._keepalive = (all_to_all, all_gather, all_gather_host, comm)
+        self._keepalive = (all_to_all, all_gather, comm)
         return comm
 
     def close(self):
