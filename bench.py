@@ -72,38 +72,77 @@ class EncodeWorkload:
 
 
 class FullWorkload:
-    """configs[2]: full proof of a C-constraint trace (linear constraints, dense stage-2 randomness)"""
+    """configs[2]: full proof of a C-constraint trace (linear constraints, dense stage-2 randomness).
+    inflight = M > 1: a step proves M such traces concurrently (one context = one set of HIP streams per trace, one
+    host thread each), so that one proof's host-only phases (the sequential 3 MiB stage-2 seed hash, decommitment,
+    envelope) are covered by the other proof's GPU work.  Default 1: a step is one proof, start to finish."""
     name = "full"
 
-    def __init__(self, ctx, constraints):
+    def __init__(self, ctx, constraints, pkg=None, inflight=1, device=0):
         self.ctx = ctx
-        self.constraints = constraints
-        self.trace = ctx.synth_prepare(constraints, 0, synth_seed=1, generated_at=0)
+        self.constraints_per_trace = constraints
+        self.inflight = inflight
+        self.constraints = constraints * inflight
+        self.ctxs = [ctx] + [pkg.Context(L_, K_, N_, device=device) for _ in range(inflight - 1)]
+        self.traces = [c.synth_prepare(constraints, 0, synth_seed=1, generated_at=0) for c in self.ctxs]
         self.rows = -(-constraints // L_)
         self.last = None
-        ctx.sync()
+        self.pool = None
+        if inflight > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=inflight)
+        for c in self.ctxs:
+            c.sync()
 
-    def step(self):
-        (addr, length), info = self.ctx.synth_prove(self.trace, copy=False)     # proof bytes stay in the pinned buffer
+    def _one(self, i):
+        (addr, length), info = self.ctxs[i].synth_prove(self.traces[i], copy=False)     # proof bytes stay in the pinned buffer
         if not (info.valid_code and info.valid_linear and info.valid_quad):
             raise SystemExit("prover self-check failed")
-        self.last = (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3)
+        return (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3, info.ms_total)
+
+    def step(self):
+        self.run(1)
+
+    def run(self, steps):
+        """`steps` steps = steps x inflight proofs; with several proofs in flight every host thread proves `steps` traces
+        back to back, so the proofs drift out of phase as they would in a proving service"""
+        if self.pool is None:
+            for _ in range(steps):
+                self.last = self._one(0)
+        else:                                   # ctypes releases the GIL for the duration of each call
+            self.last = list(self.pool.map(lambda i: [self._one(i) for _ in range(steps)][-1], range(self.inflight)))[0]
+
+    def single_proof_ms(self, reps=3):
+        """wall time of one proof with nothing else in flight (latency figure next to the throughput figure)"""
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            self._one(0)
+            dt = 1e3 * (time.perf_counter() - t0)
+            best = dt if best is None or dt < best else best
+        return best
 
     def encodes_per_step(self):
-        return 2 * self.rows + 1        # message rows + randomness rows (+ code mask on the fast path)
+        return (2 * self.rows + 1) * self.inflight        # message rows + randomness rows (+ code mask on the fast path)
 
     def describe(self):
         d = {"workload": "configs[2]: 2^%d-constraint trace, full proof (encode + column SHA-256 + Merkle + RLC checks + "
-                         "sampling + envelope), witness matrix resident in HBM" % (self.constraints.bit_length() - 1),
-             "rows": self.rows + 3, "l": L_, "k": K_, "n": N_, "sample_size": T_}
+                         "sampling + envelope), witness matrix resident in HBM" % (self.constraints_per_trace.bit_length() - 1),
+             "rows": self.rows + 3, "l": L_, "k": K_, "n": N_, "sample_size": T_, "proofs_in_flight": self.inflight}
         if self.last:
             proof = C.string_at(self.last[0], self.last[1])               # after the timed region
             d.update(proof_bytes=len(proof), proof_sha256=hashlib.sha256(proof).hexdigest(),
-                     stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]})
+                     stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]},
+                     proof_latency_ms=self.last[5])
         return d
 
     def close(self):
-        self.ctx.trace_destroy(self.trace)
+        if self.pool is not None:
+            self.pool.shutdown()
+        for c, t in zip(self.ctxs, self.traces):
+            c.trace_destroy(t)
+        for c in self.ctxs[1:]:
+            c.close()
 
 
 class ShardedWorkload:
@@ -190,6 +229,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded"])
     ap.add_argument("--log2-constraints", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="full workload: proofs (traces) proved concurrently per GPU in one step")
     a = ap.parse_args()
     log2c = a.log2_constraints if a.log2_constraints is not None else (20 if a.workload == "encode" else 24)
 
@@ -211,7 +251,7 @@ def main():
     if a.workload == "sharded":
         wl = ShardedWorkload(ctx, 1 << log2c, group, pkg)
     else:
-        wl = (FullWorkload if a.workload == "full" else EncodeWorkload)(ctx, 1 << log2c)
+        wl = FullWorkload(ctx, 1 << log2c, pkg, max(1, a.inflight), local_rank) if a.workload == "full" else EncodeWorkload(ctx, 1 << log2c)
 
     def fence():
         group.barrier()
@@ -219,11 +259,15 @@ def main():
 
     for _ in range(a.warmup):
         wl.step()
+    single_ms = wl.single_proof_ms() if hasattr(wl, "single_proof_ms") else None
     fence()
     ctx.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.step()
+    if hasattr(wl, "run"):
+        wl.run(a.steps)
+    else:
+        for _ in range(a.steps):
+            wl.step()
     fence()
     dt = time.perf_counter() - t0
     launches, prows, kms = ctx.profile_read()
@@ -257,7 +301,7 @@ def main():
             "data": "synthetic",
             "config": dict(wl.describe(), parallelism=("1 trace sharded over %d GPUs: all-to-all of codeword column slices + all-gathers" % world)
                            if sharded else "1 trace per GPU (independent traces, no collective)"),
-            "proof_wall_ms": 1e3 * dt / a.steps if a.workload != "encode" else None,
+            "proof_wall_ms": (single_ms if single_ms is not None else 1e3 * dt / a.steps) if a.workload != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": "k_encode_mid", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": rows_per_launch * alg_bytes_per_row,

@@ -266,7 +266,7 @@ struct lig_trace {
     uint8_t* h_enc = nullptr;                              // pinned: 3 x n accumulators
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
-    hipEvent_t ev_gate = nullptr;
+    hipEvent_t ev_gate = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
     uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
     static constexpr size_t CHUNK = 512;
     static constexpr uint32_t GROUP = 64;
@@ -319,6 +319,7 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_ready[i], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_used[i], hipEventDisableTiming));
         if (!T->ev_gate) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
+        for (int a3 = 0; a3 < 3; a3++) if (!T->ev_acc[a3]) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_acc[a3], hipEventDisableTiming));
     }
     {
         std::vector<uint32_t> d(R);
@@ -363,6 +364,7 @@ void lig_trace_destroy(lig_trace* T) {
         (void)hipFree(p);
     for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
     if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
+    for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
     (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
     delete T;
 }
@@ -469,6 +471,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, hipMemcpyDeviceToHost, s));   // for the decommitment (stage 3)
     uint8_t ih[32];
     {   // instance hash with no public arguments besides arg0 = "Ligero\0" (src/webgpu_prover.cpp:110-168)
         const uint8_t z[32] = {0};
@@ -557,39 +560,67 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_lin_interleave(s, lin, linH, linC, k);
     HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));
     lig::launch_quad_rows29(s, T->cw, n, 2, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
-    TRY(lig_encode(c, code));
-    TRY(lig_internal_extend_2k(c, lin));
-    TRY(lig_internal_extend_2k(c, quad));
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);                     // masks (nonbatch_context.hpp:739-753)
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
+    // Each accumulator is extended to the n evaluation points, masked (nonbatch_context.hpp:739-753) and sent to the host
+    // as soon as it is final; the host absorbs it into the stage-2 seed hash (a sequential SHA-256 over 3 MiB, the longest
+    // host step of the proof) while the GPU extends the next one.
     uint8_t* enc = T->h_enc;
-    const size_t enc_bytes = 3 * (size_t)n * 32;
-    HIP_TRY(c, hipMemcpyAsync(enc, T->acc, enc_bytes, hipMemcpyDeviceToHost, s));
+    const size_t vec_bytes = (size_t)n * 32;
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
     HIP_TRY(c, hipMemcpyAsync(T->h_small, T->dots, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipEventRecord(c->ev_join, s));
-    // prover self-check (src/webgpu_prover.cpp:355-386,465-469): the three decodes and the Merkle-node download are
-    // queued now and run on the GPU while the host hashes the 3 MiB of accumulators for the stage-2 seed
+    TRY(lig_encode(c, code));
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
+    HIP_TRY(c, hipMemcpyAsync(enc, code, vec_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(T->ev_acc[0], s));
+    TRY(lig_internal_extend_2k(c, lin));
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
+    HIP_TRY(c, hipMemcpyAsync(enc + vec_bytes, lin, vec_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(T->ev_acc[1], s));
+    TRY(lig_internal_extend_2k(c, quad));
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
+    HIP_TRY(c, hipMemcpyAsync(enc + 2 * vec_bytes, quad, vec_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(T->ev_acc[2], s));
+    // prover self-check (src/webgpu_prover.cpp:355-386,465-469): the three decodes run on the GPU while the host hashes
     H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + ((R ? R : 1) + 2 * (size_t)l) * 32);    // 3 x n
     const fr* accs[3] = {code, lin, quad};
     for (int a3 = 0; a3 < 3; a3++) {
-        HIP_TRY(c, hipMemcpyAsync(tmp, accs[a3], (size_t)n * 32, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(tmp, accs[a3], vec_bytes, hipMemcpyDeviceToDevice, s));
         TRY(lig_decode(c, tmp));
-        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, vec_bytes, hipMemcpyDeviceToHost, s));
     }
-    const size_t n_nodes = lig_merkle_nodes(n);
-    HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipEventSynchronize(c->ev_join));          // accumulators + inner products are on the host
+    HIP_TRY(c, hipEventRecord(c->ev_join, s));
+    {
+        Sha256 h2;
+        h2.add("LigetronStage2", 15).add(info->root, 32);
+        for (int a3 = 0; a3 < 3; a3++) {
+            HIP_TRY(c, hipEventSynchronize(T->ev_acc[a3]));
+            h2.add(enc + (size_t)a3 * vec_bytes, vec_bytes);
+        }
+        h2.finish(info->stage2_seed);
+    }
     {
         const H::Fr sum = H::neg(dots[0]);
         std::memcpy(info->const_sum, sum.v, 32);
     }
-    Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     mark("accumulators to host, seed hash, sampling, decodes");
+    info->ms_stage2 = ms_since(t0);
+    t0 = clk::now();
+
+    // ================= stage 3: open the sampled columns of every committed row, assemble the envelope.  The gather
+    // runs while the host derives the decommitment (the Merkle nodes were downloaded in stage 1) and lays out the envelope;
+    // the opened columns then land in place while the host evaluates the self-check predicates.
     TRY(lig_sample_init(c, idx.data(), idx.size()));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    TRY(lig_gather_rows(c, T->cw, R + 3, T->samples));
+    const size_t n_nodes = lig_merkle_nodes(n);
+    const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
+    char ver[17] = {0};
+    std::memcpy(ver, T->job.version, 16);
+    const size_t smp_bytes = (R + 3) * (size_t)t * 32;
+    const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, ver, T->job.program_hash, T->job.generated_at, k, n, t,
+                                              info->root, sib, idx, enc, smp_bytes);
+    if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
+    HIP_TRY(c, hipMemcpyAsync(T->h_proof + lay.samples_off, T->samples, smp_bytes, hipMemcpyDeviceToHost, s));   // opened columns land in place
+    HIP_TRY(c, hipEventSynchronize(c->ev_join));          // decoded accumulators are on the host
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
     info->valid_code = 1;
     for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
@@ -601,21 +632,6 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     }
     info->valid_quad = 1;
     for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[2 * (size_t)n + i])) info->valid_quad = 0;
-    mark("self-check decodes");
-    const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
-    mark("decommit");
-    info->ms_stage2 = ms_since(t0);
-    t0 = clk::now();
-
-    // ================= stage 3: open the sampled columns of every committed row, assemble the envelope
-    TRY(lig_gather_rows(c, T->cw, R + 3, T->samples));
-    char ver[17] = {0};
-    std::memcpy(ver, T->job.version, 16);
-    const size_t smp_bytes = (R + 3) * (size_t)t * 32;
-    const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, ver, T->job.program_hash, T->job.generated_at, k, n, t,
-                                              info->root, sib, idx, enc, smp_bytes);
-    if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
-    HIP_TRY(c, hipMemcpyAsync(T->h_proof + lay.samples_off, T->samples, smp_bytes, hipMemcpyDeviceToHost, s));   // opened columns land in place
     HIP_TRY(c, hipStreamSynchronize(s));
     *proof = T->h_proof;
     *proof_len = lay.total;
