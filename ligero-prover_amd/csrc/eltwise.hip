@@ -4,6 +4,7 @@
 // shader/kernels.wgsl.in:326-549.  All kernels are grid-stride over 32-byte elements with 2 x 16-byte
 // accesses per lane (a wave touches 2 KiB contiguous per operand).
 #include "kernels.hpp"
+#include "fr29.hpp"
 #include "../../include/lig_hip.h"
 
 namespace lig {
@@ -54,6 +55,52 @@ __global__ void k_eltwise(const fr* __restrict__ x, const fr* __restrict__ y, fr
     }
 }
 
+// EltwiseDivMod with one inversion per M elements (Montgomery's trick) on the 29-bit-limb core: out = x / y, x / 0 = 0 like
+// the reference's per-element extended Euclid (shader/bn254fr.wgsl.in:128-153, kernels.wgsl.in:453-466).  Thread t owns
+// elements t, t + T, ..., t + (M-1)T (T = threads in the grid: coalesced), multiplies the M denominators together (zeros
+// replaced by one), inverts the product once by Fermat (253 squarings + 109 products) and unwinds: 5M + 362 products per
+// thread instead of 363 per element.
+template <int M>
+__global__ void __launch_bounds__(256) k_div_batched(const fr* __restrict__ x, const fr* __restrict__ y, fr* __restrict__ out, size_t count) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const f29 r2 = f29_const_r2();
+    f29 one_m = f29_zero();
+    one_m.v[0] = 1;
+    one_m = f29_montmul(one_m, r2);                       // R' mod p: the Montgomery form of 1
+    f29 pre[M];                                            // pre[j] = z_0 ... z_j  (Montgomery form)
+    bool zero[M];
+    f29 run = one_m;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const size_t i = t + (size_t)j * T;
+        fr yv = fr_zero();
+        if (i < count) yv = fr_load(y + i);
+        zero[j] = !(yv.v[0] | yv.v[1] | yv.v[2] | yv.v[3] | yv.v[4] | yv.v[5] | yv.v[6] | yv.v[7]);
+        const f29 z = zero[j] ? one_m : f29_montmul(unpack29(yv), r2);
+        run = f29_montmul(run, z);
+        pre[j] = run;
+    }
+    // run^(p-2), MSB first; bit 253 of p - 2 is set, so start from run itself
+    f29 inv = run;
+    for (int bit = 252; bit >= 0; bit--) {
+        inv = f29_montmul(inv, inv);
+        uint32_t limb = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) limb = ((bit >> 5) == w) ? fr_p_limb(w) - (w == 0 ? 2u : 0u) : limb;
+        if ((limb >> (bit & 31)) & 1) inv = f29_montmul(inv, run);
+    }
+#pragma unroll
+    for (int j = M - 1; j >= 0; j--) {
+        const size_t i = t + (size_t)j * T;
+        fr yv = fr_zero(), xv = fr_zero();
+        if (i < count) { yv = fr_load(y + i); xv = fr_load(x + i); }
+        const f29 z = zero[j] ? one_m : f29_montmul(unpack29(yv), r2);
+        const f29 inv_j = j ? f29_montmul(inv, pre[j - 1]) : inv;      // (z_0..z_j)^-1 * (z_0..z_{j-1}) = z_j^-1
+        inv = f29_montmul(inv, z);
+        if (i < count) fr_store(out + i, zero[j] ? fr_zero() : pack29(f29_canon(f29_montmul(unpack29(xv), inv_j))));
+    }
+}
+
 static inline uint32_t blocks_for(size_t count) {
     size_t b = (count + 255) / 256;
     if (b > 2048) b = 2048;
@@ -63,6 +110,12 @@ static inline uint32_t blocks_for(size_t count) {
 
 void launch_eltwise(hipStream_t s, int op, const fr* x, const fr* y, fr* out, size_t count, fr scalar, uint32_t bit) {
     dim3 g(blocks_for(count)), b(256);
+    if (op == LIG_OP_DIV && count) {
+        // one k-element row: the Fermat chain is the latency floor, so keep M small and the grid wide; big batches: M = 16
+        if (count >= (1u << 20)) hipLaunchKernelGGL(k_div_batched<16>, dim3((uint32_t)((count + 16 * 256 - 1) / (16 * 256))), b, 0, s, x, y, out, count);
+        else hipLaunchKernelGGL(k_div_batched<4>, dim3((uint32_t)((count + 4 * 256 - 1) / (4 * 256))), b, 0, s, x, y, out, count);
+        return;
+    }
 #define LIG_CASE(OPC) case OPC: hipLaunchKernelGGL(k_eltwise<OPC>, g, b, 0, s, x, y, out, count, scalar, bit); break;
     switch (op) {
         LIG_CASE(LIG_OP_ADD) LIG_CASE(LIG_OP_SUB) LIG_CASE(LIG_OP_ADD_ASSIGN) LIG_CASE(LIG_OP_ADD_CONST)

@@ -8,16 +8,6 @@
 
 namespace lig {
 
-__device__ __forceinline__ f29 f29_zero() {
-    f29 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.v[i] = 0;
-    return r;
-}
-__device__ __forceinline__ f29 f29_const_r2() {
-    return f29{{F29_R2(0), F29_R2(1), F29_R2(2), F29_R2(3), F29_R2(4), F29_R2(5), F29_R2(6), F29_R2(7), F29_R2(8)}};
-}
-
 // ---------------------------------------------------------------------------------------------- stage 2
 // Partial accumulators over one group of rows, one thread per position j < count:
 //   code_part[g][j] = sum_r rc[r] * U[r][j*ues]        (rc given as rc*R' -> plain products)      if rc  != null

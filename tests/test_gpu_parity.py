@@ -77,6 +77,38 @@ def test_eltwise_all_ops(ctx512):
         c.eltwise("MUL_CONST", dx, dy, dx, N, scalar=P)
 
 
+def test_division_batched_inversion(ctx512):
+    """EltwiseDivMod shares one inversion among M denominators (Montgomery's trick): exact quotients vs the oracle's
+    per-element inverse for a row with zeros in every position class, out aliasing y, and -- for the large-batch (M = 16)
+    variant -- the defining property out * y == x (y != 0), out == 0 (y == 0) on 2^20 + 37 elements"""
+    c = ctx512
+    rng = np.random.default_rng(12)
+    N = 8192 + 5
+    x, y = ol.rand_field(rng, N), edge_mix(rng, N)
+    y[[0, 1, 2, 3, 1024, 1025, 4099, N - 1]] = 0          # neighbours in one thread's group, group boundaries, the tail
+    dx, dy, do = c.upload(x), c.upload(y), c.malloc(32 * N)
+    want = np.zeros_like(x)
+    ol.eltwise(11, x, y, want)
+    c.eltwise("DIV", dx, dy, do, N)
+    assert np.array_equal(c.download(do, (N, 8)), want)
+    c.eltwise("DIV", dx, dy, dy, N)                         # out == y
+    assert np.array_equal(c.download(dy, (N, 8)), want)
+    big = (1 << 20) + 37
+    xb, yb = ol.rand_field(rng, big), ol.rand_field(rng, big)
+    zpos = rng.integers(0, big, 500)
+    yb[zpos] = 0
+    dxb, dyb, dob, dchk = c.upload(xb), c.upload(yb), c.malloc(32 * big), c.malloc(32 * big)
+    c.eltwise("DIV", dxb, dyb, dob, big)
+    c.eltwise("MUL", dob, dyb, dchk, big)
+    q, chk = c.download(dob, (big, 8)), c.download(dchk, (big, 8))
+    nz = np.ones(big, dtype=bool)
+    nz[zpos] = False
+    assert np.array_equal(chk[nz], xb[nz])
+    assert not q[~nz].any()
+    for p in (dx, dy, do, dxb, dyb, dob, dchk):
+        c.free(p)
+
+
 def test_powmod_reference_kats(ctx512):
     """tests/webgpu/test_powmod.cpp:58-197 on the HIP backend (N = 8192)"""
     c = ctx512
