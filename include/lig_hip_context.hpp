@@ -212,7 +212,10 @@ public:
 
 private:
     static void* at(const buffer_type& b, size_t elem_off) { return static_cast<char*>(b.data()) + elem_off * 32; }
-    static size_t count(const buffer_type& b, size_t elem_off) { return b.size() / 32 - elem_off; }
+    // element offsets are WebGPU dynamic offsets (buffer_binding.hpp:27-29, engine.cpp eltwise dispatch): they move the bound
+    // window of size() bytes inside the underlying allocation, they do not shrink it (vbn254fr binds variable 0 of its
+    // 512-variable slab once and addresses the others by offset, host_modules/vbn254fr.hpp:64-69)
+    static size_t count(const buffer_type& b, size_t) { return b.size() / 32; }
     void ntt(const hip::buffer_binding& b, int which, int inverse) { hip::check(ctx_, lig_ntt(ctx_, b.bufs[0].data(), which, inverse), "ntt"); }
     // the reference runs eltwise kernels over arrayLength(x) elements (kernels.wgsl.in:326-): the shortest operand bounds the op
     void el3(int op, const hip::buffer_binding& b, hip::eltwise_offset o) {
