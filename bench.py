@@ -277,9 +277,11 @@ def main():
     if rank == 0:
         sharded = a.workload == "sharded"
         total_constraints = wl.constraints * a.steps * (1 if sharded else world)
-        # dominant kernel = k_encode_mid (K2b).  Per encoded row it must read the k coefficients and write the n coset
-        # values: (k + n) * 32 B = 1,310,720 B -- the SURVEY.md 8(d) encode figure (read k*32 + write n*32).
-        alg_bytes_per_row = (K_ + N_) * 32
+        # dominant kernel = k_encode_mid (K2b): per encoded row it reads the k coefficients and writes the three computed
+        # cosets: (k + 3k) * 32 B = 1,048,576 B.  (SURVEY.md 8(d) quotes 1,310,720 B for a whole row encode, read k*32 +
+        # write n*32; the fourth coset is the reversed message and is written by k_encode_out, so the conservative figure
+        # for THIS kernel is its own compulsory traffic.)
+        alg_bytes_per_row = (K_ + 3 * K_) * 32
         avg_launch_s = (kms / max(launches, 1)) * 1e-3
         rows_per_launch = prows / max(launches, 1)
         achieved = rows_per_launch * alg_bytes_per_row / max(avg_launch_s, 1e-12) / 1e9
@@ -288,7 +290,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)["k_encode_mid<10,4>"]
+                pmc = json.load(f)["k_encode_mid<10, true>"]
             traffic = pmc["hbm_bytes_per_row"] * rows_per_launch
             traffic_src = "profiles/pmc_traffic.json (%.0f B/row measured on %d-row launches)" % (pmc["hbm_bytes_per_row"], pmc["rows_in_launch"])
         except (OSError, KeyError, ValueError):
@@ -307,8 +309,10 @@ def main():
                          "algorithmic_bytes_per_launch": rows_per_launch * alg_bytes_per_row,
                          "avg_launch_ms": 1e3 * avg_launch_s, "rows_per_launch": rows_per_launch, "launches": launches,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
-                         "note": "integer-VALU-bound kernel (~193k 256-bit Montgomery products per row in this kernel, "
-                                 "v_mad_u64_u32 at half rate); the HBM fraction is small by construction, see DESIGN.md"},
+                         "encode_row_bytes_survey_8d": (K_ + N_) * 32,
+                         "note": "integer-VALU-bound kernel (~150k 256-bit Montgomery products per row in this kernel, "
+                                 "v_mad_u64_u32 issues at a quarter of the simple-ALU rate); the HBM fraction is small by "
+                                 "construction, see DESIGN.md"},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl.name)
