@@ -128,6 +128,30 @@ int lig_rng_fill(lig_ctx *ctx, const uint8_t *key32, uint64_t first_elem, void *
  * AES-256-CTR field stream keyed by witness_key, one dense linear-test coefficient per witness.  The envelope
  * bytes equal the reference's LigeroProofEnvelope (proto/ligero_proof.proto) for the same rows and seeds. ==== */
 typedef struct lig_trace lig_trace;
+/* Optional batch ("vbn254fr") program executed before the synthetic stream: the guest-visible batch operations of
+ * include/host_modules/vbn254fr.hpp:138-565 as a list.  Variables are slots 0..511 of k elements (l data + k-l padding);
+ * every operation works on all k elements (the reference binds k-element windows, :64-69) and raises the constraint hook
+ * the reference raises (include/zkp/nonbatch_context.hpp:497-553), whose rows are committed in program order:
+ *   SET            x <- data[data_off .. +32*len), rest 0            on_batch_init(x): k-l pads drawn, 1 row
+ *   SET_SCALAR     x[0..l) <- the element at data_off                on_batch_init(x)
+ *   COPY           out <- x                                          on_batch_equal(out, x): 2 rows
+ *   ADD, SUB       out <- x op y                                     no row
+ *   MUL            out <- x*y                                        on_batch_quadratic(x, y, x*y): 3 rows
+ *   DIV            out <- x/y  (x/0 = 0)                             on_batch_quadratic(x/y, y, x): 3 rows
+ *   ADD_CONST, SUB_CONST, CONST_SUB (c - x), MUL_CONST, MONTMUL_CONST with the element at data_off: no row
+ *   ASSERT_EQUAL                                                     on_batch_equal(x, y)
+ *   BIT_DECOMPOSE  slot table of len (= 254) u32 at data_off; out_i <- bit i of x; on_batch_bit(out_i): 1 row each
+ *   FREE           x <- 0
+ * Stage 2 treats the rows as the reference does: check_code for init / bit / quadratic rows (not for equal rows),
+ * check_quadratic for bit (x*x - x) and quadratic triples, quad += r*(x - y) for equal rows; no linear-test randomness.
+ * The reference writes the padding of on_batch_init through a mis-sliced view (it lands in variable 0);
+ * here it goes to the variable's own padding slots. */
+enum {
+    LIG_BOP_SET = 0, LIG_BOP_SET_SCALAR, LIG_BOP_COPY, LIG_BOP_ADD, LIG_BOP_SUB, LIG_BOP_MUL, LIG_BOP_DIV, LIG_BOP_ADD_CONST,
+    LIG_BOP_SUB_CONST, LIG_BOP_CONST_SUB, LIG_BOP_MUL_CONST, LIG_BOP_MONTMUL_CONST, LIG_BOP_ASSERT_EQUAL,
+    LIG_BOP_BIT_DECOMPOSE, LIG_BOP_FREE, LIG_BOP_COUNT
+};
+typedef struct { uint32_t op, out, x, y, len, reserved; uint64_t data_off; } lig_batch_op;
 typedef struct {
     uint64_t n_linear, n_quad;
     uint8_t  encoding_seed[32];      /* src/webgpu_prover.cpp:239-245 (there: std::random_device) */
@@ -135,6 +159,8 @@ typedef struct {
     uint8_t  program_hash[32];
     int64_t  generated_at;           /* metadata timestamp seconds (there: wall clock) */
     char     version[16];            /* "1.5.0" */
+    const lig_batch_op *batch_ops; uint64_t n_batch_ops;      /* NULL / 0: no batch rows; read by prepare and verify only */
+    const uint8_t *batch_data;     uint64_t batch_data_bytes;
 } lig_synth_job;
 typedef struct {
     uint8_t  root[32], stage1_seed[32], stage2_seed[32], const_sum[32];

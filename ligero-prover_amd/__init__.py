@@ -46,7 +46,8 @@ class Comm(C.Structure):
 class SynthJob(C.Structure):
     _fields_ = [("n_linear", C.c_uint64), ("n_quad", C.c_uint64), ("encoding_seed", C.c_uint8 * 32),
                 ("witness_key", C.c_uint8 * 32), ("program_hash", C.c_uint8 * 32), ("generated_at", C.c_int64),
-                ("version", C.c_char * 16)]
+                ("version", C.c_char * 16),
+                ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64)]
 
 
 class ProofInfo(C.Structure):
@@ -286,6 +287,10 @@ class Context:
             job.witness_key[i] = wk[i]
             job.program_hash[i] = 0
         job.version = b"1.5.0"
+        return self.synth_prepare_job(job)
+
+    def synth_prepare_job(self, job):
+        """prepare from a SynthJob built by make_job (e.g. with a batch program attached, tests/batch_prog.py)"""
         t = C.c_void_p()
         self.check(self.L.lig_synth_prepare(self.h, C.byref(job), C.byref(t)))
         return t

@@ -70,8 +70,7 @@ __global__ void __launch_bounds__(256) k_div_batched(const fr* __restrict__ x, c
     f29 pre[M];                                            // pre[j] = z_0 ... z_j  (Montgomery form)
     bool zero[M];
     f29 run = one_m;
-#pragma unroll
-    for (int j = 0; j < M; j++) {
+    for (int j = 0; j < M; j++) {          // kept rolled: pre[] lives in scratch, 36 bytes per step
         const size_t i = t + (size_t)j * T;
         fr yv = fr_zero();
         if (i < count) yv = fr_load(y + i);
@@ -89,7 +88,6 @@ __global__ void __launch_bounds__(256) k_div_batched(const fr* __restrict__ x, c
         for (int w = 0; w < 8; w++) limb = ((bit >> 5) == w) ? fr_p_limb(w) - (w == 0 ? 2u : 0u) : limb;
         if ((limb >> (bit & 31)) & 1) inv = f29_montmul(inv, run);
     }
-#pragma unroll
     for (int j = M - 1; j >= 0; j--) {
         const size_t i = t + (size_t)j * T;
         fr yv = fr_zero(), xv = fr_zero();

@@ -214,7 +214,54 @@ EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, con
     return L;
 }
 
-struct RowDesc { uint8_t kind; uint32_t data; };   // 0 linear, 1 x, 2 y, 3 z
+// kind: 0 linear, 1 x, 2 y, 3 z of the synthetic stream; rows committed by the batch program (lig_hip.h, lig_batch_op):
+// 4 init, 5 bit, 6 / 7 the two rows of an equality, 8 / 9 / 10 the x, y, z of a batch product or quotient
+struct RowDesc { uint8_t kind; uint32_t data; };
+enum : uint8_t { RK_INIT = 4, RK_BIT = 5, RK_EQX = 6, RK_EQY = 7, RK_BQX = 8, RK_BQY = 9, RK_BQZ = 10 };
+inline bool has_code_check(uint8_t kind) { return kind != RK_EQX && kind != RK_EQY; }      // nonbatch_context.hpp:811-825
+
+// Commit order: rows of the batch program in program order, then witness_manager's order for the synthetic stream
+// (witness_manager.hpp:497-503): full linear rows, full quadratic triples, partial linear row, partial quadratic triple.
+// Returns false for a malformed batch program.  n_init = rows that draw padding from the encoding stream at init time.
+bool plan_rows(const lig_synth_job& job, uint32_t l, std::vector<RowDesc>& rows, size_t& n_init) {
+    rows.clear();
+    n_init = 0;
+    if (job.n_batch_ops && !job.batch_ops) return false;
+    for (uint64_t i = 0; i < job.n_batch_ops; i++) {
+        const lig_batch_op& o = job.batch_ops[i];
+        if (o.op >= LIG_BOP_COUNT || o.out >= 512 || o.x >= 512 || o.y >= 512) return false;
+        const uint64_t need = o.op == LIG_BOP_SET ? 32ull * o.len : o.op == LIG_BOP_BIT_DECOMPOSE ? 4ull * o.len :
+                              (o.op == LIG_BOP_SET_SCALAR || (o.op >= LIG_BOP_ADD_CONST && o.op <= LIG_BOP_MONTMUL_CONST)) ? 32 : 0;
+        if (need && (!job.batch_data || o.data_off > job.batch_data_bytes || need > job.batch_data_bytes - o.data_off)) return false;
+        if (o.op == LIG_BOP_SET && o.len > l) return false;
+        if (o.op == LIG_BOP_BIT_DECOMPOSE && o.len > 256) return false;
+        switch (o.op) {
+            case LIG_BOP_SET: case LIG_BOP_SET_SCALAR: rows.push_back({RK_INIT, 0}); n_init++; break;
+            case LIG_BOP_COPY: case LIG_BOP_ASSERT_EQUAL: rows.push_back({RK_EQX, 0}); rows.push_back({RK_EQY, 0}); break;
+            case LIG_BOP_MUL: case LIG_BOP_DIV: rows.push_back({RK_BQX, 0}); rows.push_back({RK_BQY, 0}); rows.push_back({RK_BQZ, 0}); break;
+            case LIG_BOP_BIT_DECOMPOSE: for (uint32_t b = 0; b < o.len; b++) rows.push_back({RK_BIT, 0}); break;
+            default: break;
+        }
+    }
+    const size_t lf = job.n_linear / l, lp = job.n_linear % l, qf = job.n_quad / l, qp = job.n_quad % l;
+    for (size_t i = 0; i < lf; i++) rows.push_back({0, l});
+    for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) rows.push_back({q, l});
+    if (lp) rows.push_back({0, (uint32_t)lp});
+    if (qp) for (uint8_t q = 1; q <= 3; q++) rows.push_back({q, (uint32_t)qp});
+    return true;
+}
+// quadratic-test terms in hook order (one quadratic-stream draw each): (x, y, z) row indices; y = 0xFFFFFFFF marks the
+// equality term r * (x - z) (prover_kernels.hip k_quad_rows)
+std::vector<uint32_t> quad_terms(const std::vector<RowDesc>& rows) {
+    std::vector<uint32_t> t;
+    for (size_t r = 0; r < rows.size(); r++) {
+        const uint8_t kd = rows[r].kind;
+        if (kd == 3 || kd == RK_BQZ) { t.push_back((uint32_t)r - 2); t.push_back((uint32_t)r - 1); t.push_back((uint32_t)r); }
+        else if (kd == RK_BIT) { t.push_back((uint32_t)r); t.push_back((uint32_t)r); t.push_back((uint32_t)r); }
+        else if (kd == RK_EQY) { t.push_back((uint32_t)r - 1); t.push_back(0xFFFFFFFFu); t.push_back((uint32_t)r); }
+    }
+    return t;
+}
 
 // Row-chunk schedule [begin, end) pairs.  Chunks are `big` rows except that the exposed end of a two-stream pipeline
 // is kept short: `head` rows first (stage 2: the encode stream waits for the first randomness rows) and/or a short
@@ -249,7 +296,7 @@ struct lig_trace {
     lig_ctx* c = nullptr;
     lig_synth_job job;
     std::vector<RowDesc> rows;          // committed non-mask rows in commit order
-    size_t R = 0;
+    size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
     fr* cw = nullptr;                   // (R+3) x n codewords, resident across the stages
     fr* randb = nullptr;                // chunk x k randomness rows
@@ -274,6 +321,91 @@ struct lig_trace {
 
 #define TRY(x) do { int rc__ = (x); if (rc__ != LIG_OK) return rc__; } while (0)
 
+// The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
+// kernel into a temporary + a copy (as vbn254fr_module does), every hook a device-to-device copy of the rows it names
+// into the witness matrix.  The padding of an initialised variable comes from the encoding stream, 192 draws per init
+// in program order (pad_encoding_random, nonbatch_context.hpp:497-510).
+static int run_batch_program(lig_ctx* c, const lig_synth_job& job, fr* rows_out) {
+    const uint32_t l = c->l, k = c->k, pad = k - l;
+    hipStream_t s = c->stream;
+    uint32_t nvars = 1;
+    for (uint64_t i = 0; i < job.n_batch_ops; i++) {
+        const lig_batch_op& o = job.batch_ops[i];
+        nvars = std::max(nvars, std::max(o.out, std::max(o.x, o.y)) + 1);
+        if (o.op == LIG_BOP_BIT_DECOMPOSE)
+            for (uint32_t b = 0; b < o.len; b++) { uint32_t slot; std::memcpy(&slot, job.batch_data + o.data_off + 4ull * b, 4); nvars = std::max(nvars, (slot & 511u) + 1); }
+    }
+    fr* vars = nullptr; fr* tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&vars, (size_t)nvars * k * sizeof(fr)));
+    struct Free { fr*& a; fr*& b; lig_ctx* c; ~Free() { (void)hipStreamSynchronize(c->stream); (void)hipFree(a); (void)hipFree(b); } } guard{vars, tmp, c};
+    HIP_TRY(c, hipMalloc((void**)&tmp, (size_t)k * sizeof(fr)));
+    HIP_TRY(c, hipMemsetAsync(vars, 0, (size_t)nvars * k * sizeof(fr), s));
+    uint32_t rk[60];
+    lig::aes256_expand_host(job.encoding_seed, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const size_t vb = (size_t)k * sizeof(fr);
+    size_t r = 0, inits = 0;
+    auto var = [&](uint32_t i) { return vars + (size_t)i * k; };
+    auto commit = [&](const fr* src) -> int { HIP_TRY(c, hipMemcpyAsync(rows_out + (r++) * (size_t)k, src, vb, hipMemcpyDeviceToDevice, s)); return LIG_OK; };
+    auto to_out = [&](uint32_t out) -> int { HIP_TRY(c, hipMemcpyAsync(var(out), tmp, vb, hipMemcpyDeviceToDevice, s)); return LIG_OK; };
+    std::vector<uint8_t> stage;
+    for (uint64_t i = 0; i < job.n_batch_ops; i++) {
+        const lig_batch_op& o = job.batch_ops[i];
+        const uint8_t* data = job.batch_data ? job.batch_data + o.data_off : nullptr;
+        switch (o.op) {
+            case LIG_BOP_SET: case LIG_BOP_SET_SCALAR: {
+                stage.assign(vb, 0);                                                    // write_buffer_clear
+                if (o.op == LIG_BOP_SET) std::memcpy(stage.data(), data, 32ull * o.len);
+                else for (uint32_t e = 0; e < l; e++) std::memcpy(stage.data() + 32ull * e, data, 32);
+                HIP_TRY(c, hipMemcpyAsync(var(o.x), stage.data(), vb, hipMemcpyHostToDevice, s));
+                HIP_TRY(c, hipStreamSynchronize(s));                                    // `stage` is reused
+                lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)(inits++) * pad, var(o.x), 1, pad, k, l, 1, pad);
+                TRY(commit(var(o.x)));
+                break;
+            }
+            case LIG_BOP_COPY:
+                if (o.out != o.x) HIP_TRY(c, hipMemcpyAsync(var(o.out), var(o.x), vb, hipMemcpyDeviceToDevice, s));
+                TRY(commit(var(o.out))); TRY(commit(var(o.x)));
+                break;
+            case LIG_BOP_ADD: TRY(lig_eltwise(c, LIG_OP_ADD, var(o.x), var(o.y), tmp, k, nullptr, 0)); TRY(to_out(o.out)); break;
+            case LIG_BOP_SUB: TRY(lig_eltwise(c, LIG_OP_SUB, var(o.x), var(o.y), tmp, k, nullptr, 0)); TRY(to_out(o.out)); break;
+            case LIG_BOP_MUL:
+                TRY(lig_eltwise(c, LIG_OP_MUL, var(o.x), var(o.y), tmp, k, nullptr, 0));
+                TRY(commit(var(o.x))); TRY(commit(var(o.y))); TRY(commit(tmp));
+                TRY(to_out(o.out));
+                break;
+            case LIG_BOP_DIV:
+                TRY(lig_eltwise(c, LIG_OP_DIV, var(o.x), var(o.y), tmp, k, nullptr, 0));
+                TRY(commit(tmp)); TRY(commit(var(o.y))); TRY(commit(var(o.x)));
+                TRY(to_out(o.out));
+                break;
+            case LIG_BOP_ADD_CONST: case LIG_BOP_SUB_CONST: case LIG_BOP_CONST_SUB: case LIG_BOP_MUL_CONST: case LIG_BOP_MONTMUL_CONST: {
+                static const int map[5] = {LIG_OP_ADD_CONST, LIG_OP_SUB_CONST, LIG_OP_CONST_SUB, LIG_OP_MUL_CONST, LIG_OP_MONTMUL_CONST};
+                TRY(lig_eltwise(c, map[o.op - LIG_BOP_ADD_CONST], var(o.x), nullptr, tmp, k, data, 0));
+                TRY(to_out(o.out));
+                break;
+            }
+            case LIG_BOP_ASSERT_EQUAL: TRY(commit(var(o.x))); TRY(commit(var(o.y))); break;
+            case LIG_BOP_BIT_DECOMPOSE:
+                for (uint32_t b = 0; b < o.len; b++) {
+                    uint32_t slot;
+                    std::memcpy(&slot, data + 4ull * b, 4);
+                    slot &= 511u;
+                    TRY(lig_eltwise(c, LIG_OP_BIT_DECOMPOSE, var(o.x), nullptr, tmp, k, nullptr, b));
+                    TRY(to_out(slot));
+                    TRY(commit(var(slot)));
+                }
+                break;
+            case LIG_BOP_FREE: HIP_TRY(c, hipMemsetAsync(var(o.x), 0, vb, s)); break;
+            default: break;
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
 extern "C" {
 
 // plan_rows: commit order of witness_manager (witness_manager.hpp:497-503): full linear rows, full quadratic
@@ -285,13 +417,10 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     if (l >= k || l < 2 || t > n) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l < k and 192 <= n");
     lig_trace* T = new lig_trace();
     T->c = c; T->job = *job;
-    const size_t lf = job->n_linear / l, lp = job->n_linear % l, qf = job->n_quad / l, qp = job->n_quad % l;
-    for (size_t i = 0; i < lf; i++) T->rows.push_back({0, l});
-    for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) T->rows.push_back({q, l});
-    if (lp) T->rows.push_back({0, (uint32_t)lp});
-    if (qp) for (uint8_t q = 1; q <= 3; q++) T->rows.push_back({q, (uint32_t)qp});
+    if (!plan_rows(*job, l, T->rows, T->n_init)) { delete T; FAIL(c, LIG_E_ARG, "malformed batch program"); }
     const size_t R = T->R = T->rows.size();
-    for (size_t r = 0; r < R; r++) if (T->rows[r].kind == 3) { T->triples.push_back((uint32_t)r - 2); T->triples.push_back((uint32_t)r - 1); T->triples.push_back((uint32_t)r); }
+    T->triples = quad_terms(T->rows);
+    for (T->RB = 0; T->RB < R && T->rows[T->RB].kind >= RK_INIT; T->RB++) {}
     const size_t chunk = lig_trace::CHUNK, groups = (chunk + lig_trace::GROUP - 1) / lig_trace::GROUP;
     *out = T;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
@@ -333,8 +462,12 @@ int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     lig::aes256_expand_host(job->witness_key, rk);
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (T->RB) TRY(run_batch_program(c, *job, T->msgs));
+    lig::aes256_expand_host(job->witness_key, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint64_t pos = 0;
-    size_t r = 0;
+    size_t r = T->RB;
     while (r < R) {
         const RowDesc d = T->rows[r];
         if (d.kind == 0) {                      // run of linear rows with the same fill
@@ -396,8 +529,9 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     uint64_t epos = 0;
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, T->msgs, R, pad, k, l, 1, pad);                 // pad_encoding_random of every row
-    epos += (uint64_t)R * pad;
+    epos = (uint64_t)T->n_init * pad;                                                              // batch init rows drew theirs in prepare
+    lig::launch_rng_fill_rows(s, c->rk_dev, epos, T->msgs + T->RB * (size_t)k, R - T->RB, pad, k, l, 1, pad);   // pad_encoding_random of every stream row
+    epos += (uint64_t)(R - T->RB) * pad;
     mark("  pads");
     fr* mask = T->cw + R * (size_t)n;                                                               // the 3 mask rows are formed in place
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
@@ -487,11 +621,14 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple (three engines, same key)
         std::vector<H::Fr> rc, rq;
         FieldStream code(info->stage1_seed), quad(info->stage1_seed);
-        code.next(R, rc);
+        size_t n_code = 0;
+        for (size_t r = 0; r < R; r++) n_code += has_code_check(T->rows[r].kind);
+        code.next(n_code, rc);
         quad.next(NT, rq);
         std::vector<lig::f29s> coef(R + 2 * NT + 1);
+        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
         const H::Fr R261sq = H::mul(R261, R261);
-        for (size_t r = 0; r < R; r++) coef[r] = to_f29s_host(rc[r], R261);
+        for (size_t r = 0, ci = 0; r < R; r++) if (has_code_check(T->rows[r].kind)) coef[r] = to_f29s_host(rc[ci++], R261);
         for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
         HIP_TRY(c, hipMemcpyAsync(T->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
         lig::aes256_expand_host(info->stage1_seed, rk);
@@ -681,6 +818,7 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
     lig_shard* S = new lig_shard();
     *out = S;
     S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world; S->ncol = n / world;
+    if (job->n_batch_ops) FAIL(c, LIG_E_ARG, "batch rows are not supported by the sharded prover");
     const size_t lf = job->n_linear / l, lp = job->n_linear % l, qf = job->n_quad / l, qp = job->n_quad % l;
     for (size_t i = 0; i < lf; i++) S->rows.push_back({0, l});
     for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) S->rows.push_back({q, l});
@@ -1027,13 +1165,8 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     hipStream_t s = c->stream;
     // ---- row plan of the public constraint stream
     std::vector<RowDesc> rows;
-    {
-        const size_t lf = job->n_linear / l, lp = job->n_linear % l, qf = job->n_quad / l, qp = job->n_quad % l;
-        for (size_t i = 0; i < lf; i++) rows.push_back({0, l});
-        for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) rows.push_back({q, l});
-        if (lp) rows.push_back({0, (uint32_t)lp});
-        if (qp) for (uint8_t q = 1; q <= 3; q++) rows.push_back({q, (uint32_t)qp});
-    }
+    size_t n_init = 0;
+    if (!plan_rows(*job, l, rows, n_init)) return LIG_E_ARG;
     const size_t R = rows.size();
     // ---- parse the envelope (proto/ligero_proof.proto; deserialize_proof, proof_serializer.hpp:193-226)
     PbReader top{proof, proof + proof_len}, meta{nullptr, nullptr}, body{nullptr, nullptr};
@@ -1106,8 +1239,7 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
     struct Cleanup { std::vector<void*>& v; lig_ctx* c; void* sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
     const size_t groups = (CH + lig_trace::GROUP - 1) / lig_trace::GROUP;
-    std::vector<uint32_t> triples;
-    for (size_t r = 0; r < R; r++) if (rows[r].kind == 3) { triples.push_back((uint32_t)r - 2); triples.push_back((uint32_t)r - 1); triples.push_back((uint32_t)r); }
+    const std::vector<uint32_t> triples = quad_terms(rows);
     const size_t NT = triples.size() / 3;
     TRY(dm((void**)&dS, smp_bytes));
     TRY(dm((void**)&drand, CH * (size_t)k * 32));
@@ -1129,11 +1261,14 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     {
         std::vector<H::Fr> rc, rq;
         FieldStream code(seed1), quad(seed1);
-        code.next(R, rc);
+        size_t n_code = 0;
+        for (size_t r = 0; r < R; r++) n_code += has_code_check(rows[r].kind);
+        code.next(n_code, rc);
         quad.next(NT, rq);
         std::vector<lig::f29s> coef(R + 2 * NT + 1);
+        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
         const H::Fr R261sq = H::mul(R261, R261);
-        for (size_t r = 0; r < R; r++) coef[r] = to_f29s_host(rc[r], R261);
+        for (size_t r = 0, ci = 0; r < R; r++) if (has_code_check(rows[r].kind)) coef[r] = to_f29s_host(rc[ci++], R261);
         for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
         HIP_TRY(c, hipMemcpyAsync(dcoef, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
         uint32_t rk[60];

@@ -54,10 +54,12 @@ __global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, siz
     if (j >= count) return;
     f29 a = unpack29(fr_load(quad + j));
     for (size_t t = 0; t < n_triples; t++) {
+        const uint32_t yi = triples[3 * t + 1];
         const f29 x = unpack29(fr_load(U + (size_t)triples[3 * t] * urs + (size_t)j * ues));
-        const f29 y = unpack29(fr_load(U + (size_t)triples[3 * t + 1] * urs + (size_t)j * ues));
         const f29 z = unpack29(fr_load(U + (size_t)triples[3 * t + 2] * urs + (size_t)j * ues));
-        const f29 xy = f29_montmul(f29_montmul(x, y), f29_load_tab(rq2 + t));      // x*y*rq  (< 1.2p)
+        // y index 0xFFFFFFFF: the equality term rq * (x - z) of on_batch_equal (nonbatch_context.hpp:811-825), i.e. y = 1
+        const f29 xy = yi == 0xFFFFFFFFu ? f29_montmul(x, f29_load_tab(rq1 + t))
+                                         : f29_montmul(f29_montmul(x, unpack29(fr_load(U + (size_t)yi * urs + (size_t)j * ues))), f29_load_tab(rq2 + t));      // x*y*rq  (< 1.2p)
         const f29 zq = f29_montmul(z, f29_load_tab(rq1 + t));                       // z*rq    (< 1.2p)
         a = f29_add(a, f29_add(xy, f29_sub_k2(f29_zero(), zq)));                    // + xy + (2p - zq)
         a = f29_reduce_2p(a);

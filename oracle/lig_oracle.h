@@ -123,6 +123,28 @@ size_t lo_serialize_proof(uint8_t *out, size_t cap,
                           const lo_fr *samples, size_t nsample_elems);
 
 /* ---- synthetic row stream + reference-structured prover / verifier ---- */
+/* Batch ("vbn254fr") program: the guest-visible batch operations of include/host_modules/vbn254fr.hpp:138-565 as a
+ * list, executed before the synthetic stream.  Variables are slots 0..511 of k elements (l data + k-l padding); every
+ * operation works on all k elements (the reference binds k-element windows, vbn254fr.hpp:64-69) and raises the
+ * constraint hook the reference raises (nonbatch_context.hpp:497-553): the rows it names are committed in program order.
+ *   SET x <- data[data_off .. +32*len), rest 0                      -> on_batch_init(x)   (k-l pads drawn, 1 row)
+ *   SET_SCALAR x[0..l) <- data[data_off .. +32)                      -> on_batch_init(x)
+ *   COPY out <- x                                                    -> on_batch_equal(out, x)        (2 rows)
+ *   ADD/SUB out <- x op y;  *_CONST with the 32-byte constant at data_off (CONST_SUB: c - x)          (no row)
+ *   MUL out <- x*y                                                   -> on_batch_quadratic(x, y, x*y) (3 rows)
+ *   DIV out <- x/y                                                   -> on_batch_quadratic(x/y, y, x) (3 rows)
+ *   ASSERT_EQUAL                                                     -> on_batch_equal(x, y)
+ *   BIT_DECOMPOSE: slot table of `len` (= 254) u32 at data_off; out_i <- bit i of x -> on_batch_bit(out_i) (1 row each)
+ *   FREE x <- 0
+ * The reference writes the padding of on_batch_init through a mis-sliced view (it lands in variable 0);
+ * here, as in the HIP prover, it goes to the variable's own padding slots. */
+enum {
+    LO_BOP_SET = 0, LO_BOP_SET_SCALAR, LO_BOP_COPY, LO_BOP_ADD, LO_BOP_SUB, LO_BOP_MUL, LO_BOP_DIV, LO_BOP_ADD_CONST,
+    LO_BOP_SUB_CONST, LO_BOP_CONST_SUB, LO_BOP_MUL_CONST, LO_BOP_MONTMUL_CONST, LO_BOP_ASSERT_EQUAL, LO_BOP_BIT_DECOMPOSE,
+    LO_BOP_FREE, LO_BOP_COUNT
+};
+typedef struct { uint32_t op, out, x, y, len, reserved; uint64_t data_off; } lo_batch_op;
+
 typedef struct {
     uint32_t l, k, n, t;
     uint64_t n_linear;            /* number of linear constraints (witness slots) */
@@ -131,6 +153,8 @@ typedef struct {
     uint8_t  witness_key[32];     /* AES key of the synthetic witness stream */
     int64_t  generated_at;
     int      threads;
+    const lo_batch_op *batch_ops; uint64_t n_batch_ops;        /* optional batch program (NULL / 0: none) */
+    const uint8_t *batch_data;    uint64_t batch_data_bytes;
 } lo_job;
 
 typedef struct {

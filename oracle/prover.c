@@ -36,20 +36,110 @@ void lo_synth_key(uint64_t seed, uint8_t key[32]) {
 /* ------------------------------------------------------------------ row plan
  * Commit order (witness_manager.hpp:497-503 + callbacks firing as rows fill): full linear rows, full
  * quadratic triples, then at finalize the partial linear row, the partial quadratic triple, 3 masks. */
-typedef struct { int kind; /* 0 linear, 1 quad x, 2 quad y, 3 quad z */ uint32_t data; } rowdesc;
+typedef struct { int kind; /* 0 linear, 1 quad x, 2 quad y, 3 quad z; batch rows: 4 init, 5 bit, 6/7 equal x/y, 8/9/10 quadratic x/y/z */ uint32_t data; } rowdesc;
+enum { RK_INIT = 4, RK_BIT = 5, RK_EQX = 6, RK_EQY = 7, RK_BQX = 8, RK_BQY = 9, RK_BQZ = 10 };
+static int has_code_check(int kind) { return kind != RK_EQX && kind != RK_EQY; }      /* nonbatch_context.hpp:811-825: no check_code */
+static int mid_of_group(int kind) { return kind == 1 || kind == 2 || kind == RK_EQX || kind == RK_BQX || kind == RK_BQY; }
+
+/* rows committed by the batch program, in program order (-1: malformed program) */
+static long batch_plan(const lo_job *j, rowdesc *d) {
+    long r = 0;
+    for (uint64_t i = 0; i < j->n_batch_ops; i++) {
+        const lo_batch_op *o = &j->batch_ops[i];
+        if (o->op >= LO_BOP_COUNT || o->out >= 512 || o->x >= 512 || o->y >= 512) return -1;
+        const uint64_t need = o->op == LO_BOP_SET ? 32ull * o->len : o->op == LO_BOP_BIT_DECOMPOSE ? 4ull * o->len :
+                              (o->op == LO_BOP_SET_SCALAR || (o->op >= LO_BOP_ADD_CONST && o->op <= LO_BOP_MONTMUL_CONST)) ? 32 : 0;
+        if (need && (o->data_off > j->batch_data_bytes || need > j->batch_data_bytes - o->data_off)) return -1;
+        if (o->op == LO_BOP_SET && o->len > j->l) return -1;
+        if (o->op == LO_BOP_BIT_DECOMPOSE && o->len > 256) return -1;
+        switch (o->op) {
+        case LO_BOP_SET: case LO_BOP_SET_SCALAR: if (d) d[r] = (rowdesc){RK_INIT, 0}; r += 1; break;
+        case LO_BOP_COPY: case LO_BOP_ASSERT_EQUAL: if (d) { d[r] = (rowdesc){RK_EQX, 0}; d[r + 1] = (rowdesc){RK_EQY, 0}; } r += 2; break;
+        case LO_BOP_MUL: case LO_BOP_DIV: if (d) { d[r] = (rowdesc){RK_BQX, 0}; d[r + 1] = (rowdesc){RK_BQY, 0}; d[r + 2] = (rowdesc){RK_BQZ, 0}; } r += 3; break;
+        case LO_BOP_BIT_DECOMPOSE: for (uint32_t b = 0; b < o->len; b++) { if (d) d[r] = (rowdesc){RK_BIT, 0}; r++; } break;
+        default: break;
+        }
+    }
+    return r;
+}
 
 static size_t plan_rows(const lo_job *j, rowdesc **out) {
     size_t lf = j->n_linear / j->l, lp = j->n_linear % j->l;
     size_t qf = j->n_quad / j->l, qp = j->n_quad % j->l;
-    size_t total = lf + (lp ? 1 : 0) + 3 * (qf + (qp ? 1 : 0));
+    long rb = batch_plan(j, NULL);
+    if (rb < 0) rb = 0;                                   /* malformed programs are rejected by lo_prove / lo_verify */
+    size_t total = (size_t)rb + lf + (lp ? 1 : 0) + 3 * (qf + (qp ? 1 : 0));
     rowdesc *d = malloc(sizeof(rowdesc) * (total ? total : 1));
-    size_t r = 0;
+    size_t r = (size_t)rb;
+    if (rb) batch_plan(j, d);
     for (size_t i = 0; i < lf; i++) d[r++] = (rowdesc){0, j->l};
     for (size_t i = 0; i < qf; i++) for (int t = 1; t <= 3; t++) d[r++] = (rowdesc){t, j->l};
     if (lp) d[r++] = (rowdesc){0, (uint32_t)lp};
     if (qp) for (int t = 1; t <= 3; t++) d[r++] = (rowdesc){t, (uint32_t)qp};
     *out = d;
     return total;
+}
+
+/* The batch program on k-element variables; committed rows are appended to `rows` (vbn254fr.hpp:138-565 for the
+ * operations, nonbatch_context.hpp:497-553 for what each hook commits).  `enc` = the encoding stream (pads). */
+static void batch_run(const lo_job *j, lo_rng *enc, lo_fr *rows) {
+    const uint32_t l = j->l, k = j->k;
+    if (!j->n_batch_ops) return;
+    lo_fr *vars = calloc((size_t)512 * k, sizeof(lo_fr)), *tmp = calloc(k, sizeof(lo_fr));
+    size_t r = 0;
+#define VAR(i) (vars + (size_t)(i) * k)
+#define COMMIT(src) do { memcpy(rows + (r++) * (size_t)k, (src), sizeof(lo_fr) * k); } while (0)
+    for (uint64_t i = 0; i < j->n_batch_ops; i++) {
+        const lo_batch_op *o = &j->batch_ops[i];
+        const uint8_t *data = j->batch_data + o->data_off;
+        lo_fr c;
+        switch (o->op) {
+        case LO_BOP_SET: case LO_BOP_SET_SCALAR:
+            memset(VAR(o->x), 0, sizeof(lo_fr) * k);                       /* write_buffer_clear */
+            if (o->op == LO_BOP_SET) memcpy(VAR(o->x), data, 32ull * o->len);
+            else for (uint32_t e = 0; e < l; e++) memcpy(&VAR(o->x)[e], data, 32);
+            lo_rng_fill(enc, VAR(o->x) + l, k - l);                        /* on_batch_init: pad_encoding_random */
+            COMMIT(VAR(o->x));
+            break;
+        case LO_BOP_COPY:
+            memmove(VAR(o->out), VAR(o->x), sizeof(lo_fr) * k);
+            COMMIT(VAR(o->out)); COMMIT(VAR(o->x));                        /* on_batch_equal(out, in) */
+            break;
+        case LO_BOP_ADD: lo_eltwise(LO_OP_ADD, VAR(o->x), VAR(o->y), tmp, k, NULL, 0); memcpy(VAR(o->out), tmp, sizeof(lo_fr) * k); break;
+        case LO_BOP_SUB: lo_eltwise(LO_OP_SUB, VAR(o->x), VAR(o->y), tmp, k, NULL, 0); memcpy(VAR(o->out), tmp, sizeof(lo_fr) * k); break;
+        case LO_BOP_MUL:
+            lo_eltwise(LO_OP_MUL, VAR(o->x), VAR(o->y), tmp, k, NULL, 0);
+            COMMIT(VAR(o->x)); COMMIT(VAR(o->y)); COMMIT(tmp);             /* on_batch_quadratic(x, y, tmp) */
+            memcpy(VAR(o->out), tmp, sizeof(lo_fr) * k);
+            break;
+        case LO_BOP_DIV:
+            lo_eltwise(LO_OP_DIV, VAR(o->x), VAR(o->y), tmp, k, NULL, 0);
+            COMMIT(tmp); COMMIT(VAR(o->y)); COMMIT(VAR(o->x));             /* on_batch_quadratic(tmp, y, x) */
+            memcpy(VAR(o->out), tmp, sizeof(lo_fr) * k);
+            break;
+        case LO_BOP_ADD_CONST: case LO_BOP_SUB_CONST: case LO_BOP_CONST_SUB: case LO_BOP_MUL_CONST: case LO_BOP_MONTMUL_CONST: {
+            static const int map[5] = {LO_OP_ADD_CONST, LO_OP_SUB_CONST, LO_OP_CONST_SUB, LO_OP_MUL_CONST, LO_OP_MONTMUL_CONST};
+            memcpy(&c, data, 32);
+            lo_eltwise(map[o->op - LO_BOP_ADD_CONST], VAR(o->x), NULL, tmp, k, &c, 0);
+            memcpy(VAR(o->out), tmp, sizeof(lo_fr) * k);
+            break;
+        }
+        case LO_BOP_ASSERT_EQUAL: COMMIT(VAR(o->x)); COMMIT(VAR(o->y)); break;
+        case LO_BOP_BIT_DECOMPOSE:
+            for (uint32_t b = 0; b < o->len; b++) {
+                uint32_t slot; memcpy(&slot, data + 4ull * b, 4);
+                lo_eltwise(LO_OP_BIT_DECOMPOSE, VAR(o->x), NULL, tmp, k, NULL, b);
+                memcpy(VAR(slot & 511), tmp, sizeof(lo_fr) * k);
+                COMMIT(VAR(slot & 511));                                   /* on_batch_bit */
+            }
+            break;
+        case LO_BOP_FREE: memset(VAR(o->x), 0, sizeof(lo_fr) * k); break;
+        default: break;
+        }
+    }
+#undef VAR
+#undef COMMIT
+    free(vars); free(tmp);
 }
 size_t lo_job_rows(const lo_job *j) { rowdesc *d; size_t r = plan_rows(j, &d); free(d); return r + 3; }
 
@@ -60,8 +150,10 @@ void lo_form_rows(const lo_job *j, lo_fr *rows, lo_fr *mask_code, lo_fr *mask_li
     const uint32_t l = j->l, k = j->k;
     rowdesc *d; size_t R = plan_rows(j, &d);
     lo_rng wit, enc; lo_rng_init(&wit, j->witness_key); lo_rng_init(&enc, j->encoding_seed);
+    batch_run(j, &enc, rows);                                               /* batch rows come first, with their own pads */
     for (size_t r = 0; r < R; r++) {
         lo_fr *row = rows + r * k;
+        if (d[r].kind >= RK_INIT) continue;
         memset(row, 0, sizeof(lo_fr) * k);
         if (d[r].kind != 3) lo_rng_fill(&wit, row, d[r].data);        /* linear, x, y: fresh witnesses */
         else {                                                          /* z = x * y */
@@ -153,7 +245,7 @@ static void gather(lo_fr *dst, const lo_fr *cw, const uint32_t *idx, uint32_t t)
 /* rows per batch, never splitting a quadratic triple (x,y,z must be encoded together) */
 static size_t batch_len(const rowdesc *d, size_t b, size_t R, size_t B) {
     size_t nb = R - b < B ? R - b : B;
-    while (nb > 0 && (d[b + nb - 1].kind == 1 || d[b + nb - 1].kind == 2)) nb--;
+    while (nb > 0 && mid_of_group(d[b + nb - 1].kind)) nb--;
     return nb;
 }
 
@@ -165,6 +257,7 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     const uint32_t l = j->l, k = j->k, n = j->n, t = j->t;
     const int T = j->threads > 0 ? j->threads : 1;
     lo_omp_threads = T;
+    if (batch_plan(j, NULL) < 0) return -1;
     lo_ctx *c = lo_ctx_new(l, k, n);
     if (!c) return -1;
     rowdesc *d; size_t R = plan_rows(j, &d);
@@ -230,8 +323,9 @@ int lo_prove(const lo_job *j, lo_proof *P) {
         lo_encode_rows(c, rows + b * k, cws, nb, T);
         lo_encode_rows(c, rrows, rws, nb, T);
         for (size_t r = 0; r < nb; r++) {                       /* coefficient draws in call order */
-            lo_rng_next(&code_rng, &rcs[r]);
-            if (d[b + r].kind == 3) lo_rng_next(&quad_rng, &rqs[r]);
+            const int kd = d[b + r].kind;
+            if (has_code_check(kd)) lo_rng_next(&code_rng, &rcs[r]);
+            if (kd == 3 || kd == RK_BIT || kd == RK_EQY || kd == RK_BQZ) lo_rng_next(&quad_rng, &rqs[r]);
         }
         /* the per-row executor calls of check_code / check_linear / check_quadratic, column-block parallel */
 #ifdef _OPENMP
@@ -240,11 +334,16 @@ int lo_prove(const lo_job *j, lo_proof *P) {
         for (long jb = 0; jb < (long)n; jb += 256) {
             size_t blk = n - jb < 256 ? n - jb : 256;
             for (size_t r = 0; r < nb; r++) {
-                lo_eltwise(LO_OP_FMA_CONST, cws + r * n + jb, NULL, P->code + jb, blk, &rcs[r], 0);
-                lo_eltwise(LO_OP_FMA, cws + r * n + jb, rws + r * n + jb, P->lin + jb, blk, NULL, 0);
-                if (d[b + r].kind == 3) {
-                    lo_eltwise(LO_OP_MUL, cws + (r - 2) * n + jb, cws + (r - 1) * n + jb, tmp1 + jb, blk, NULL, 0);
+                const int kd = d[b + r].kind;
+                if (has_code_check(kd)) lo_eltwise(LO_OP_FMA_CONST, cws + r * n + jb, NULL, P->code + jb, blk, &rcs[r], 0);
+                if (d[b + r].data) lo_eltwise(LO_OP_FMA, cws + r * n + jb, rws + r * n + jb, P->lin + jb, blk, NULL, 0);
+                if (kd == 3 || kd == RK_BQZ || kd == RK_BIT) {           /* check_quadratic: x*y - z (bit: x*x - x) */
+                    const size_t rx = kd == RK_BIT ? r : r - 2, ry = kd == RK_BIT ? r : r - 1;
+                    lo_eltwise(LO_OP_MUL, cws + rx * n + jb, cws + ry * n + jb, tmp1 + jb, blk, NULL, 0);
                     lo_eltwise(LO_OP_SUB, tmp1 + jb, cws + r * n + jb, tmp2 + jb, blk, NULL, 0);
+                    lo_eltwise(LO_OP_FMA_CONST, tmp2 + jb, NULL, P->quad + jb, blk, &rqs[r], 0);
+                } else if (kd == RK_EQY) {                               /* on_batch_equal: quad += r * (x - y) */
+                    lo_eltwise(LO_OP_SUB, cws + (r - 1) * n + jb, cws + r * n + jb, tmp2 + jb, blk, NULL, 0);
                     lo_eltwise(LO_OP_FMA_CONST, tmp2 + jb, NULL, P->quad + jb, blk, &rqs[r], 0);
                 }
             }
@@ -337,6 +436,7 @@ int lo_verify(const lo_job *j, const lo_fr *const_sum, const uint8_t *proof, siz
         default: break;
         }
     }
+    if (batch_plan(j, NULL) < 0) ok = 0;
     rowdesc *d = NULL; size_t R = plan_rows(j, &d);
     if (ok && (cb != 32ull * n || lb != 32ull * n || qb != 32ull * n || sb != 32ull * (R + 3) * t || nidx != t)) ok = 0;
     lo_ctx *c = ok ? lo_ctx_new(l, k, n) : NULL;
@@ -358,14 +458,24 @@ int lo_verify(const lo_job *j, const lo_fr *const_sum, const uint8_t *proof, siz
         for (size_t r = 0; ok && r < R; r++) {
             const lo_fr *s = S + r * t;
             lo_colsha_update(st, s, t);
-            rand_row(&lin_rng, rr, d[r].data, k); memset(rr + k, 0, sizeof(lo_fr) * (n - k)); lo_encode(c, rr); gather(rg, rr, si, t);
-            lo_fr rc; lo_rng_next(&code_rng, &rc);
-            lo_eltwise(LO_OP_FMA_CONST, s, NULL, vc, t, &rc, 0);
-            lo_eltwise(LO_OP_FMA, s, rg, vl, t, NULL, 0);
-            if (d[r].kind == 3) {
+            const int kd = d[r].kind;
+            if (d[r].data) {
+                rand_row(&lin_rng, rr, d[r].data, k); memset(rr + k, 0, sizeof(lo_fr) * (n - k)); lo_encode(c, rr); gather(rg, rr, si, t);
+                lo_eltwise(LO_OP_FMA, s, rg, vl, t, NULL, 0);
+            }
+            if (has_code_check(kd)) {
+                lo_fr rc; lo_rng_next(&code_rng, &rc);
+                lo_eltwise(LO_OP_FMA_CONST, s, NULL, vc, t, &rc, 0);
+            }
+            if (kd == 3 || kd == RK_BQZ || kd == RK_BIT) {
                 lo_fr rq; lo_rng_next(&quad_rng, &rq);
-                lo_eltwise(LO_OP_MUL, s - 2 * (size_t)t, s - t, t1, t, NULL, 0);
+                const lo_fr *sx = kd == RK_BIT ? s : s - 2 * (size_t)t, *sy = kd == RK_BIT ? s : s - t;
+                lo_eltwise(LO_OP_MUL, sx, sy, t1, t, NULL, 0);
                 lo_eltwise(LO_OP_SUB, t1, s, t2, t, NULL, 0);
+                lo_eltwise(LO_OP_FMA_CONST, t2, NULL, vq, t, &rq, 0);
+            } else if (kd == RK_EQY) {
+                lo_fr rq; lo_rng_next(&quad_rng, &rq);
+                lo_eltwise(LO_OP_SUB, s - t, s, t2, t, NULL, 0);
                 lo_eltwise(LO_OP_FMA_CONST, t2, NULL, vq, t, &rq, 0);
             }
         }

@@ -26,7 +26,8 @@ class Job(C.Structure):
     _fields_ = [("l", C.c_uint32), ("k", C.c_uint32), ("n", C.c_uint32), ("t", C.c_uint32),
                 ("n_linear", C.c_uint64), ("n_quad", C.c_uint64),
                 ("encoding_seed", C.c_uint8 * 32), ("witness_key", C.c_uint8 * 32),
-                ("generated_at", C.c_int64), ("threads", C.c_int)]
+                ("generated_at", C.c_int64), ("threads", C.c_int),
+                ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64)]
 
 
 class Proof(C.Structure):
