@@ -5,7 +5,9 @@
 // 32 keystream bytes as 4 little-endian u64 -> >>2 -> subtract p if >= p).  The reference draws these one at
 // a time on the host (k-l pads per row, one per constraint in stage 2); on the GPU element e of a stream is
 // computed independently from keystream blocks 2e and 2e+1, so a whole batch of rows is one launch.
-// T-table AES with the tables staged in LDS (1 KiB Te0 + 256 B S-box per workgroup).
+// T-table AES with the four rotated tables staged in LDS (4 KiB per workgroup): the sampler runs next to the VALU-bound
+// encode kernels, so it is written for the fewest VALU instructions -- no rotates (v_alignbit is a half-rate
+// instruction on gfx950), three-input xors (v_bitop3_b32), and the last round masks S-box bytes out of the same tables.
 #include "kernels.hpp"
 
 namespace lig {
@@ -56,40 +58,40 @@ void aes256_expand_host(const uint8_t key[32], uint32_t rk[60]) {
     }
 }
 
-__device__ uint32_t g_te0[256];
-__device__ uint32_t g_sbox[256];
+__device__ uint32_t g_te[4 * 256];     // Te0 | Te1 = ror(Te0, 8) | Te2 = ror(Te0, 16) | Te3 = ror(Te0, 24)
 
-__device__ __forceinline__ uint32_t ror32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+__device__ __forceinline__ uint32_t x3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
-__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const uint32_t* te0, const uint32_t* sb,
-                                             uint64_t block_index, uint32_t out[4]) {
+// te = the four tables back to back (LDS).  Te0[x] = (2s, s, s, 3s) from the most significant byte down, so the plain
+// S-box byte sits in bits 24-31 of Te2, 16-23 of Te3, 8-15 of Te0 and 0-7 of Te1: the last round needs no S-box table.
+__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const uint32_t* te, uint64_t block_index, uint32_t out[4]) {
+    const uint32_t *t0 = te, *t1 = te + 256, *t2 = te + 512, *t3 = te + 768;
     uint32_t s0 = rk[0], s1 = rk[1], s2 = (uint32_t)(block_index >> 32) ^ rk[2], s3 = (uint32_t)block_index ^ rk[3];
 #pragma unroll
     for (int r = 1; r < 14; r++) {
-        const uint32_t t0 = te0[s0 >> 24] ^ ror32(te0[(s1 >> 16) & 255], 8) ^ ror32(te0[(s2 >> 8) & 255], 16) ^ ror32(te0[s3 & 255], 24) ^ rk[4 * r];
-        const uint32_t t1 = te0[s1 >> 24] ^ ror32(te0[(s2 >> 16) & 255], 8) ^ ror32(te0[(s3 >> 8) & 255], 16) ^ ror32(te0[s0 & 255], 24) ^ rk[4 * r + 1];
-        const uint32_t t2 = te0[s2 >> 24] ^ ror32(te0[(s3 >> 16) & 255], 8) ^ ror32(te0[(s0 >> 8) & 255], 16) ^ ror32(te0[s1 & 255], 24) ^ rk[4 * r + 2];
-        const uint32_t t3 = te0[s3 >> 24] ^ ror32(te0[(s0 >> 16) & 255], 8) ^ ror32(te0[(s1 >> 8) & 255], 16) ^ ror32(te0[s2 & 255], 24) ^ rk[4 * r + 3];
-        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+        const uint32_t a0 = x3(t0[s0 >> 24], t1[(s1 >> 16) & 255], t2[(s2 >> 8) & 255]), a1 = x3(t0[s1 >> 24], t1[(s2 >> 16) & 255], t2[(s3 >> 8) & 255]);
+        const uint32_t a2 = x3(t0[s2 >> 24], t1[(s3 >> 16) & 255], t2[(s0 >> 8) & 255]), a3 = x3(t0[s3 >> 24], t1[(s0 >> 16) & 255], t2[(s1 >> 8) & 255]);
+        const uint32_t b0 = x3(a0, t3[s3 & 255], rk[4 * r]), b1 = x3(a1, t3[s0 & 255], rk[4 * r + 1]);
+        const uint32_t b2 = x3(a2, t3[s1 & 255], rk[4 * r + 2]), b3 = x3(a3, t3[s2 & 255], rk[4 * r + 3]);
+        s0 = b0; s1 = b1; s2 = b2; s3 = b3;
     }
-    out[0] = ((sb[s0 >> 24] << 24) | (sb[(s1 >> 16) & 255] << 16) | (sb[(s2 >> 8) & 255] << 8) | sb[s3 & 255]) ^ rk[56];
-    out[1] = ((sb[s1 >> 24] << 24) | (sb[(s2 >> 16) & 255] << 16) | (sb[(s3 >> 8) & 255] << 8) | sb[s0 & 255]) ^ rk[57];
-    out[2] = ((sb[s2 >> 24] << 24) | (sb[(s3 >> 16) & 255] << 16) | (sb[(s0 >> 8) & 255] << 8) | sb[s1 & 255]) ^ rk[58];
-    out[3] = ((sb[s3 >> 24] << 24) | (sb[(s0 >> 16) & 255] << 16) | (sb[(s1 >> 8) & 255] << 8) | sb[s2 & 255]) ^ rk[59];
+    out[0] = x3(t2[s0 >> 24] & 0xff000000u, t3[(s1 >> 16) & 255] & 0x00ff0000u, t0[(s2 >> 8) & 255] & 0x0000ff00u) ^ (t1[s3 & 255] & 0xffu) ^ rk[56];
+    out[1] = x3(t2[s1 >> 24] & 0xff000000u, t3[(s2 >> 16) & 255] & 0x00ff0000u, t0[(s3 >> 8) & 255] & 0x0000ff00u) ^ (t1[s0 & 255] & 0xffu) ^ rk[57];
+    out[2] = x3(t2[s2 >> 24] & 0xff000000u, t3[(s3 >> 16) & 255] & 0x00ff0000u, t0[(s0 >> 8) & 255] & 0x0000ff00u) ^ (t1[s1 & 255] & 0xffu) ^ rk[58];
+    out[3] = x3(t2[s3 >> 24] & 0xff000000u, t3[(s0 >> 16) & 255] & 0x00ff0000u, t0[(s1 >> 8) & 255] & 0x0000ff00u) ^ (t1[s2 & 255] & 0xffu) ^ rk[59];
 }
 
 __global__ void k_rng_fill(const uint32_t* __restrict__ rk_g, uint64_t first_elem, fr* __restrict__ out, size_t count) {
-    __shared__ uint32_t te0[256];
-    __shared__ uint32_t sb[256];
+    __shared__ uint32_t te[4 * 256];
     __shared__ uint32_t rk[60];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) { te0[i] = g_te0[i]; sb[i] = g_sbox[i]; }
+    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) te[i] = g_te[i];
     if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
     __syncthreads();
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
         const uint64_t blk = 2 * (first_elem + e);
         uint32_t o[8];
-        aes256_block(rk, te0, sb, blk, o);
-        aes256_block(rk, te0, sb, blk + 1, o + 4);
+        aes256_block(rk, te, blk, o);
+        aes256_block(rk, te, blk + 1, o + 4);
         fr v;
 #pragma unroll
         for (int i = 0; i < 8; i++) v.v[i] = __builtin_bswap32(o[i]);   // keystream bytes -> little-endian limbs
@@ -104,10 +106,9 @@ __global__ void k_rng_fill(const uint32_t* __restrict__ rk_g, uint64_t first_ele
 // batch, or the (0, r, 0, r, ...) pattern of a mask row (elem_stride = 2).
 __global__ void k_rng_fill_rows(const uint32_t* __restrict__ rk_g, uint64_t first, fr* __restrict__ out, size_t rows,
                                 uint32_t per_row, size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
-    __shared__ uint32_t te0[256];
-    __shared__ uint32_t sb[256];
+    __shared__ uint32_t te[4 * 256];
     __shared__ uint32_t rk[60];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) { te0[i] = g_te0[i]; sb[i] = g_sbox[i]; }
+    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) te[i] = g_te[i];
     if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
     __syncthreads();
     const size_t total = rows * per_row;
@@ -116,8 +117,8 @@ __global__ void k_rng_fill_rows(const uint32_t* __restrict__ rk_g, uint64_t firs
         const uint32_t i = (uint32_t)(e - r * per_row);
         const uint64_t blk = 2 * (first + r * stream_stride + i);
         uint32_t o[8];
-        aes256_block(rk, te0, sb, blk, o);
-        aes256_block(rk, te0, sb, blk + 1, o + 4);
+        aes256_block(rk, te, blk, o);
+        aes256_block(rk, te, blk + 1, o + 4);
         fr v;
 #pragma unroll
         for (int w = 0; w < 8; w++) v.v[w] = __builtin_bswap32(o[w]);
@@ -139,10 +140,10 @@ void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t firs
 // per-device table upload, called from lig_ctx_create
 void aes_upload_tables() {
     const AesTables& T = host_tables();
-    uint32_t sb32[256];
-    for (int i = 0; i < 256; i++) sb32[i] = T.sbox[i];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_te0), T.te0, sizeof(T.te0));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sbox), sb32, sizeof(sb32));
+    uint32_t te[4 * 256];
+    for (int t = 0; t < 4; t++)
+        for (int i = 0; i < 256; i++) te[256 * t + i] = t ? (T.te0[i] >> (8 * t)) | (T.te0[i] << (32 - 8 * t)) : T.te0[i];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_te), te, sizeof(te));
 }
 
 void launch_rng_fill(hipStream_t s, const uint32_t* rk60_dev, uint64_t first_elem, fr* out, size_t count) {

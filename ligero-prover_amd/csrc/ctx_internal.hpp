@@ -42,6 +42,7 @@ struct lig_ctx {
 
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on = nullptr);
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
+int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows);
 
 #define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; } while (0)
 #define HIP_TRY(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); return LIG_E_HIP; } } while (0)

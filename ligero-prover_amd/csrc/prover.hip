@@ -591,8 +591,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     }
     mark("encode message rows");
     TRY(lig_encode(c, mask));
-    TRY(lig_encode_2k(c, mlin));
-    TRY(lig_encode_2k(c, mquad));
+    TRY(lig_internal_encode_2k_rows(c, mlin, 2));          // mlin and mquad are adjacent rows: one pass of 31 launches
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
     lig::launch_sha_update_rows(s_sha, T->sha_state, n, mask, n, 3, absorbed);
@@ -952,8 +951,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
     if (Rl) TRY(lig_internal_encode_rows(c, S->msgs, S->cw, Rl, false));
     TRY(lig_encode(c, mask));
-    TRY(lig_encode_2k(c, mlin));
-    TRY(lig_encode_2k(c, mquad));
+    TRY(lig_internal_encode_2k_rows(c, mlin, 2));          // mlin and mquad are adjacent rows: one pass of 31 launches
     // column slices: block h of `send` = my rows restricted to rank h's columns
     for (uint32_t h = 0; h < W && Rl; h++)
         HIP_TRY(c, hipMemcpy2DAsync(S->send + (size_t)h * RM * ncol, ncol * 32, S->cw + (size_t)h * ncol, (size_t)n * 32, ncol * 32, Rl,
