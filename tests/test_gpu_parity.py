@@ -336,6 +336,8 @@ def test_rlc_and_gather_vs_oracle(ctx512):
 
 @pytest.mark.parametrize("l,k,n,n_linear,n_quad", [
     (320, 512, 2048, 700, 0), (320, 512, 2048, 640, 330), (320, 512, 2048, 100, 700), (320, 512, 2048, 1, 0),
+    (320, 512, 2048, 0, 0),              # empty statement: only the three mask rows are committed
+    (320, 512, 2048, 0, 321),            # quadratic constraints only (one full + one partial triple)
     (832, 1024, 4096, 2000, 900),        # k without a batched fast path: generic radix-2 kernels end to end
     (8000, 8192, 32768, 3 * 8000 + 123, 8000 + 5),
 ])

@@ -241,7 +241,7 @@ def test_seeds():
     assert s2.tobytes() == hashlib.sha256(b"LigetronStage2\0" + root + a.tobytes() + b.tobytes() + c.tobytes()).digest()
 
 
-@pytest.mark.parametrize("n_linear,n_quad", [(700, 0), (640, 330), (100, 700)])
+@pytest.mark.parametrize("n_linear,n_quad", [(700, 0), (640, 330), (100, 700), (0, 0), (0, 321)])
 def test_reference_structured_prover_and_verifier(n_linear, n_quad):
     """config-1 counterpart: a tiny row stream through the whole 3-stage flow; the restated verifier accepts."""
     import ctypes as C
