@@ -12,6 +12,10 @@
  * (:150-153) -- here the values are written as intended; vbn254fr_set_bytes reads every element from bytes + len * count
  * (:266) -- callers of set() pass the decoded elements.
  *
+ * Recording: with record(true) every guest operation is also appended to a lig_batch_op program (include/lig_hip.h) --
+ * the form in which the batched prover / verifier (lig_synth_prepare, lig_synth_verify) and the oracle take a batch
+ * computation: slots = handle / k, constants and values in the data blob.
+ *
  * Context concept: executor() -> hip_context&, on_batch_init(buffer&), on_batch_bit(buffer&), on_batch_equal(buffer&,
  * buffer&), on_batch_quadratic(buffer&, buffer&, buffer&).
  */
@@ -37,6 +41,11 @@ public:
     static constexpr size_t num_bits = 254;                      // Context::field_type::num_bits for BN254 Fr
 
     explicit hip_vbn254fr(Context* ctx) : ctx_(ctx), executor_(ctx->executor()) {}
+
+    // ---- program recording (no upstream counterpart: the reference re-runs the guest instead of keeping a program)
+    void record(bool on) { record_ = on; }
+    const std::vector<lig_batch_op>& recorded_ops() const { return ops_; }
+    const std::vector<uint8_t>& recorded_data() const { return data_; }
 
     // vbn254fr.hpp:54-78 (allocation is delayed until the first batch variable is requested)
     void initialize_buffer() {
@@ -66,6 +75,7 @@ public:
     }
     // vbn254fr_free / vbn254fr_deallocate (:123-127,:143-149): the buffer is cleared and goes to the BACK of the list
     void vbn254fr_free(handle_t h) {
+        log(LIG_BOP_FREE, 0, h, 0);
         executor_.clear_buffer(get_buffer_from_offset(h));
         free_list_.emplace_back(h);
     }
@@ -74,11 +84,14 @@ public:
     void vbn254fr_set_ui(handle_t fp, const uint32_t* ui, size_t len) {
         std::vector<bignum_t> vals(len);
         for (size_t i = 0; i < len; i++) vals[i] = bignum_t(ui[i]);
+        log_set(fp, vals);
         set_elements(fp, vals);
     }
     // vbn254fr_set_ui_scalar (:170-183): the same value in all l data slots
     void vbn254fr_set_ui_scalar(handle_t fp, uint32_t ui) {
-        set_elements(fp, std::vector<bignum_t>(num_buf_elements_, bignum_t(ui)));
+        const bignum_t v(ui);
+        if (record_) log(LIG_BOP_SET_SCALAR, 0, fp, 0, 0, blob(v.limbs, 32));
+        set_elements(fp, std::vector<bignum_t>(num_buf_elements_, v));
     }
     // vbn254fr_set_str / _set_bytes (:185-275) after parsing: one canonical element per slot (write_limbs + on_batch_init)
     void vbn254fr_set(handle_t fp, const std::vector<hip::scalar>& elems) {
@@ -86,13 +99,18 @@ public:
         std::vector<bignum_t> vals;
         vals.reserve(elems.size());
         for (const auto& e : elems) vals.emplace_back(e);
+        log_set(fp, vals);
         set_elements(fp, vals);
     }
     // vbn254fr_set_str_scalar / _set_bytes_scalar (:219-243,:277-296)
-    void vbn254fr_set_scalar(handle_t fp, const hip::scalar& e) { set_elements(fp, std::vector<bignum_t>(num_buf_elements_, bignum_t(e))); }
+    void vbn254fr_set_scalar(handle_t fp, const hip::scalar& e) {
+        if (record_) log(LIG_BOP_SET_SCALAR, 0, fp, 0, 0, blob(e.data(), 32));
+        set_elements(fp, std::vector<bignum_t>(num_buf_elements_, bignum_t(e)));
+    }
 
     // vbn254fr_copy (:298-317)
     void vbn254fr_copy(handle_t out_h, handle_t in_h) {
+        log(LIG_BOP_COPY, out_h, in_h, 0);
         buffer_t in = get_buffer_from_offset(in_h), out = get_buffer_from_offset(out_h);
         if (in == out) {
             executor_.copy_buffer_to_buffer(in, tmp_buf_);
@@ -107,42 +125,51 @@ public:
 
     // ---- arithmetic (:353-560).  Every op computes into the temporary and copies to `out`, so out may alias x or y.
     void vbn254fr_addmod(handle_t out, handle_t x, handle_t y) {
+        log(LIG_BOP_ADD, out, x, y);
         executor_.EltwiseAddMod(bind_compute3_, {.x = x, .y = y});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     void vbn254fr_addmod_constant(handle_t out, handle_t x, const hip::scalar& k) {
+        log_const(LIG_BOP_ADD_CONST, out, x, k);
         executor_.EltwiseAddMod(bind_compute2_, k, {.x = x});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     void vbn254fr_submod(handle_t out, handle_t x, handle_t y) {
+        log(LIG_BOP_SUB, out, x, y);
         executor_.EltwiseSubMod(bind_compute3_, {.x = x, .y = y});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     void vbn254fr_submod_constant(handle_t out, handle_t x, const hip::scalar& k) {
+        log_const(LIG_BOP_SUB_CONST, out, x, k);
         executor_.EltwiseSubConstMod(bind_compute2_, k, {.x = x});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     void vbn254fr_constant_submod(handle_t out, const hip::scalar& k, handle_t x) {
+        log_const(LIG_BOP_CONST_SUB, out, x, k);
         executor_.EltwiseConstSubMod(bind_compute2_, k, {.x = x});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     // vbn254fr_mulmod (:446-470): z = x * y is a quadratic row triple (x, y, z) raised BEFORE the copy to out
     void vbn254fr_mulmod(handle_t out, handle_t x, handle_t y) {
+        log(LIG_BOP_MUL, out, x, y);
         buffer_t bx = get_buffer_from_offset(x), by = get_buffer_from_offset(y);
         executor_.EltwiseMultMod(bind_compute3_, {.x = x, .y = y});
         ctx_->on_batch_quadratic(bx, by, tmp_buf_);
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     void vbn254fr_mulmod_constant(handle_t out, handle_t x, const hip::scalar& k) {
+        log_const(LIG_BOP_MUL_CONST, out, x, k);
         executor_.EltwiseMultMod(bind_compute2_, k, {.x = x});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     void vbn254fr_mont_mul_constant(handle_t out, handle_t x, const hip::scalar& k) {
+        log_const(LIG_BOP_MONTMUL_CONST, out, x, k);
         executor_.EltwiseMontMultMod(bind_compute2_, k, {.x = x});
         executor_.copy_buffer_to_buffer(tmp_buf_, get_buffer_from_offset(out));
     }
     // vbn254fr_divmod (:507-525): q = x / y is constrained as q * y = x, i.e. the triple (q, y, x)
     void vbn254fr_divmod(handle_t out, handle_t x, handle_t y) {
+        log(LIG_BOP_DIV, out, x, y);
         buffer_t bx = get_buffer_from_offset(x), by = get_buffer_from_offset(y);
         executor_.EltwiseDivMod(bind_compute3_, {.x = x, .y = y});
         ctx_->on_batch_quadratic(tmp_buf_, by, bx);
@@ -150,11 +177,17 @@ public:
     }
     // vbn254fr_assert_equal (:527-547)
     void vbn254fr_assert_equal(handle_t x, handle_t y) {
+        log(LIG_BOP_ASSERT_EQUAL, 0, x, y);
         buffer_t bx = get_buffer_from_offset(x), by = get_buffer_from_offset(y);
         ctx_->on_batch_equal(bx, by);
     }
     // vbn254fr_bit_decompose (:549-565): bit i of every element of x into out[i], each a committed "bit" row
     void vbn254fr_bit_decompose(const handle_t* out, handle_t x) {
+        if (record_) {
+            std::vector<uint32_t> slots(num_bits);
+            for (uint32_t i = 0; i < num_bits; i++) slots[i] = slot(out[i]);
+            log(LIG_BOP_BIT_DECOMPOSE, 0, x, 0, (uint32_t)num_bits, blob(slots.data(), 4 * slots.size()));
+        }
         for (uint32_t i = 0; i < num_bits; i++) {
             buffer_t bit = get_buffer_from_offset(out[i]);
             executor_.EltwiseBitDecompose(bind_compute2_, i, {.x = x});
@@ -172,6 +205,19 @@ private:
         executor_.write_buffer_clear(x, vals.data(), vals.size());
         ctx_->on_batch_init(x);
     }
+    void log_set(handle_t fp, const std::vector<bignum_t>& vals) {
+        if (record_) log(LIG_BOP_SET, 0, fp, 0, (uint32_t)vals.size(), blob(vals.data(), 32 * vals.size()));
+    }
+    uint32_t slot(handle_t h) const { return (uint32_t)(h / executor_.padding_size()); }
+    uint64_t blob(const void* p, size_t n) {
+        const uint64_t off = data_.size();
+        data_.insert(data_.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n);
+        return off;
+    }
+    void log(uint32_t op, handle_t out, handle_t x, handle_t y, uint32_t len = 0, uint64_t off = 0) {
+        if (record_) ops_.push_back(lig_batch_op{op, slot(out), slot(x), slot(y), len, 0, off});
+    }
+    void log_const(uint32_t op, handle_t out, handle_t x, const hip::scalar& k) { if (record_) log(op, out, x, 0, 0, blob(k.data(), 32)); }
 
     Context* ctx_;
     executor_t& executor_;
@@ -180,6 +226,9 @@ private:
     std::deque<size_t> free_list_;
     buffer_t buffer_base_, tmp_buf_;
     hip::buffer_binding bind_compute2_, bind_compute3_;
+    bool record_ = false;
+    std::vector<lig_batch_op> ops_;
+    std::vector<uint8_t> data_;
 };
 
 }  // namespace ligero

@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
     executor.ntt_init(l, k, n, 0, 0, 0, 0, 0);
     recording_context ctx(executor, f);
     ligero::hip_vbn254fr<recording_context> v(&ctx);
+    v.record(argc > 2);
     using H = ligero::hip_vbn254fr<recording_context>::handle_t;
 
     const H a = v.vbn254fr_alloc(), b = v.vbn254fr_alloc(), c = v.vbn254fr_alloc(), d = v.vbn254fr_alloc(), e = v.vbn254fr_alloc();
@@ -86,7 +87,8 @@ int main(int argc, char** argv) {
     big[2] = scalar_of(0, 0);
     v.vbn254fr_set(c, big);                                        // I
     v.vbn254fr_set_scalar(d, K);                                   // I
-    v.vbn254fr_divmod(c, d, c);                                    // Q: division by zero slots -> 0
+    v.vbn254fr_addmod(c, c, d);                                    // no zero denominators: q * y = x must hold to be provable
+    v.vbn254fr_divmod(c, d, c);                                    // Q (d/c, c, d), out aliasing y
     v.vbn254fr_free(a);                                            // cleared, goes to the BACK of the FIFO free list
     const H g = v.vbn254fr_alloc();                                // -> the 6th slot, not a's
     std::printf("realloc %u free %zu\n", g, v.free_variables());
@@ -95,6 +97,16 @@ int main(int argc, char** argv) {
     v.vbn254fr_bit_decompose(bits.data(), d);                      // 254 x B
     v.finalize();
     std::fclose(f);
+    if (argc > 2) {                                                // the recorded lig_batch_op program: n_ops, ops, n_bytes, data
+        FILE* g = std::fopen(argv[2], "wb");
+        if (!g) return 4;
+        const uint64_t n_ops = v.recorded_ops().size(), n_bytes = v.recorded_data().size();
+        std::fwrite(&n_ops, 8, 1, g);
+        std::fwrite(v.recorded_ops().data(), sizeof(lig_batch_op), n_ops, g);
+        std::fwrite(&n_bytes, 8, 1, g);
+        std::fwrite(v.recorded_data().data(), 1, n_bytes, g);
+        std::fclose(g);
+    }
     std::printf("inits %llu\n", (unsigned long long)ctx.inits);
     return 0;
 }

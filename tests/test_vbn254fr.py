@@ -73,6 +73,7 @@ def replay():
     z = [x * x % P for x in e]; m.quad(e, e, z); e = z
     c = m.init([(0xffffffffffffffff | (0x1fffffffffffffff << 128)) % P, 1, 0])
     d = m.init([Kc] * L_)
+    c = [(x + y) % P for x, y in zip(c, d)]
     q = [x * inv(y) % P if y else 0 for x, y in zip(d, c)]; m.quad(q, c, d); c = q
     for i in range(254):
         m.bit([(x >> i) & 1 for x in d])
@@ -99,3 +100,47 @@ def test_vbn254fr_program_rows_match_integer_replay(tmp_path):
             pos += K_ * 32
             assert ol.from_limbs(got) == row, "record %d (%s) row %d" % (i, kind, r)
     assert pos == len(raw)
+
+
+@pytest.mark.gpu
+def test_recorded_program_proves_like_the_oracle(tmp_path):
+    """the operations hip_vbn254fr records while it runs are a lig_batch_op program; proving it (HIP) gives the envelope the
+    oracle gives for the same program, valid, and the committed batch rows are the rows the hooks saw (data slots)"""
+    import ctypes as C
+
+    import batch_prog
+    exe = build_exe()
+    log, prog_path = tmp_path / "rows.bin", tmp_path / "prog.bin"
+    subprocess.check_output([exe, str(log), str(prog_path)])
+    raw = prog_path.read_bytes()
+    n_ops = int.from_bytes(raw[:8], "little")
+    ops_b = raw[8:8 + 32 * n_ops]
+    n_bytes = int.from_bytes(raw[8 + 32 * n_ops:16 + 32 * n_ops], "little")
+    data_b = raw[16 + 32 * n_ops:16 + 32 * n_ops + n_bytes]
+    assert n_ops == 21 and len(data_b) == n_bytes
+
+    def attach(job):
+        ops = (batch_prog.BatchOp * n_ops).from_buffer_copy(ops_b)
+        data = (C.c_uint8 * n_bytes).from_buffer_copy(data_b)
+        job.batch_ops, job.n_batch_ops = C.cast(ops, C.c_void_p), n_ops
+        job.batch_data, job.batch_data_bytes = C.cast(data, C.c_void_p), n_bytes
+        job._keep = (ops, data)
+        return job
+
+    amd = hip_lib.load()
+    ojob = attach(ol.make_job(L_, K_, 2048, 192, 500, 0, generated_at=9, threads=4))
+    pr = ol.Proof()
+    assert ol.lib().lo_prove(C.byref(ojob), C.byref(pr)) == 0
+    c = amd.Context(L_, K_, 2048)
+    try:
+        job = attach(amd.Context.make_job(500, 0, generated_at=9))
+        tr = c.synth_prepare_job(job)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert (pr.valid_code, pr.valid_linear, pr.valid_quad) == (1, 1, 1)
+        assert proof == bytes(pr.proof[:pr.proof_len])
+        assert c.synth_verify(job, bytes(info.const_sum), proof).accept == 1
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
+        c.close()
