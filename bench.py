@@ -126,8 +126,10 @@ class FullWorkload:
         return (2 * self.rows + 1) * self.inflight        # message rows + randomness rows (+ code mask on the fast path)
 
     def describe(self):
-        d = {"workload": "configs[2]: 2^%d-constraint trace, full proof (encode + column SHA-256 + Merkle + RLC checks + "
-                         "sampling + envelope), witness matrix resident in HBM" % (self.constraints_per_trace.bit_length() - 1),
+        lg = self.constraints_per_trace.bit_length() - 1
+        d = {"workload": "%s2^%d-constraint trace, full proof (encode + column SHA-256 + Merkle + RLC checks + "
+                         "sampling + envelope), witness matrix resident in HBM"
+                         % ("configs[2]: " if lg == 24 else "configs[3] trace on one GPU: " if lg == 26 else "", lg),
              "rows": self.rows + 3, "l": L_, "k": K_, "n": N_, "sample_size": T_, "proofs_in_flight": self.inflight}
         if self.last:
             proof = C.string_at(self.last[0], self.last[1])               # after the timed region

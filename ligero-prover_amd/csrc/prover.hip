@@ -410,19 +410,27 @@ extern "C" {
 
 // plan_rows: commit order of witness_manager (witness_manager.hpp:497-503): full linear rows, full quadratic
 // triples, partial linear row, partial quadratic triple
+static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T);
 int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
     CHECK_CTX(c);
     if (!job || !out) return LIG_E_ARG;
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
-    if (l >= k || l < 2 || t > n) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l < k and 192 <= n");
+    *out = nullptr;
     lig_trace* T = new lig_trace();
     T->c = c; T->job = *job;
-    if (!plan_rows(*job, l, T->rows, T->n_init)) { delete T; FAIL(c, LIG_E_ARG, "malformed batch program"); }
+    T->job.batch_ops = nullptr; T->job.batch_data = nullptr;       // the program is consumed here; the caller's memory is not kept
+    const int rc = synth_prepare_impl(c, job, T);
+    if (rc != LIG_OK) { lig_trace_destroy(T); return rc; }         // nothing is handed out on failure
+    *out = T;
+    return LIG_OK;
+}
+static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T) {
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
+    if (l >= k || l < 2 || t > n) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l < k and 192 <= n");
+    if (!plan_rows(*job, l, T->rows, T->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
     const size_t R = T->R = T->rows.size();
     T->triples = quad_terms(T->rows);
     for (T->RB = 0; T->RB < R && T->rows[T->RB].kind >= RK_INIT; T->RB++) {}
     const size_t chunk = lig_trace::CHUNK, groups = (chunk + lig_trace::GROUP - 1) / lig_trace::GROUP;
-    *out = T;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
     TRY(dm((void**)&T->cw, (R + 3) * (size_t)n * 32));
@@ -809,14 +817,23 @@ struct lig_shard {
     size_t h_proof_cap = 0;
 };
 
+static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S);
 int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, const lig_comm* comm, lig_shard** out) {
     CHECK_CTX(c);
     if (!job || !out || !comm || world == 0 || rank >= world) return LIG_E_ARG;
+    *out = nullptr;
+    lig_shard* S = new lig_shard();
+    S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world;
+    S->job.batch_ops = nullptr; S->job.batch_data = nullptr;
+    const int rc = shard_prepare_impl(c, job, rank, world, S);
+    if (rc != LIG_OK) { lig_shard_destroy(S); return rc; }
+    *out = S;
+    return LIG_OK;
+}
+static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S) {
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     if (l >= k || l < 2 || t > n || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l < k, 192 <= n and world | n");
-    lig_shard* S = new lig_shard();
-    *out = S;
-    S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world; S->ncol = n / world;
+    S->ncol = n / world;
     if (job->n_batch_ops) FAIL(c, LIG_E_ARG, "batch rows are not supported by the sharded prover");
     const size_t lf = job->n_linear / l, lp = job->n_linear % l, qf = job->n_quad / l, qp = job->n_quad % l;
     for (size_t i = 0; i < lf; i++) S->rows.push_back({0, l});
