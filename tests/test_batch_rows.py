@@ -168,3 +168,47 @@ def test_hip_false_equality_fails_quadratic_test_and_bad_program_is_rejected(amd
     finally:
         ol.lib().lo_proof_free(C.byref(pr))
         c.close()
+
+
+# ------------------------------------------------------------------------------------------------ whole-proof regression pins
+import json                                         # noqa: E402
+import os                                           # noqa: E402
+
+PINS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_pins.json")))["jobs"]
+
+
+def _pin_id(p):
+    return "l%d_k%d_lin%d_quad%d_%s" % (p["l"], p["k"], p["n_linear"], p["n_quad"], p["batch"] or "nobatch")
+
+
+@pytest.mark.parametrize("pin", PINS, ids=_pin_id)
+def test_oracle_matches_whole_proof_pins(pin):
+    """tests/golden/proof_pins.json (made by tests/golden/make_proof_pins.py from this oracle): drift detector"""
+    j = ol.make_job(pin["l"], pin["k"], pin["n"], 192, pin["n_linear"], pin["n_quad"], generated_at=pin["generated_at"], threads=2)
+    if pin["batch"]:
+        demo_program(with_bits=pin["batch"] == "demo").attach(j)
+    pr = ol.Proof()
+    assert ol.lib().lo_prove(C.byref(j), C.byref(pr)) == 0
+    try:
+        assert hashlib.sha256(bytes(pr.proof[:pr.proof_len])).hexdigest() == pin["proof_sha256"]
+        assert bytes(pr.root).hex() == pin["root"] and bytes(pr.const_sum).hex() == pin["const_sum"]
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pin", PINS, ids=_pin_id)
+def test_hip_matches_whole_proof_pins(amd, pin):
+    c = amd.Context(pin["l"], pin["k"], pin["n"])
+    try:
+        job = amd.Context.make_job(pin["n_linear"], pin["n_quad"], generated_at=pin["generated_at"])
+        if pin["batch"]:
+            demo_program(with_bits=pin["batch"] == "demo").attach(job)
+        tr = c.synth_prepare_job(job)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        assert hashlib.sha256(proof).hexdigest() == pin["proof_sha256"] and len(proof) == pin["proof_len"]
+        assert bytes(info.root).hex() == pin["root"] and bytes(info.stage2_seed).hex() == pin["stage2_seed"]
+        assert [info.valid_code, info.valid_linear, info.valid_quad] == pin["valid"]
+    finally:
+        c.close()
