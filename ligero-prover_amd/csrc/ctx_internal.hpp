@@ -44,7 +44,9 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
 int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows);
 
-#define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; } while (0)
+// every entry point may be called from any host thread (bench.py proves from worker threads): the context's device is made
+// current for the calling thread first -- HIP streams and allocations are only usable with their own device current
+#define CHECK_CTX(c) do { if (!(c)) return LIG_E_ARG; if (hipSetDevice((c)->device) != hipSuccess) { (c)->err = "hipSetDevice failed"; return LIG_E_HIP; } } while (0)
 #define HIP_TRY(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); return LIG_E_HIP; } } while (0)
 #define FAIL(c, code, msg) do { (c)->err = (msg); return (code); } while (0)
 

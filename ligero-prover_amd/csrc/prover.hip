@@ -497,6 +497,7 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
 
 void lig_trace_destroy(lig_trace* T) {
     if (!T) return;
+    (void)hipSetDevice(T->c->device);
     (void)hipStreamSynchronize(T->c->stream);
     T->c->sha.erase(T->sha_state);
     for (void* p : {(void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
@@ -514,6 +515,7 @@ uint64_t lig_trace_rows(const lig_trace* T) { return T ? T->R + 3 : 0; }
 int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
     if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = T->c;
+    CHECK_CTX(c);
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l;
     const size_t R = T->R;
     hipStream_t s = c->stream;
@@ -919,6 +921,7 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
 
 void lig_shard_destroy(lig_shard* S) {
     if (!S) return;
+    (void)hipSetDevice(S->c->device);
     (void)hipStreamSynchronize(S->c->stream);
     S->c->sha.erase(S->sha_state);
     for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
@@ -932,6 +935,7 @@ void lig_shard_destroy(lig_shard* S) {
 int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
     if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = S->c;
+    CHECK_CTX(c);
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l, W = S->world;
     const size_t R = S->R, Rl = S->Rl, r0 = S->r0, RM = S->rows_max, ncol = S->ncol;
     hipStream_t s = c->stream;
