@@ -189,6 +189,15 @@ typedef struct {
 int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t const_sum[32], const uint8_t *proof, size_t proof_len,
                      lig_verify_info *out);
 
+/* ==== proof file framing (src/webgpu_prover.cpp:437-457 writes gzip(level 6) of the serialized envelope with
+ * Boost.iostreams; src/webgpu_verifier.cpp:249-253 reads it back).  Host-only helpers on zlib: the output is a standard
+ * gzip member that any gzip reader (the reference's gzip_decompressor included) accepts; compressed BYTES depend on the
+ * zlib version and on Boost's header fields, so bit-exactness is defined on the uncompressed envelope. ==== */
+size_t lig_proof_gzip_bound(size_t envelope_len);
+int    lig_proof_gzip(const uint8_t *envelope, size_t len, uint8_t *out, size_t cap, size_t *out_len);
+size_t lig_proof_gunzip_size(const uint8_t *gz, size_t len);           /* ISIZE trailer; 0 if not a gzip member */
+int    lig_proof_gunzip(const uint8_t *gz, size_t len, uint8_t *out, size_t cap, size_t *out_len);
+
 /* ==== one trace sharded over the GPUs of a node (configs[3]).  Rows are dealt to ranks in contiguous
  * blocks; the column hash is column-partitioned after ONE all-to-all of codeword column slices; leaves, partial
  * stage-2 sums (k + 2k + 2k values per rank, added mod p locally) and opened columns are all-gathered.  The collectives

@@ -29,6 +29,7 @@ EXPORTS = [
     "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
     "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
     "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify",
+    "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
 ]
 
 
@@ -118,6 +119,12 @@ def load_library():
     L.lig_trace_rows.restype = u64
     L.lig_trace_destroy.argtypes = [vp]
     L.lig_trace_destroy.restype = None
+    L.lig_proof_gzip_bound.restype = sz
+    L.lig_proof_gzip_bound.argtypes = [sz]
+    L.lig_proof_gzip.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
+    L.lig_proof_gunzip_size.restype = sz
+    L.lig_proof_gunzip_size.argtypes = [vp, sz]
+    L.lig_proof_gunzip.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
     L.lig_synth_verify.argtypes = [vp, C.POINTER(SynthJob), vp, vp, sz, C.POINTER(VerifyInfo)]
     L.lig_shard_prepare.argtypes = [vp, C.POINTER(SynthJob), u32, u32, C.POINTER(Comm), C.POINTER(vp)]
     L.lig_shard_prove.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]

@@ -51,3 +51,33 @@ def test_binding_fails_loudly_without_library(tmp_path, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("missing library must raise")
+
+
+def test_proof_file_gzip_framing_roundtrip_with_python_gzip():
+    """host-only helpers (no GPU): gzip(level 6) member of an envelope, as webgpu_prover.cpp:437-457 writes the proof file;
+    interoperable with any gzip implementation in both directions"""
+    import ctypes as C
+    import gzip
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    lib = mod.load_library()
+    env = bytes(range(256)) * 300 + b"\x0a\x10" + bytes(5000)
+    cap = lib.lig_proof_gzip_bound(len(env))
+    out = (C.c_uint8 * cap)()
+    n = C.c_size_t()
+    src = (C.c_uint8 * len(env)).from_buffer_copy(env)
+    assert lib.lig_proof_gzip(src, len(env), out, cap, C.byref(n)) == 0
+    gz = bytes(out[:n.value])
+    assert gz[:2] == b"\x1f\x8b" and gzip.decompress(gz) == env
+    assert lib.lig_proof_gunzip_size(out, n.value) == len(env)
+    # the other direction: a member written by another gzip
+    theirs = gzip.compress(env, compresslevel=6)
+    tsrc = (C.c_uint8 * len(theirs)).from_buffer_copy(theirs)
+    back = (C.c_uint8 * len(env))()
+    assert lib.lig_proof_gunzip(tsrc, len(theirs), back, len(env), C.byref(n)) == 0 and bytes(back[:n.value]) == env
+    # too small an output buffer / not gzip
+    small = (C.c_uint8 * 10)()
+    assert lib.lig_proof_gunzip(tsrc, len(theirs), small, 10, C.byref(n)) != 0
+    assert lib.lig_proof_gunzip(src, len(env), back, len(env), C.byref(n)) != 0
+    assert lib.lig_proof_gunzip_size(src, len(env)) == 0
