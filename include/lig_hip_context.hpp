@@ -156,6 +156,19 @@ public:
     hip::buffer_binding bind_sha256_buffer(buffer_type in) { return {{in}}; }
     hip::buffer_binding bind_sampling(buffer_type from, buffer_type to) { return {{from, to}}; }
 
+    hip::buffer_binding bind_scalar(buffer_type s) { return {{s}}; }
+    hip::buffer_binding bind_powmod(buffer_type exp, buffer_type coeff, buffer_type out) { return {{exp, coeff, out}}; }
+
+    // ---- powmod (wgpu.hpp:84-85,104-107; src/webgpu/engine.cpp:214-223,674-680; powmod_context.cpp:178-268).  Exponents
+    // are one u32 per element; the per-base table of squarings is rebuilt by set_base inside the library.
+    void powmod_init(size_t num_exponent_bits = 32) {
+        if (num_exponent_bits == 0 || num_exponent_bits > 32) throw std::invalid_argument("powmod_init: 1..32 exponent bits");
+        powmod_bits_ = num_exponent_bits;
+    }
+    void powmod_set_base(const hip::scalar& base) { need_powmod(); powmod_base_ = base; powmod_has_base_ = true; }
+    void EltwisePowMod(const hip::buffer_binding& b) { pow(b, 0); }        // out = coeff * base^exp
+    void EltwisePowAddMod(const hip::buffer_binding& b) { pow(b, 1); }     // out += coeff * base^exp
+
     // ---- transforms (wgpu.hpp:98-110)
     void encode_ntt_device(const hip::buffer_binding& b) { hip::check(ctx_, lig_encode(ctx_, b.bufs[0].data()), "encode_ntt_device"); }
     void decode_ntt_device(const hip::buffer_binding& b) { hip::check(ctx_, lig_decode(ctx_, b.bufs[0].data()), "decode_ntt_device"); }
@@ -185,6 +198,7 @@ public:
     }
 #ifdef LIG_HAVE_GMP
     static hip::scalar to_scalar(const mpz_class& v) { return hip::device_bignum(v).to_scalar(); }
+    void powmod_set_base(const mpz_class& base, const mpz_class& /*p: fixed BN254 modulus*/) { powmod_set_base(to_scalar(base)); }
     void EltwiseAddMod(const hip::buffer_binding& b, const mpz_class& c, hip::eltwise_offset o = {}) { EltwiseAddMod(b, to_scalar(c), o); }
     void EltwiseSubConstMod(const hip::buffer_binding& b, const mpz_class& c, hip::eltwise_offset o = {}) { EltwiseSubConstMod(b, to_scalar(c), o); }
     void EltwiseConstSubMod(const hip::buffer_binding& b, const mpz_class& c, hip::eltwise_offset o = {}) { EltwiseConstSubMod(b, to_scalar(c), o); }
@@ -211,6 +225,18 @@ public:
     }
 
 private:
+    void need_powmod() const {       // the reference throws std::logic_error when powmod is used before powmod_init (engine.cpp:1505-1512)
+        if (!powmod_bits_) throw std::logic_error("powmod context is not initialised: call powmod_init first");
+    }
+    void pow(const hip::buffer_binding& b, int add) {
+        need_powmod();
+        if (!powmod_has_base_) throw std::logic_error("powmod: call powmod_set_base first");
+        const auto& exp = b.bufs[0]; const auto& coeff = b.bufs[1]; const auto& out = b.bufs[2];
+        size_t n = out.size() / 32;
+        if (coeff.size() / 32 < n) n = coeff.size() / 32;
+        if (exp.size() / 4 < n) n = exp.size() / 4;
+        hip::check(ctx_, lig_powmod(ctx_, powmod_base_.data(), exp.data(), coeff.data(), out.data(), n, add), "EltwisePowMod");
+    }
     static void* at(const buffer_type& b, size_t elem_off) { return static_cast<char*>(b.data()) + elem_off * 32; }
     // element offsets are WebGPU dynamic offsets (buffer_binding.hpp:27-29, engine.cpp eltwise dispatch): they move the bound
     // window of size() bytes inside the underlying allocation, they do not shrink it (vbn254fr binds variable 0 of its
@@ -235,6 +261,9 @@ private:
     lig_ctx* ctx_ = nullptr;
     int device_ = 0;
     size_t sha_instances_ = 0;
+    size_t powmod_bits_ = 0;
+    bool powmod_has_base_ = false;
+    hip::scalar powmod_base_{};
 };
 
 }  // namespace ligero

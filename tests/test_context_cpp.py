@@ -41,3 +41,34 @@ def test_hip_context_stage1_rows_match_oracle():
         msgs[r, :, 1] = (vals >> 32).astype(np.uint32)
     cws = ol.Ctx(320, k, n).encode_rows(msgs, threads=2)
     assert out == ol.colsha(cws).tobytes().hex()
+
+
+PSRC = os.path.join(ROOT, "tests", "cpp", "powmod_kat.cpp")
+PEXE = os.path.join(ROOT, "tests", "cpp", "powmod_kat")
+
+
+def build_powmod_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), PSRC,
+                           "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip",
+                           "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-o", PEXE])
+    return PEXE
+
+
+def test_hip_context_powmod_surface_compiles():
+    assert os.path.exists(build_powmod_exe())
+
+
+@pytest.mark.gpu
+def test_hip_context_powmod_like_reference_fixture():
+    """powmod_init / powmod_set_base / bind_powmod / EltwisePowMod / EltwisePowAddMod (wgpu.hpp:84-107) driven like
+    tests/webgpu/test_powmod.cpp's generator case"""
+    lines = subprocess.check_output([build_powmod_exe()]).decode().strip().splitlines()
+    assert lines[0] == "misuse_throws 1"
+    for ln in lines[1:]:
+        parts = ln.split()
+        i = int(parts[0])
+        got = int("".join(parts[1:]), 16)
+        assert got == 2 * pow(7, i, ol.P) % ol.P
