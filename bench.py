@@ -98,6 +98,8 @@ class FullWorkload:
         (addr, length), info = self.ctxs[i].synth_prove(self.traces[i], copy=False)     # proof bytes stay in the pinned buffer
         if not (info.valid_code and info.valid_linear and info.valid_quad):
             raise SystemExit("prover self-check failed")
+        if i == 0:
+            self.last_info = info
         return (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3, info.ms_total)
 
     def step(self):
@@ -136,6 +138,13 @@ class FullWorkload:
             d.update(proof_bytes=len(proof), proof_sha256=hashlib.sha256(proof).hexdigest(),
                      stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]},
                      proof_latency_ms=self.last[5])
+            # outside the timed region: the HIP verifier on that proof (informational)
+            pkg = sys.modules["ligero_prover_amd"]
+            job = pkg.Context.make_job(self.constraints_per_trace, 0, synth_seed=1, generated_at=0)
+            info = self.last_info
+            t0 = time.perf_counter()
+            v = self.ctx.synth_verify(job, bytes(info.const_sum), proof)
+            d.update(verifier_accepts=bool(v.accept), verify_ms=1e3 * (time.perf_counter() - t0))
         return d
 
     def close(self):
