@@ -270,7 +270,12 @@ def main():
 
     for _ in range(a.warmup):
         wl.step()
-    single_ms = wl.single_proof_ms() if hasattr(wl, "single_proof_ms") else None
+    single_ms, single_prof = None, None
+    if hasattr(wl, "single_proof_ms"):            # latency probe: one proof at a time, dominant kernel bracketed as well
+        ctx.profile_enable(True)
+        single_ms = wl.single_proof_ms()
+        single_prof = ctx.profile_read()
+        ctx.profile_enable(False)
     fence()
     ctx.profile_enable(True)
     t0 = time.perf_counter()
@@ -321,6 +326,10 @@ def main():
                          "avg_launch_ms": 1e3 * avg_launch_s, "rows_per_launch": rows_per_launch, "launches": launches,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
                          "encode_row_bytes_survey_8d": (K_ + N_) * 32,
+                         "one_proof_in_flight": None if not single_prof or not single_prof[0] else {
+                             "avg_launch_ms": single_prof[2] / single_prof[0], "rows_per_launch": single_prof[1] / single_prof[0],
+                             "achieved": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9,
+                             "frac": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9 / 8000.0},
                          "note": "integer-VALU-bound kernel (~150k 256-bit Montgomery products per row in this kernel, "
                                  "v_mad_u64_u32 issues at a quarter of the simple-ALU rate); the HBM fraction is small by "
                                  "construction, see DESIGN.md"},
