@@ -165,9 +165,9 @@ def test_encode_golden_k512(ctx512):
     assert c.download(nodes, (32,), dtype=np.uint8).tobytes().hex() == g["root"]
 
 
-@pytest.mark.parametrize("k", [512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("k", [512, 1024, 2048, 4096, 8192, 32768])
 def test_transforms_vs_oracle(amd, k):
-    """fast path (k = 512/2048/8192) and generic radix-2 path (1024/4096) against the oracle"""
+    """fast path (k = 512/2048/8192) and generic radix-2 path (1024/4096, and 32768: four times the production packing) against the oracle"""
     n, l = 4 * k, k - 192
     c = amd.Context(l, k, n)
     o = ol.Ctx(l, k, n)
