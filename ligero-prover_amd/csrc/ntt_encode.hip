@@ -153,14 +153,28 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
         for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
         __syncthreads();
         tile_step<LOG2B, S + 1>(x, tw, L, t);
+    } else if constexpr (LOG2B & 1) {
+        // B = 2 * 4^STEPS: the radix-4 steps have built the two half-size transforms; one radix-2 stage of span B joins
+        // them.  Thread t owns positions t + q*B/4 from here on (the exit ownership), i.e. the pairs (t, t + B/2) and
+        // (t + B/4, t + 3B/4) with twiddles W_B^t and W_B^(t + B/4).
+        constexpr uint32_t B = 1u << LOG2B, T = B / 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] = lds_get(L, t + q * T);
+        const f29 ta = f29_montmul(x[2], f29_load_tab(tw + (B / 2 - 1) + t));
+        const f29 tb = f29_montmul(x[3], f29_load_tab(tw + (B / 2 - 1) + t + T));
+        u = f29_add(x[0], ta); x[2] = f29_sub_k2(x[0], ta); x[0] = u;               // at-rest operands: + at most 2p
+        u = f29_add(x[1], tb); x[3] = f29_sub_k2(x[1], tb); x[1] = u;
     }
 }
 // Size-B DIT transform.  Entry: x[q] = input number brev(4t + q) (bit-reversed load), normalised, < 3p.
 // Exit: x[q] = output number t + q*B/4 (natural order, the coalesced ownership pattern), lazy:
-// limbs < 2.5*2^30 + 8, value < 14p + 4p*(STEPS-1) <= 30p.
+// limbs < 2.5*2^30 + 8, value < 14p + 4p*(STEPS-1) + 2p <= 30p.
 template <int LOG2B>
 __device__ __forceinline__ void tile_dft(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
-    static_assert(LOG2B % 2 == 0 && LOG2B >= 4, "tile length must be a power of 4, at least 16");
+    static_assert(LOG2B >= 4 && LOG2B <= 10, "tile length 16 .. 1024 (36 bytes of LDS per element, static LDS <= 64 KiB)");
     tile_step<LOG2B, 0>(x, tw, L, t);
 }
 
@@ -256,7 +270,7 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
     for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, v[q1]);
 }
 
-bool encode_fast_supported(uint32_t k) { return k == 512 || k == 2048 || k == 8192; }
+bool encode_fast_supported(uint32_t k) { return k == 512 || k == 1024 || k == 2048 || k == 4096 || k == 8192; }
 
 template <int LOG2B, bool FULL>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
@@ -280,6 +294,10 @@ void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* o
     switch (ep.log2B * 2 + (half ? 1 : 0)) {
         case 12: encode_rows_t<6, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
         case 13: encode_rows_t<6, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 14: encode_rows_t<7, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 15: encode_rows_t<7, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 18: encode_rows_t<9, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 19: encode_rows_t<9, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
         case 16: encode_rows_t<8, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
         case 17: encode_rows_t<8, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
         case 20: encode_rows_t<10, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;

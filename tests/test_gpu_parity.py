@@ -167,7 +167,8 @@ def test_encode_golden_k512(ctx512):
 
 @pytest.mark.parametrize("k", [512, 1024, 2048, 4096, 8192, 32768])
 def test_transforms_vs_oracle(amd, k):
-    """fast path (k = 512/2048/8192) and generic radix-2 path (1024/4096, and 32768: four times the production packing) against the oracle"""
+    """fast path (k = 512 ... 8192; tile lengths 64 ... 1024, odd log2 lengths take one extra radix-2 stage) and the generic
+    radix-2 path (k = 32768: four times the production packing) against the oracle"""
     n, l = 4 * k, k - 192
     c = amd.Context(l, k, n)
     o = ol.Ctx(l, k, n)
@@ -338,7 +339,8 @@ def test_rlc_and_gather_vs_oracle(ctx512):
     (320, 512, 2048, 700, 0), (320, 512, 2048, 640, 330), (320, 512, 2048, 100, 700), (320, 512, 2048, 1, 0),
     (320, 512, 2048, 0, 0),              # empty statement: only the three mask rows are committed
     (320, 512, 2048, 0, 321),            # quadratic constraints only (one full + one partial triple)
-    (832, 1024, 4096, 2000, 900),        # k without a batched fast path: generic radix-2 kernels end to end
+    (832, 1024, 4096, 2000, 900),        # tile length 128 = 2 * 4^3: fast path with the extra radix-2 stage
+    (16192, 16384, 65536, 20000, 16200), # k above the fast path (tile would not fit static LDS): generic radix-2 kernels end to end
     (8000, 8192, 32768, 3 * 8000 + 123, 8000 + 5),
 ])
 def test_batched_prover_equals_reference_structured_oracle(amd, l, k, n, n_linear, n_quad):
