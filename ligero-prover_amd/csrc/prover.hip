@@ -808,6 +808,8 @@ struct lig_shard {
     std::vector<RowDesc> rows;                 // global plan
     std::vector<size_t> bounds;                // world + 1 row boundaries
     std::vector<uint64_t> wit_pos, lin_pos;    // stream position of every global row (+1 entry)
+    std::vector<uint64_t> code_ord;            // number of code-test draws before every global row (+1 entry)
+    size_t RB = 0, n_init = 0;                 // leading rows committed by the batch program, of those: init rows
     size_t R = 0, r0 = 0, Rl = 0, rows_max = 0, ncol = 0;
     fr *msgs = nullptr, *cw = nullptr, *send = nullptr, *recv = nullptr, *randb = nullptr, *rhalf = nullptr, *acc = nullptr,
        *parts = nullptr, *accp = nullptr, *accg = nullptr, *dots = nullptr, *smp = nullptr, *smpg = nullptr;
@@ -836,33 +838,38 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     if (l >= k || l < 2 || t > n || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l < k, 192 <= n and world | n");
     S->ncol = n / world;
-    if (job->n_batch_ops) FAIL(c, LIG_E_ARG, "batch rows are not supported by the sharded prover");
-    const size_t lf = job->n_linear / l, lp = job->n_linear % l, qf = job->n_quad / l, qp = job->n_quad % l;
-    for (size_t i = 0; i < lf; i++) S->rows.push_back({0, l});
-    for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) S->rows.push_back({q, l});
-    if (lp) S->rows.push_back({0, (uint32_t)lp});
-    if (qp) for (uint8_t q = 1; q <= 3; q++) S->rows.push_back({q, (uint32_t)qp});
+    if (!plan_rows(*job, l, S->rows, S->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
     const size_t R = S->R = S->rows.size();
-    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0);
+    for (S->RB = 0; S->RB < R && S->rows[S->RB].kind >= RK_INIT; S->RB++) {}
+    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0);
     for (size_t r = 0; r < R; r++) {
-        S->wit_pos[r + 1] = S->wit_pos[r] + (S->rows[r].kind == 3 ? 0 : S->rows[r].data);   // z rows draw nothing
+        const uint8_t kd = S->rows[r].kind;
+        S->wit_pos[r + 1] = S->wit_pos[r] + ((kd == 3 || kd >= RK_INIT) ? 0 : S->rows[r].data);   // z rows and batch rows draw nothing
         S->lin_pos[r + 1] = S->lin_pos[r] + S->rows[r].data;
+        S->code_ord[r + 1] = S->code_ord[r] + has_code_check(kd);                                    // position in the code-test stream
     }
     S->bounds.assign(world + 1, R);
     S->bounds[0] = 0;
     for (uint32_t g = 1; g < world; g++) {
         size_t b = (size_t)(((unsigned __int128)R * g) / world);
-        while (b < R && (S->rows[b].kind == 2 || S->rows[b].kind == 3)) b++;      // never split a triple
+        auto inside_group = [&](uint8_t kd) { return kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ; };
+        while (b < R && inside_group(S->rows[b].kind)) b++;                       // never split a triple / an equality pair
         S->bounds[g] = std::max(b, S->bounds[g - 1]);
     }
     for (uint32_t g = 0; g < world; g++) S->rows_max = std::max(S->rows_max, S->bounds[g + 1] - S->bounds[g]);
     if (!S->rows_max) S->rows_max = 1;
     S->r0 = S->bounds[rank]; S->Rl = S->bounds[rank + 1] - S->bounds[rank];
     const size_t Rl = S->Rl, r0 = S->r0, RM = S->rows_max;
-    size_t ord = 0;
-    for (size_t r = 0; r < R; r++) if (S->rows[r].kind == 3) {
-        if (r >= r0 && r < r0 + Rl) { for (int q = 2; q >= 0; q--) S->triples.push_back((uint32_t)(r - q - r0)); S->triple_ord.push_back(ord); }
-        ord++;
+    {   // quadratic-test terms whose rows are local, with local row indices; triple_ord = position in the quadratic stream
+        const std::vector<uint32_t> all = quad_terms(S->rows);
+        for (size_t i = 0; i < all.size() / 3; i++) {
+            const size_t last = all[3 * i + 2];
+            if (last < r0 || last >= r0 + Rl) continue;
+            S->triples.push_back(all[3 * i] - (uint32_t)r0);
+            S->triples.push_back(all[3 * i + 1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : all[3 * i + 1] - (uint32_t)r0);
+            S->triples.push_back(all[3 * i + 2] - (uint32_t)r0);
+            S->triple_ord.push_back(i);
+        }
     }
     const size_t chunk = lig_trace::CHUNK, groups = (chunk + lig_trace::GROUP - 1) / lig_trace::GROUP;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
@@ -903,7 +910,22 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
     lig::aes256_expand_host(job->witness_key, rk);
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (size_t r = 0; r < Rl;) {
+    size_t r_first = 0;
+    if (S->RB) {          // the batch program is small: every rank runs it and keeps the rows it owns
+        fr* all = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&all, S->RB * (size_t)k * sizeof(fr)));
+        const int rc = run_batch_program(c, *job, all);
+        const size_t lo = std::min(r0, S->RB), hi = std::min(r0 + Rl, S->RB);
+        if (rc == LIG_OK && hi > lo) (void)hipMemcpyAsync(S->msgs + (lo - r0) * (size_t)k, all + lo * (size_t)k, (hi - lo) * (size_t)k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(all);
+        if (rc != LIG_OK) return rc;
+        r_first = hi - lo;
+        lig::aes256_expand_host(job->witness_key, rk);                    // the program used the encoding key
+        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    for (size_t r = r_first; r < Rl;) {
         const RowDesc d = S->rows[r0 + r];
         if (d.kind == 0) {
             lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[r0 + r], S->msgs + r * k, 1, d.data, k, 0, 1, d.data);
@@ -950,8 +972,12 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig::aes256_expand_host(S->job.encoding_seed, rk);
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)r0 * pad, S->msgs, Rl, pad, k, l, 1, pad);          // pads of the local rows
-    uint64_t epos = (uint64_t)R * pad;
+    {   // pads of the local stream rows (batch rows carry theirs from the program); position = draws before the row
+        const size_t first = std::max(r0, S->RB), last = r0 + Rl;
+        if (last > first)
+            lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)(S->n_init + (first - S->RB)) * pad, S->msgs + (first - r0) * (size_t)k, last - first, pad, k, l, 1, pad);
+    }
+    uint64_t epos = (uint64_t)(S->n_init + (R - S->RB)) * pad;
     fr* mask = S->cw + Rl * (size_t)n; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;           // masks: formed by every rank
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;
@@ -1008,14 +1034,14 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     const size_t NTl = S->triple_ord.size();
     {
         std::vector<H::Fr> rc, rq;
-        size_t NT = 0;
-        for (size_t r = 0; r < R; r++) NT += S->rows[r].kind == 3;
+        const size_t NT = quad_terms(S->rows).size() / 3;
         FieldStream code(info->stage1_seed), quad(info->stage1_seed);
-        code.next(R, rc);
+code.next(S->code_ord[R], rc);
         quad.next(NT, rq);
         std::vector<lig::f29s> coef(Rl + 2 * NTl + 1);
         const H::Fr R261sq = H::mul(R261, R261);
-        for (size_t r = 0; r < Rl; r++) coef[r] = to_f29s_host(rc[r0 + r], R261);
+        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
+        for (size_t r = 0; r < Rl; r++) if (has_code_check(S->rows[r0 + r].kind)) coef[r] = to_f29s_host(rc[S->code_ord[r0 + r]], R261);
         for (size_t i = 0; i < NTl; i++) { coef[Rl + i] = to_f29s_host(rq[S->triple_ord[i]], R261sq); coef[Rl + NTl + i] = to_f29s_host(rq[S->triple_ord[i]], R261); }
         HIP_TRY(c, hipMemcpyAsync(S->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
         lig::aes256_expand_host(info->stage1_seed, rk);

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 WORKER = textwrap.dedent('''
     import hashlib, importlib.util, json, os, sys
     root, l, k, n, n_lin, n_quad = sys.argv[1], *map(int, sys.argv[2:7])
+    batch = len(sys.argv) > 7 and sys.argv[7] == "1"
+    sys.path.insert(0, os.path.join(root, "tests"))
     def load(name, rel):
         spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
         m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
@@ -24,6 +26,9 @@ WORKER = textwrap.dedent('''
     g = dist.Group("gloo")
     ctx = pkg.Context(l, k, n, device=0)
     job = pkg.Context.make_job(n_lin, n_quad, generated_at=77)
+    if batch:                            # a batch program ahead of the synthetic stream (tests/test_batch_rows.py)
+        import test_batch_rows
+        test_batch_rows.demo_program().attach(job)
     comm = g.make_comm(pkg, ctx)
     sh = ctx.shard_prepare(job, g.rank, g.world, comm)
     proof, info = ctx.shard_prove(sh)
@@ -31,7 +36,7 @@ WORKER = textwrap.dedent('''
     ctx.shard_destroy(sh)
     ref = None
     if g.rank == 0:                      # the unsharded prover on the same job
-        tr = ctx.synth_prepare(n_lin, n_quad, generated_at=77)
+        tr = ctx.synth_prepare_job(job)
         ref, rinfo = ctx.synth_prove(tr)
         ctx.trace_destroy(tr)
     digs = g.gather_digests(hashlib.sha256(proof).digest())
@@ -44,11 +49,11 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port):
+def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch=False):
     script = tmp_path / "shard_worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad)],
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad), "1" if batch else "0"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
              for r in range(world)]
     outs = []
@@ -68,6 +73,15 @@ def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, 
     outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, 29741 + world)
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert len({o["sha"] for o in outs}) == 1
+    assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_proof_with_batch_rows_equals_single_gpu_proof(tmp_path, world):
+    """the batch program's rows are dealt to the ranks like any other rows (every rank runs the small program and keeps
+    its slice; equality pairs and product triples are never split across ranks)"""
+    outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, 29791 + world, batch=True)
+    assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
 
 
