@@ -127,6 +127,42 @@ __global__ void k_rng_fill_rows(const uint32_t* __restrict__ rk_g, uint64_t firs
         fr_store(out + r * row_stride + col_off + (size_t)i * elem_stride, fr_reduce_once(v));
     }
 }
+// Dense variant for whole randomness rows: row r of `out` (k elements) = per_row stream elements followed by zeros, so the
+// buffer needs no memset beforehand (the runtime's fill kernel reaches only ~1.4 TB/s).
+__global__ void k_rng_fill_rows_dense(const uint32_t* __restrict__ rk_g, uint64_t first, fr* __restrict__ out, size_t rows,
+                                      uint32_t per_row, uint32_t k) {
+    __shared__ uint32_t te[4 * 256];
+    __shared__ uint32_t rk[60];
+    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) te[i] = g_te[i];
+    if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
+    __syncthreads();
+    const size_t total = rows * k;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / k;
+        const uint32_t i = (uint32_t)(e - r * k);
+        fr v = fr_zero();
+        if (i < per_row) {
+            const uint64_t blk = 2 * (first + r * (uint64_t)per_row + i);
+            uint32_t o[8];
+            aes256_block(rk, te, blk, o);
+            aes256_block(rk, te, blk + 1, o + 4);
+#pragma unroll
+            for (int w = 0; w < 8; w++) v.v[w] = __builtin_bswap32(o[w]);
+#pragma unroll
+            for (int w = 0; w < 8; w++) v.v[w] = (v.v[w] >> 2) | (w < 7 ? (v.v[w + 1] << 30) : 0u);
+            v = fr_reduce_once(v);
+        }
+        fr_store(out + e, v);
+    }
+}
+void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k) {
+    const size_t total = rows * k;
+    if (!total) return;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_rng_fill_rows_dense, dim3((uint32_t)blocks), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
+}
+
 void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,
                           size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
     const size_t total = rows * per_row;
