@@ -37,6 +37,7 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
 void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out);
+void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
 void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
 }  // namespace lig
@@ -673,13 +674,12 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
-        HIP_TRY(c, hipMemsetAsync(rb, 0, nb * (size_t)k * 32, s2));
         uint64_t lpos = chunk_pos[ci];
-        for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order
+        for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order; zeros after
             size_t run = 1;
             const uint32_t d = T->rows[b + r].data;
             while (r + run < nb && T->rows[b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows(s2, c->rk_dev, lpos, rb + r * k, run, d, k, 0, 1, d);
+            lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
             lpos += (uint64_t)run * d; r += run;
         }
         HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2));
@@ -1036,7 +1036,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         std::vector<H::Fr> rc, rq;
         const size_t NT = quad_terms(S->rows).size() / 3;
         FieldStream code(info->stage1_seed), quad(info->stage1_seed);
-code.next(S->code_ord[R], rc);
+        code.next(S->code_ord[R], rc);
         quad.next(NT, rq);
         std::vector<lig::f29s> coef(Rl + 2 * NTl + 1);
         const H::Fr R261sq = H::mul(R261, R261);
