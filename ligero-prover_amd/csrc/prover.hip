@@ -37,6 +37,8 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
 void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out);
+void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
+                             const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
 void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
@@ -438,7 +440,7 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
     TRY(dm((void**)&T->randb, 2 * chunk * (size_t)k * 32));          // double-buffered
     TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
     TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
-    TRY(dm((void**)&T->parts, 2 * groups * (size_t)n * 32));
+    TRY(dm((void**)&T->parts, 3 * groups * (size_t)n * 32));
     TRY(dm((void**)&T->dots, (R ? R : 1) * 32));
     TRY(dm((void**)&T->samples, (R + 3) * (size_t)t * 32));
     TRY(dm((void**)&T->sha_state, lig_sha_state_bytes(n)));
@@ -657,8 +659,11 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     // codeword coset 2 against the coset-2 values of the randomness rows, and the two are interleaved once per proof.
     fr* code = T->acc; fr* lin = T->acc + n; fr* quad = T->acc + 2 * (size_t)n; fr* tmp = T->acc + 3 * (size_t)n;
     fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
-    HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
+    // group partials of the three k-column accumulators: group g of every chunk adds into slot g, combined once at the end
     const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
+    fr* p_code = T->parts; fr* p_linH = T->parts + groups * (size_t)n; fr* p_linC = T->parts + 2 * groups * (size_t)n;
+    HIP_TRY(c, hipMemsetAsync(T->parts, 0, 3 * groups * (size_t)n * 32, s));
+    HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
     fr* rhalf = T->rcw;                                   // chunk x 2k
     // The randomness rows of chunk b+1 (AES sampling: LDS-bound) and their inner products with the witness rows are
     // formed on the side stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
@@ -695,11 +700,15 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        lig::launch_rlc_rows29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, linC, T->parts,
-                               T->parts + groups * (size_t)n, lig_trace::GROUP / 4);
-        lig::launch_rlc_rows29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, code, linH, T->parts,
-                               T->parts + groups * (size_t)n, lig_trace::GROUP / 4);
+        lig::launch_rlc_accumulate29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_trace::GROUP / 4);
+        lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_trace::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
+    }
+    {   // one combine per accumulator and proof
+        const uint32_t pg = (uint32_t)((lig_trace::CHUNK + lig_trace::GROUP / 4 - 1) / (lig_trace::GROUP / 4));
+        lig::launch_rlc_combine(s, code, p_code, pg, k);
+        lig::launch_rlc_combine(s, linH, p_linH, pg, k);
+        lig::launch_rlc_combine(s, linC, p_linC, pg, k);
     }
     mark("stage2 rows (rng+dot+encode+rlc)");
     lig::launch_sum_elems(s, linH, k, 1, T->dots);       // the linear-test constant is minus this sum (prover_kernels.hip)

@@ -17,12 +17,13 @@ namespace lig {
 // 6 terms, value < 1.2p * group <= 2^261 for group <= 128).
 __global__ void __launch_bounds__(256) k_rlc_partial(const fr* __restrict__ U, size_t urs, uint32_t ues, const fr* __restrict__ Rn,
                                                      size_t rrs, size_t rows, uint32_t count, const f29s* __restrict__ rc,
-                                                     uint32_t group_rows, fr* __restrict__ code_part, fr* __restrict__ lin_part) {
+                                                     uint32_t group_rows, fr* __restrict__ code_part, fr* __restrict__ lin_part, int accumulate) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const size_t r0 = (size_t)blockIdx.y * group_rows;
     const size_t r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
     f29 ac = f29_zero(), al = f29_zero();
+    if (accumulate && rc != nullptr) ac = unpack29(fr_load(code_part + (size_t)blockIdx.y * count + j));     // running partial, < 2p
     int since = 0;
     for (size_t r = r0; r < r1; r++) {
         const f29 u = unpack29(fr_load(U + r * urs + (size_t)j * ues));
@@ -31,7 +32,11 @@ __global__ void __launch_bounds__(256) k_rlc_partial(const fr* __restrict__ U, s
         if (++since == 6) { ac = f29_qnorm(ac); al = f29_qnorm(al); since = 0; }
     }
     if (rc != nullptr) fr_store(code_part + (size_t)blockIdx.y * count + j, pack29(f29_reduce_2p(ac)));
-    if (Rn != nullptr) fr_store(lin_part + (size_t)blockIdx.y * count + j, pack29(f29_montmul(f29_qnorm(al), f29_const_r2())));
+    if (Rn != nullptr) {
+        f29 v = f29_montmul(f29_qnorm(al), f29_const_r2());                                                     // plain value, < 1.2p
+        if (accumulate) v = f29_reduce_2p(f29_add(v, unpack29(fr_load(lin_part + (size_t)blockIdx.y * count + j))));
+        fr_store(lin_part + (size_t)blockIdx.y * count + j, pack29(v));
+    }
 }
 
 // acc[j] = (acc[j] + sum_g part[g][j]) mod p, canonical
@@ -73,9 +78,17 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
                        const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows) {
     const uint32_t groups = (uint32_t)((rows + group_rows - 1) / group_rows);
     dim3 g((count + 255) / 256, groups);
-    hipLaunchKernelGGL(k_rlc_partial, g, dim3(256), 0, s, U, urs, ues, Rn, rrs, rows, count, rc_dev, group_rows, part_code, part_lin);
+    hipLaunchKernelGGL(k_rlc_partial, g, dim3(256), 0, s, U, urs, ues, Rn, rrs, rows, count, rc_dev, group_rows, part_code, part_lin, 0);
     if (rc_dev != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, code, part_code, groups, count);
     if (Rn != nullptr) hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, lin, part_lin, groups, count);
+}
+// partial pass only, ADDING to the group partials already in part_code / part_lin (zeroed by the caller before the first
+// chunk): the prover combines once per proof instead of once per chunk.  Group g of every chunk adds to slot g.
+void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
+                             const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows) {
+    const uint32_t groups = (uint32_t)((rows + group_rows - 1) / group_rows);
+    dim3 g((count + 255) / 256, groups);
+    hipLaunchKernelGGL(k_rlc_partial, g, dim3(256), 0, s, U, urs, ues, Rn, rrs, rows, count, rc_dev, group_rows, part_code, part_lin, 1);
 }
 // acc[j] = (acc[j] + sum_g part[g*count + j]) mod p  (used to add the all-gathered per-GPU partial accumulators)
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count) {
