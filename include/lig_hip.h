@@ -185,6 +185,8 @@ typedef struct {
     int32_t parsed, indices_match;
     int32_t valid_merkle, valid_code, valid_linear, valid_quad, code_equal, linear_equal, quad_equal;   /* webgpu_verifier.cpp:412-442 */
     int32_t accept;
+    int32_t reserved;
+    double  ms_total;                /* wall time of the call */
 } lig_verify_info;
 int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t const_sum[32], const uint8_t *proof, size_t proof_len,
                      lig_verify_info *out);

@@ -35,7 +35,7 @@ EXPORTS = [
 
 class VerifyInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("parsed", "indices_match", "valid_merkle", "valid_code", "valid_linear", "valid_quad",
-                                          "code_equal", "linear_equal", "quad_equal", "accept")]
+                                          "code_equal", "linear_equal", "quad_equal", "accept", "reserved")] + [("ms_total", C.c_double)]
 
 A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 

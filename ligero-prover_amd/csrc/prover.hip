@@ -1215,6 +1215,8 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     CHECK_CTX(c);
     if (!job || !const_sum || !proof || !out) return LIG_E_ARG;
     std::memset(out, 0, sizeof *out);
+    const auto t_begin = clk::now();
+    struct Stamp { lig_verify_info* o; decltype(t_begin) t0; ~Stamp() { o->ms_total = ms_since(t0); } } stamp{out, t_begin};
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     hipStream_t s = c->stream;
     // ---- row plan of the public constraint stream
@@ -1285,7 +1287,7 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     out->indices_match = idx == pidx;
     if (!out->indices_match) return LIG_OK;
     // ---- device buffers
-    const size_t CH = 256;
+    const size_t CH = 512;
     fr *dS = nullptr, *drand = nullptr, *drcw = nullptr, *drg = nullptr, *dacc = nullptr, *dparts = nullptr, *dpoly = nullptr;
     uint32_t *dsha = nullptr, *dleaves = nullptr, *dtri = nullptr;
     lig::f29s* dcoef = nullptr;
