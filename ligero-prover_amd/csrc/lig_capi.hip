@@ -122,13 +122,15 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
         if ((rc = upload29(c, si, &ep.seam_inv)) != LIG_OK) return rc;
         if ((rc = upload29(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
     }
-    // twist[r-1][j1][i2] = w_n^(r*(j1 + 8*i2)), r = 1..3
+    // twist[r-1][j1][i2] = k^-1 * w_n^(r*(j1 + 8*i2)), r = 1..3.  The 1/k of the inverse transform rides on the twist (every
+    // computed coset has one; coset 0 is copied from the message), so K2a stores unscaled coefficients.
     {
         std::vector<lig::f29s> tw((size_t)3 * k);
+        const H::Fr kinv = H::inv(H::from_u64(k));
         for (uint32_t r = 1; r < 4; r++) {
             std::vector<H::Fr> pw = powers_plain(H::pow_u64(w4k, r), k);
             for (uint32_t j1 = 0; j1 < A; j1++)
-                for (uint32_t i2 = 0; i2 < B; i2++) tw[((size_t)(r - 1) * A + j1) * B + i2] = to_f29s(pw[j1 + (size_t)A * i2]);
+                for (uint32_t i2 = 0; i2 < B; i2++) tw[((size_t)(r - 1) * A + j1) * B + i2] = to_f29s(H::mul(kinv, pw[j1 + (size_t)A * i2]));
         }
         if ((rc = upload29(c, tw, &ep.twist)) != LIG_OK) return rc;
     }

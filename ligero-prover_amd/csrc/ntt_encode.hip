@@ -12,7 +12,7 @@
 //
 //   K1  encode_in  : thread = (row, i2).  Radix-8 butterfly across the strided elements msg[B*i1 + i2], seam
 //                    twiddle w_k^(-i2*j1) -> Y[j1][i2].
-//   K2a encode_coef: workgroup = (row, j1).  Size-B inverse transform of Y[j1][.] in LDS, times k^-1
+//   K2a encode_coef: workgroup = (row, j1).  Size-B inverse transform of Y[j1][.] in LDS (the 1/k factor rides on the K2b twist)
 //                    -> C[j1][j2] = coefficient c[j1 + 8*j2].
 //   K2b encode_mid : workgroup = (row, j1, coset r).  C[j1][.] * w_n^(r*i) -> size-B forward transform in LDS
 //                    -> times seam twiddle psi^(j1*q2) -> Z[r][j1][q2].                 (72% of all multiplies)
@@ -190,10 +190,10 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_coef(const fr* __re
 #pragma unroll
     for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + (__brev(4 * t + q) >> (32 - LOG2B))));
     tile_dft<LOG2B>(x, tw_inv, L, t);
-    const f29 ki = f29_load_tab(kinv);
+    (void)kinv;                                    // the 1/k factor is folded into the twist tables of K2b (lig_capi.hip)
     fr* c = Cc + (size_t)blockIdx.x * B;
 #pragma unroll
-    for (int q = 0; q < 4; q++) fr_store(c + t + q * T, pack29(f29_montmul(x[q], ki)));
+    for (int q = 0; q < 4; q++) fr_store(c + t + q * T, pack29(f29_reduce_2p(x[q])));
 }
 
 // ---------------------------------------------------------------------------------------------------- K2b
