@@ -42,7 +42,8 @@ struct lig_ctx {
 
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on = nullptr);
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
-int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows);
+int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t on = nullptr);
+int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on = nullptr);
 
 // every entry point may be called from any host thread (bench.py proves from worker threads): the context's device is made
 // current for the calling thread first -- HIP streams and allocations are only usable with their own device current

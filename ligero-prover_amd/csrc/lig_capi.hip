@@ -338,9 +338,18 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
 }
 // values of a degree-<2k polynomial on <w_n^2> (buf[0..2k), rest of the n-buffer zero) -> its values on all n points
 // encode_2k of `rows` consecutive n-element buffers in one pass of the radix-2 kernels (the two degree-<2k mask rows)
-int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows) {
-    lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_2K], (fr*)buf, rows, c->n);
-    lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, rows, c->n);
+int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t on) {
+    hipStream_t st = on ? on : c->stream;
+    lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_2K], (fr*)buf, rows, c->n);
+    lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)buf, rows, c->n);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+// encode of one n-element buffer with the radix-2 kernels only (no shared scratch: safe next to a batched encode on another stream)
+int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on) {
+    hipStream_t st = on ? on : c->stream;
+    lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
+    lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }

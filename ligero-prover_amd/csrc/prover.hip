@@ -578,6 +578,10 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     TRY(lig_sha_init(c, T->sha_state, n));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
+    // The three mask rows do not depend on the witness: their ~60 small radix-2 launches run on the side stream under the
+    // first chunk's encode (the hash of chunk 0 is queued behind them and has to wait for that encode anyway).
+    TRY(lig_internal_encode_generic(c, mask, s_sha));
+    TRY(lig_internal_encode_2k_rows(c, mlin, 2, s_sha));      // mlin and mquad are adjacent rows: one pass
     if (s_enc != s) HIP_TRY(c, hipStreamWaitEvent(s_enc, c->ev_fork, 0));
     uint64_t absorbed = 0;
     for (const auto& ch : chunk_schedule(R, lig_trace::CHUNK, 0, 96)) {
@@ -603,8 +607,6 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     }
     mark("encode message rows");
-    TRY(lig_encode(c, mask));
-    TRY(lig_internal_encode_2k_rows(c, mlin, 2));          // mlin and mquad are adjacent rows: one pass of 31 launches
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
     lig::launch_sha_update_rows(s_sha, T->sha_state, n, mask, n, 3, absorbed);
