@@ -632,23 +632,8 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
 
     // ================= stage 2: code / linear / quadratic accumulators over the resident codewords
     const size_t NT = T->triples.size() / 3;
-    {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple (three engines, same key)
-        std::vector<H::Fr> rc, rq;
-        FieldStream code(info->stage1_seed), quad(info->stage1_seed);
-        size_t n_code = 0;
-        for (size_t r = 0; r < R; r++) n_code += has_code_check(T->rows[r].kind);
-        code.next(n_code, rc);
-        quad.next(NT, rq);
-        std::vector<lig::f29s> coef(R + 2 * NT + 1);
-        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
-        const H::Fr R261sq = H::mul(R261, R261);
-        for (size_t r = 0, ci = 0; r < R; r++) if (has_code_check(T->rows[r].kind)) coef[r] = to_f29s_host(rc[ci++], R261);
-        for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
-        HIP_TRY(c, hipMemcpyAsync(T->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
-        lig::aes256_expand_host(info->stage1_seed, rk);
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
+    lig::aes256_expand_host(info->stage1_seed, rk);           // key of the code / linear / quadratic streams (three engines, same key)
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
     // Accumulators.  All three tests are sums of low-degree polynomials, so they are accumulated where they are
     // cheapest and extended to the n evaluation points once per proof (exact field arithmetic => same values as the
     // reference's per-row n-point updates, nonbatch_context.hpp:756-780):
@@ -695,6 +680,22 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));            // the side stream starts after the key upload / memset above
     HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
     if (n_chunks) TRY(form_rand_chunk(0));
+    {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple -- computed on the host while the
+        // side stream already samples the first randomness rows
+        std::vector<H::Fr> rc, rq;
+        FieldStream code(info->stage1_seed), quad(info->stage1_seed);
+        size_t n_code = 0;
+        for (size_t r = 0; r < R; r++) n_code += has_code_check(T->rows[r].kind);
+        code.next(n_code, rc);
+        quad.next(NT, rq);
+        std::vector<lig::f29s> coef(R + 2 * NT + 1);
+        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
+        const H::Fr R261sq = H::mul(R261, R261);
+        for (size_t r = 0, ci = 0; r < R; r++) if (has_code_check(T->rows[r].kind)) coef[r] = to_f29s_host(rc[ci++], R261);
+        for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
+        HIP_TRY(c, hipMemcpyAsync(T->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
     for (size_t ci = 0; ci < n_chunks; ci++) {
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
