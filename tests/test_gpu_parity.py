@@ -436,3 +436,33 @@ def test_hip_verifier_agrees_with_restated_verifier(amd, l, k, n, n_linear, n_qu
         assert c.synth_verify(job2, cs, proof).accept == 0
     finally:
         c.close()
+
+
+def test_concurrent_contexts_prove_independently(amd):
+    """two contexts (= two sets of streams) proving from two host threads at the same time, as bench.py does with
+    --inflight 2, give the envelopes they give alone: no state is shared between contexts"""
+    import threading
+    jobs = [(320, 512, 2048, 5000, 700, 11), (320, 512, 2048, 3000, 0, 12)]
+
+    def prove(job, out, idx, reps):
+        l, k, n, nl, nq, ts = job
+        c = amd.Context(l, k, n)
+        try:
+            tr = c.synth_prepare(nl, nq, generated_at=ts)
+            proofs = [c.synth_prove(tr)[0] for _ in range(reps)]
+            c.trace_destroy(tr)
+            out[idx] = proofs
+        finally:
+            c.close()
+
+    alone = [None, None]
+    for i, j in enumerate(jobs):
+        prove(j, alone, i, 1)
+    both = [None, None]
+    th = [threading.Thread(target=prove, args=(j, both, i, 6)) for i, j in enumerate(jobs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert both[i] is not None and all(p == alone[i][0] for p in both[i])
