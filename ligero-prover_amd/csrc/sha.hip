@@ -70,27 +70,34 @@ __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, cons
     // The column chain is sequential in rows: this kernel is latency-bound with only n_inst/64 waves and usually runs
     // next to an encode kernel on the side stream.  Highest wave priority lets it issue whenever it is ready, so its
     // critical path stays close to the stand-alone one while the encode waves fill the remaining issue slots.
-    // (s_setprio(3) measured: no gain stand-alone, slower when co-resident with the encode kernels)
+    // (s_setprio(3) measured: no gain stand-alone, slower when co-resident with the encode kernels.  A two-wave variant --
+    // one wave expanding the message schedule of block b+1 into LDS while the other runs the rounds of block b -- was
+    // measured too: same stand-alone time, 2 % slower proofs; the per-block barrier and LDS round trip eat the shorter chain.)
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_inst) return;
     uint32_t h[8], w[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) h[i] = st[(size_t)i * n_inst + j];
-    // virtual element sequence: the pending half block (if any) followed by the new rows; one compression per pair
+    // virtual element sequence: the pending half block (if any) followed by the new rows; one compression per pair.
+    // The two elements of the NEXT pair are requested before the current compression starts, so that their HBM latency
+    // (about a quarter of a compression for a lone wave) is covered by the ~1470 instructions of the rounds.
     const size_t pend = (size_t)(rows_before & 1);
     const size_t total = nrows + pend;
-    for (size_t v = 0; v + 1 < total; v += 2) {
+    auto elem = [&](size_t v) -> fr {                      // virtual element v
         if (v == 0 && pend) {
+            fr e;
 #pragma unroll
-            for (int i = 0; i < 8; i++) w[i] = st[(size_t)(8 + i) * n_inst + j];
-        } else {
-            const fr e0 = fr_load(rows + (v - pend) * row_stride + j);
-#pragma unroll
-            for (int i = 0; i < 8; i++) w[i] = e0.v[i];
+            for (int i = 0; i < 8; i++) e.v[i] = st[(size_t)(8 + i) * n_inst + j];
+            return e;
         }
-        const fr e1 = fr_load(rows + (v + 1 - pend) * row_stride + j);
+        return fr_load(rows + (v - pend) * row_stride + j);
+    };
+    fr n0 = fr_zero(), n1 = fr_zero();
+    if (total >= 2) { n0 = elem(0); n1 = elem(1); }
+    for (size_t v = 0; v + 1 < total; v += 2) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[8 + i] = e1.v[i];
+        for (int i = 0; i < 8; i++) { w[i] = n0.v[i]; w[8 + i] = n1.v[i]; }
+        if (v + 3 < total) { n0 = elem(v + 2); n1 = elem(v + 3); }
         sha256_compress(h, w);
     }
     if (total & 1) {         // odd tail: keep the element for the next call / final
