@@ -466,3 +466,32 @@ def test_concurrent_contexts_prove_independently(amd):
         t.join()
     for i in range(2):
         assert both[i] is not None and all(p == alone[i][0] for p in both[i])
+
+
+@pytest.mark.parametrize("n_linear,n_quad", [
+    (320 * 509, 320),            # 509 linear rows + one triple = 512 rows: exactly one chunk
+    (320 * 510, 320 + 7),        # the full triple occupies rows 510-512: it straddles the 512-row chunk boundary
+    (320 * 511 + 3, 0),          # 511 full rows + partial = 512
+    (320 * 512 + 1, 5),          # 513 linear rows (last partial) + a partial triple
+    (320 * 1020, 320 * 2 + 1),   # 1020 + 6 + 3 rows: two chunk boundaries, triples at 1020-1028
+])
+def test_batched_prover_chunk_boundaries(amd, n_linear, n_quad):
+    """row counts around the 512-row launch chunks (and the 64 / 16-row accumulation groups) with quadratic triples
+    straddling a chunk boundary: envelope equal to the oracle's"""
+    l, k, n = 320, 512, 2048
+    c = amd.Context(l, k, n)
+    try:
+        tr = c.synth_prepare(n_linear, n_quad, generated_at=3)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+    finally:
+        c.close()
+    job = ol.make_job(l, k, n, 192, n_linear, n_quad, generated_at=3, threads=8)
+    pr = ol.Proof()
+    assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) == 0
+    try:
+        assert info.rows == pr.rows
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert proof == bytes(pr.proof[:pr.proof_len])
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
