@@ -1295,14 +1295,15 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     uint32_t *dsha = nullptr, *dleaves = nullptr, *dtri = nullptr;
     lig::f29s* dcoef = nullptr;
     std::vector<void*> owned;
-    auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
-    struct Cleanup { std::vector<void*>& v; lig_ctx* c; void* sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
+    auto dm0 = [&](void** p, size_t bytes, bool zero) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
+    auto dm = [&](void** p, size_t bytes) -> int { return dm0(p, bytes, true); };
+    struct Cleanup { std::vector<void*>& v; lig_ctx* c; void* sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
     const size_t groups = (CH + lig_trace::GROUP - 1) / lig_trace::GROUP;
     const std::vector<uint32_t> triples = quad_terms(rows);
     const size_t NT = triples.size() / 3;
     TRY(dm((void**)&dS, smp_bytes));
-    TRY(dm((void**)&drand, CH * (size_t)k * 32));
-    TRY(dm((void**)&drcw, CH * (size_t)n * 32));
+    TRY(dm0((void**)&drand, 2 * CH * (size_t)k * 32, false));        // double-buffered, every element written by the sampler
+    TRY(dm0((void**)&drcw, CH * (size_t)n * 32, false));
     TRY(dm((void**)&drg, (R ? R : 1) * (size_t)t * 32));
     TRY(dm((void**)&dacc, 3 * (size_t)t * 32));
     TRY(dm((void**)&dparts, 2 * groups * (size_t)t * 32));
@@ -1344,18 +1345,37 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     // ---- randomness rows of the public stream, encoded, read at the sampled positions; accumulators on 192-vectors
     TRY(lig_sample_init(c, idx.data(), idx.size()));
     fr* vc = dacc; fr* vl = dacc + t; fr* vq = dacc + 2 * (size_t)t;
+    // the sampler of chunk b+1 runs on the side stream under the encode of chunk b (double-buffered rows)
     uint64_t lpos = 0;
-    for (size_t b = 0; b < R; b += CH) {
-        const size_t nb = std::min(CH, R - b);
-        HIP_TRY(c, hipMemsetAsync(drand, 0, nb * (size_t)k * 32, s));
+    hipStream_t s2 = c->stream2;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    struct Events { hipEvent_t* a; hipEvent_t* b; ~Events() { for (int i = 0; i < 2; i++) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } } } events{ev_ready, ev_used};
+    for (int i = 0; i < 2; i++) { HIP_TRY(c, hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&ev_used[i], hipEventDisableTiming)); }
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key upload done
+    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    const size_t n_chunks = (R + CH - 1) / CH;
+    auto sample_chunk = [&](size_t ci) -> int {
+        const size_t b = ci * CH, nb = std::min(CH, R - b);
+        fr* rb = drand + (ci & 1) * CH * (size_t)k;
+        if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, ev_used[ci & 1], 0));
         for (size_t r = 0; r < nb;) {
             size_t run = 1;
             const uint32_t d = rows[b + r].data;
             while (r + run < nb && rows[b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows(s, c->rk_dev, lpos, drand + r * k, run, d, k, 0, 1, d);
+            lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
             lpos += (uint64_t)run * d; r += run;
         }
-        TRY(lig_internal_encode_rows(c, drand, drcw, nb, false));
+        HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2));
+        return LIG_OK;
+    };
+    if (n_chunks) TRY(sample_chunk(0));
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+        const size_t b = ci * CH, nb = std::min(CH, R - b);
+        fr* rb = drand + (ci & 1) * CH * (size_t)k;
+        if (ci + 1 < n_chunks) TRY(sample_chunk(ci + 1));
+        HIP_TRY(c, hipStreamWaitEvent(s, ev_ready[ci & 1], 0));
+        TRY(lig_internal_encode_rows(c, rb, drcw, nb, false));
+        HIP_TRY(c, hipEventRecord(ev_used[ci & 1], s));
         TRY(lig_gather_rows(c, drcw, nb, drg + b * t));
         lig::launch_rlc_rows29(s, dS + b * t, t, 1, drg + b * t, t, nb, t, dcoef + b, vc, vl, dparts, dparts + groups * (size_t)t, lig_trace::GROUP);
     }
