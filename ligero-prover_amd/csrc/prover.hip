@@ -12,288 +12,7 @@
 // The guest interpreter / constraint generator is out of scope; rows come from the synthetic
 // constraint stream of BASELINE.md 3: n_linear witness slots + n_quad slots of x*y=z, one dense linear-test
 // coefficient per witness.
-#include <openssl/evp.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <utility>
-#include <vector>
-
-#include "ctx_internal.hpp"
-#include "fr29.hpp"
-#include "host_field.hpp"
-
-namespace H = lig::host;
-
-namespace lig {
-void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,
-                          size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride);
-void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
-                       const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows);
-void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
-                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
-void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out);
-void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
-                             const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows);
-void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
-void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
-void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
-}  // namespace lig
-
-namespace {
-
-using clk = std::chrono::steady_clock;
-double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
-
-// ---------------------------------------------------------------- host crypto (OpenSSL, as the reference: hash.hpp:153-214, csprng.hpp)
-struct Sha256 {
-    EVP_MD_CTX* c;
-    Sha256() : c(EVP_MD_CTX_new()) { EVP_DigestInit_ex(c, EVP_sha256(), nullptr); }
-    ~Sha256() { EVP_MD_CTX_free(c); }
-    Sha256& add(const void* p, size_t n) { EVP_DigestUpdate(c, p, n); return *this; }
-    void finish(uint8_t out[32]) { unsigned int l = 32; EVP_DigestFinal_ex(c, out, &l); }
-};
-// keystream element e of the AES-256-CTR stream (IV = 0): blocks 2e, 2e+1  -> field element (finite_field_gmp.hpp:66-78)
-struct FieldStream {
-    EVP_CIPHER_CTX* c;
-    explicit FieldStream(const uint8_t key[32]) : c(EVP_CIPHER_CTX_new()) {
-        const uint8_t iv[16] = {0};
-        EVP_EncryptInit_ex(c, EVP_aes_256_ctr(), nullptr, key, iv);
-    }
-    ~FieldStream() { EVP_CIPHER_CTX_free(c); }
-    // sequential draws (the engine is only ever read front to back on the host)
-    void next(size_t count, std::vector<H::Fr>& out) {
-        std::vector<uint8_t> zero(32 * count, 0), ks(32 * count);
-        int len = 0;
-        EVP_EncryptUpdate(c, ks.data(), &len, zero.data(), (int)zero.size());
-        out.resize(count);
-        for (size_t i = 0; i < count; i++) {
-            H::Fr v;
-            std::memcpy(v.v, ks.data() + 32 * i, 32);
-            for (int w = 0; w < 4; w++) v.v[w] = (v.v[w] >> 2) | (w < 3 ? (v.v[w + 1] << 62) : 0);
-            if (H::geq(v, H::P)) v = H::sub_nored(v, H::P);
-            out[i] = v;
-        }
-    }
-};
-
-// hash_random_engine<sha256> (include/zkp/random.hpp:87-146)
-struct HashRandomEngine {
-    uint8_t seed[32], buf[32];
-    uint64_t state = 0;
-    int off = -1;
-    explicit HashRandomEngine(const uint8_t s[32]) { std::memcpy(seed, s, 32); }
-    uint8_t operator()() {
-        if (off < 0) {
-            Sha256 h;
-            if (state) h.add(seed, 32);             // the seed is absorbed only after the first flush
-            uint8_t le[8];
-            for (int i = 0; i < 8; i++) le[i] = (uint8_t)(state >> (8 * i));
-            h.add(le, 8).finish(buf);
-            state++;
-            off = 31;
-        }
-        return buf[off--];
-    }
-};
-// boost::random::detail::generate_uniform_int over an 8-bit engine (Boost is not vendored upstream)
-uint64_t uniform_u64(HashRandomEngine& e, uint64_t range) {
-    if (range == 0) return 0;
-    if (range == 255) return e();
-    if (range < 255) {
-        const uint64_t bucket = 256 / (range + 1);
-        for (;;) { const uint64_t r = e() / bucket; if (r <= range) return r; }
-    }
-    for (;;) {
-        const uint64_t limit = (range + 1) / 256;     // range < 2^64 - 1 always here
-        uint64_t result = 0, mult = 1;
-        bool exact = false;
-        while (mult <= limit) {
-            result += (uint64_t)e() * mult;
-            if (mult * 255 == range - mult + 1) { exact = true; break; }
-            mult *= 256;
-        }
-        if (exact) return result;
-        uint64_t inc = uniform_u64(e, range / mult);
-        if (UINT64_MAX / mult < inc) continue;
-        inc *= mult;
-        result += inc;
-        if (result < inc || result > range) continue;
-        return result;
-    }
-}
-// portable_sample + sort (include/util/portable_sample.hpp:15-33, src/webgpu_prover.cpp:343-351)
-std::vector<uint32_t> sample_columns(const uint8_t seed[32], uint32_t n, uint32_t t) {
-    HashRandomEngine e(seed);
-    std::vector<uint32_t> a(n), out;
-    for (uint32_t i = 0; i < n; i++) a[i] = i;
-    if (t > n) t = n;
-    for (uint32_t i = 0; i < t; i++) {
-        const uint64_t j = i + uniform_u64(e, (uint64_t)(n - 1) - i);
-        std::swap(a[i], a[j]);
-        out.push_back(a[i]);
-    }
-    std::sort(out.begin(), out.end());
-    return out;
-}
-// merkle_tree::decommit + canonical sibling order (merkle_tree.hpp:155-215, proof_serializer.hpp:82-117)
-std::vector<uint8_t> decommit(const uint8_t* nodes, size_t P, const std::vector<uint32_t>& idx) {
-    std::vector<uint8_t> sib;
-    std::vector<uint8_t> known(P, 0), upper(P, 0);
-    for (uint32_t i : idx) known[i] = 1;
-    size_t start = P - 1, end = 2 * P - 1;
-    while (start > 0) {
-        std::fill(upper.begin(), upper.end(), 0);
-        for (size_t i = start; i < end; i += 2) {
-            const size_t ll = i - start;
-            const bool kl = known[ll], kr = known[ll + 1];
-            if (kl && kr) upper[ll / 2] = 1;
-            else if (kr) { sib.insert(sib.end(), nodes + 32 * i, nodes + 32 * i + 32); upper[ll / 2] = 1; }
-            else if (kl) { sib.insert(sib.end(), nodes + 32 * (i + 1), nodes + 32 * (i + 1) + 32); upper[ll / 2] = 1; }
-        }
-        known.swap(upper);
-        start = (start - 1) / 2; end = (end - 1) / 2;
-    }
-    return sib;
-}
-
-// ---------------------------------------------------------------- protobuf wire writer (proto/ligero_proof.proto, proto/common.proto)
-struct Pb {
-    std::vector<uint8_t> b;
-    void var(uint64_t v) { do { uint8_t c = v & 0x7f; v >>= 7; if (v) c |= 0x80; b.push_back(c); } while (v); }
-    void tag(uint32_t f, uint32_t wt) { var(((uint64_t)f << 3) | wt); }
-    void u(uint32_t f, uint64_t v) { if (v) { tag(f, 0); var(v); } }
-    void bytes(uint32_t f, const void* p, size_t n) { tag(f, 2); var(n); const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); }
-    void msg(uint32_t f, const Pb& m) { bytes(f, m.b.data(), m.b.size()); }
-};
-size_t varlen(uint64_t v) { size_t n = 1; while (v > 0x7f) { v >>= 7; n++; } return n; }
-
-// serialize_proof (include/zkp/proof_serializer.hpp:166-191) + metadata (src/webgpu_prover.cpp:410-427), written
-// straight into a caller-provided (pinned) buffer.  The four FixedU32Vector payloads are raw little-endian limb
-// bytes: the three accumulators are copied in, the position of the sample payload is returned so that the
-// device->host copy of the opened columns lands directly inside the envelope.
-struct EnvelopeLayout { size_t total = 0, samples_off = 0; };
-EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, const uint8_t program_hash[32], int64_t generated_at,
-                              uint32_t k, uint32_t n, uint32_t t, const uint8_t root[32], const std::vector<uint8_t>& siblings,
-                              const std::vector<uint32_t>& idx, const uint8_t* enc3, size_t sample_bytes) {
-    auto digest = [](const uint8_t d[32]) { Pb m; m.bytes(1, d, 32); return m; };
-    Pb meta;
-    if (version[0]) meta.bytes(1, version, std::strlen(version));
-    meta.u(2, 1); meta.u(3, 1);
-    meta.msg(4, digest(program_hash));
-    { Pb ts; ts.u(1, (uint64_t)generated_at); meta.msg(5, ts); }
-    meta.u(6, k); meta.u(7, n); meta.u(8, t); meta.u(9, 128);
-    Pb md;
-    md.u(1, 1);
-    md.msg(2, digest(root));
-    for (size_t i = 0; i < siblings.size() / 32; i++) md.msg(3, digest(siblings.data() + 32 * i));
-    if (!idx.empty()) { Pb pk; for (uint32_t v : idx) pk.var(v); md.bytes(4, pk.b.data(), pk.b.size()); }
-    const size_t vec = (size_t)n * 32;
-    auto fixed_len = [](size_t nb) { return nb ? 1 + varlen(nb) + nb : 0; };
-    const size_t body_len = 1 + varlen(md.b.size()) + md.b.size() + 3 * (1 + varlen(fixed_len(vec)) + fixed_len(vec)) + 1 +
-                            varlen(fixed_len(sample_bytes)) + fixed_len(sample_bytes);
-    Pb head;
-    head.msg(1, meta);
-    head.tag(2, 2); head.var(body_len);
-    head.msg(1, md);
-    EnvelopeLayout L;
-    size_t pos = 0;
-    auto put = [&](const void* p, size_t nb) { if (pos + nb <= cap) std::memcpy(dst + pos, p, nb); pos += nb; };
-    put(head.b.data(), head.b.size());
-    for (uint32_t f = 2; f <= 5; f++) {
-        const size_t nb = f < 5 ? vec : sample_bytes;
-        Pb h;
-        h.tag(f, 2); h.var(fixed_len(nb));
-        if (nb) { h.tag(1, 2); h.var(nb); }
-        put(h.b.data(), h.b.size());
-        if (f < 5) put(enc3 + (size_t)(f - 2) * vec, nb);
-        else { L.samples_off = pos; pos += nb; }
-    }
-    L.total = pos;
-    return L;
-}
-
-// kind: 0 linear, 1 x, 2 y, 3 z of the synthetic stream; rows committed by the batch program (lig_hip.h, lig_batch_op):
-// 4 init, 5 bit, 6 / 7 the two rows of an equality, 8 / 9 / 10 the x, y, z of a batch product or quotient
-struct RowDesc { uint8_t kind; uint32_t data; };
-enum : uint8_t { RK_INIT = 4, RK_BIT = 5, RK_EQX = 6, RK_EQY = 7, RK_BQX = 8, RK_BQY = 9, RK_BQZ = 10 };
-inline bool has_code_check(uint8_t kind) { return kind != RK_EQX && kind != RK_EQY; }      // nonbatch_context.hpp:811-825
-
-// Commit order: rows of the batch program in program order, then witness_manager's order for the synthetic stream
-// (witness_manager.hpp:497-503): full linear rows, full quadratic triples, partial linear row, partial quadratic triple.
-// Returns false for a malformed batch program.  n_init = rows that draw padding from the encoding stream at init time.
-bool plan_rows(const lig_synth_job& job, uint32_t l, std::vector<RowDesc>& rows, size_t& n_init) {
-    rows.clear();
-    n_init = 0;
-    if (job.n_batch_ops && !job.batch_ops) return false;
-    for (uint64_t i = 0; i < job.n_batch_ops; i++) {
-        const lig_batch_op& o = job.batch_ops[i];
-        if (o.op >= LIG_BOP_COUNT || o.out >= 512 || o.x >= 512 || o.y >= 512) return false;
-        const uint64_t need = o.op == LIG_BOP_SET ? 32ull * o.len : o.op == LIG_BOP_BIT_DECOMPOSE ? 4ull * o.len :
-                              (o.op == LIG_BOP_SET_SCALAR || (o.op >= LIG_BOP_ADD_CONST && o.op <= LIG_BOP_MONTMUL_CONST)) ? 32 : 0;
-        if (need && (!job.batch_data || o.data_off > job.batch_data_bytes || need > job.batch_data_bytes - o.data_off)) return false;
-        if (o.op == LIG_BOP_SET && o.len > l) return false;
-        if (o.op == LIG_BOP_BIT_DECOMPOSE && o.len > 256) return false;
-        switch (o.op) {
-            case LIG_BOP_SET: case LIG_BOP_SET_SCALAR: rows.push_back({RK_INIT, 0}); n_init++; break;
-            case LIG_BOP_COPY: case LIG_BOP_ASSERT_EQUAL: rows.push_back({RK_EQX, 0}); rows.push_back({RK_EQY, 0}); break;
-            case LIG_BOP_MUL: case LIG_BOP_DIV: rows.push_back({RK_BQX, 0}); rows.push_back({RK_BQY, 0}); rows.push_back({RK_BQZ, 0}); break;
-            case LIG_BOP_BIT_DECOMPOSE: for (uint32_t b = 0; b < o.len; b++) rows.push_back({RK_BIT, 0}); break;
-            default: break;
-        }
-    }
-    const size_t lf = job.n_linear / l, lp = job.n_linear % l, qf = job.n_quad / l, qp = job.n_quad % l;
-    for (size_t i = 0; i < lf; i++) rows.push_back({0, l});
-    for (size_t i = 0; i < qf; i++) for (uint8_t q = 1; q <= 3; q++) rows.push_back({q, l});
-    if (lp) rows.push_back({0, (uint32_t)lp});
-    if (qp) for (uint8_t q = 1; q <= 3; q++) rows.push_back({q, (uint32_t)qp});
-    return true;
-}
-// quadratic-test terms in hook order (one quadratic-stream draw each): (x, y, z) row indices; y = 0xFFFFFFFF marks the
-// equality term r * (x - z) (prover_kernels.hip k_quad_rows)
-std::vector<uint32_t> quad_terms(const std::vector<RowDesc>& rows) {
-    std::vector<uint32_t> t;
-    for (size_t r = 0; r < rows.size(); r++) {
-        const uint8_t kd = rows[r].kind;
-        if (kd == 3 || kd == RK_BQZ) { t.push_back((uint32_t)r - 2); t.push_back((uint32_t)r - 1); t.push_back((uint32_t)r); }
-        else if (kd == RK_BIT) { t.push_back((uint32_t)r); t.push_back((uint32_t)r); t.push_back((uint32_t)r); }
-        else if (kd == RK_EQY) { t.push_back((uint32_t)r - 1); t.push_back(0xFFFFFFFFu); t.push_back((uint32_t)r); }
-    }
-    return t;
-}
-
-// Row-chunk schedule [begin, end) pairs.  Chunks are `big` rows except that the exposed end of a two-stream pipeline
-// is kept short: `head` rows first (stage 2: the encode stream waits for the first randomness rows) and/or a short
-// last chunk of `tail` rows (stage 1: the column hash of the last chunk runs after the last encode).
-std::vector<std::pair<size_t, size_t>> chunk_schedule(size_t R, size_t big, size_t head, size_t tail) {
-    std::vector<std::pair<size_t, size_t>> out;
-    size_t b = 0;
-    if (head && R > head + tail) { out.push_back({0, head}); b = head; }
-    const size_t stop = (tail && R > b + tail) ? R - tail : R;
-    while (b < stop) { const size_t e = std::min(stop, b + big); out.push_back({b, e}); b = e; }
-    if (b < R) out.push_back({b, R});
-    return out;
-}
-
-lig::f29s to_f29s_host(const H::Fr& plain, const H::Fr& scale) {
-    const H::Fr m = H::mul(plain, scale);
-    lig::f29s o;
-    std::memset(&o, 0, sizeof o);
-    for (int i = 0; i < 9; i++) {
-        const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
-        uint64_t v = m.v[w] >> sh;
-        if (sh > 35 && w < 3) v |= m.v[w + 1] << (64 - sh);
-        o.v[i] = (uint32_t)(i < 8 ? (v & 0x1FFFFFFFull) : v);
-    }
-    return o;
-}
-const H::Fr R261 = {{0x2fd4e1568fffff57ull, 0x75bba827a494b01aull, 0x5301fa84819caa80ull, 0x0dc83629563d4475ull}};   // 2^261 mod p
-
-}  // namespace
+#include "prover_common.hpp"
 
 struct lig_trace {
     lig_ctx* c = nullptr;
@@ -318,17 +37,13 @@ struct lig_trace {
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
     hipEvent_t ev_gate = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
     uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
-    static constexpr size_t CHUNK = 512;
-    static constexpr uint32_t GROUP = 64;
 };
-
-#define TRY(x) do { int rc__ = (x); if (rc__ != LIG_OK) return rc__; } while (0)
 
 // The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
 // kernel into a temporary + a copy (as vbn254fr_module does), every hook a device-to-device copy of the rows it names
 // into the witness matrix.  The padding of an initialised variable comes from the encoding stream, 192 draws per init
 // in program order (pad_encoding_random, nonbatch_context.hpp:497-510).
-static int run_batch_program(lig_ctx* c, const lig_synth_job& job, fr* rows_out) {
+int lig_run_batch_program(lig_ctx* c, const lig_synth_job& job, fr* rows_out) {
     const uint32_t l = c->l, k = c->k, pad = k - l;
     hipStream_t s = c->stream;
     uint32_t nvars = 1;
@@ -433,7 +148,7 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
     const size_t R = T->R = T->rows.size();
     T->triples = quad_terms(T->rows);
     for (T->RB = 0; T->RB < R && T->rows[T->RB].kind >= RK_INIT; T->RB++) {}
-    const size_t chunk = lig_trace::CHUNK, groups = (chunk + lig_trace::GROUP - 1) / lig_trace::GROUP;
+    const size_t chunk = lig_tune::CHUNK, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
     TRY(dm((void**)&T->cw, (R + 3) * (size_t)n * 32));
@@ -473,7 +188,7 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
     lig::aes256_expand_host(job->witness_key, rk);
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (T->RB) TRY(run_batch_program(c, *job, T->msgs));
+    if (T->RB) TRY(lig_run_batch_program(c, *job, T->msgs));
     lig::aes256_expand_host(job->witness_key, rk);
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -584,7 +299,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     TRY(lig_internal_encode_2k_rows(c, mlin, 2, s_sha));      // mlin and mquad are adjacent rows: one pass
     if (s_enc != s) HIP_TRY(c, hipStreamWaitEvent(s_enc, c->ev_fork, 0));
     uint64_t absorbed = 0;
-    for (const auto& ch : chunk_schedule(R, lig_trace::CHUNK, 0, 96)) {
+    for (const auto& ch : chunk_schedule(R, lig_tune::CHUNK, 0, 96)) {
         const size_t b = ch.first, nb = ch.second - ch.first;
         TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
@@ -647,14 +362,14 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     fr* code = T->acc; fr* lin = T->acc + n; fr* quad = T->acc + 2 * (size_t)n; fr* tmp = T->acc + 3 * (size_t)n;
     fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
     // group partials of the three k-column accumulators: group g of every chunk adds into slot g, combined once at the end
-    const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
+    const size_t groups = (lig_tune::CHUNK + lig_tune::GROUP - 1) / lig_tune::GROUP;
     fr* p_code = T->parts; fr* p_linH = T->parts + groups * (size_t)n; fr* p_linC = T->parts + 2 * groups * (size_t)n;
     HIP_TRY(c, hipMemsetAsync(T->parts, 0, 3 * groups * (size_t)n * 32, s));
     HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
     fr* rhalf = T->rcw;                                   // chunk x 2k
     // The randomness rows of chunk b+1 (AES sampling: LDS-bound) and their inner products with the witness rows are
     // formed on the side stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
-    const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_trace::CHUNK, 96, 0);
+    const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_tune::CHUNK, 96, 0);
     const size_t n_chunks = sched2.size();
     std::vector<uint64_t> chunk_pos(n_chunks + 1, 0);
     for (size_t ci = 0; ci < n_chunks; ci++) {
@@ -664,7 +379,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     }
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
-        fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
+        fr* rb = T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k;
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
         uint64_t lpos = chunk_pos[ci];
         for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order; zeros after
@@ -698,17 +413,17 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     }
     for (size_t ci = 0; ci < n_chunks; ci++) {
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
-        fr* rb = T->randb + (ci & 1) * lig_trace::CHUNK * (size_t)k;
+        fr* rb = T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k;
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        lig::launch_rlc_accumulate29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_trace::GROUP / 4);
-        lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_trace::GROUP / 4);
+        lig::launch_rlc_accumulate29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);
+        lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
     {   // one combine per accumulator and proof
-        const uint32_t pg = (uint32_t)((lig_trace::CHUNK + lig_trace::GROUP / 4 - 1) / (lig_trace::GROUP / 4));
+        const uint32_t pg = (uint32_t)((lig_tune::CHUNK + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4));
         lig::launch_rlc_combine(s, code, p_code, pg, k);
         lig::launch_rlc_combine(s, linH, p_linH, pg, k);
         lig::launch_rlc_combine(s, linC, p_linC, pg, k);
@@ -801,679 +516,4 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
 }
 
 
-// =====================================================================================================================
-// One trace sharded over the GPUs of a node (BASELINE.json configs[3]).
-//
-// Rows are dealt to ranks in contiguous blocks (never splitting an x,y,z triple); every rank forms, encodes and keeps
-// only its own rows.  Leaf_j hashes ALL rows in commit order, so the hash is column-partitioned: after one all-to-all of
-// codeword column slices rank h owns columns [h*n/W, (h+1)*n/W) of every row, hashes them in rank (= row) order and the
-// n/W leaves per rank are all-gathered; the Merkle tree is then built redundantly on every rank.  The stage-2 tests are
-// sums over rows: every rank accumulates its rows on the low-degree domains (k + 2k + 2k values), the partial sums are
-// all-gathered and added mod p locally (RCCL has no modular reduction).  Opened columns are all-gathered in row order.
-// The collectives are supplied by the caller (lig_comm: torch.distributed over RCCL/xGMI in ligero-prover_amd/dist.py),
-// this file only sees device pointers.  Every rank ends with the same envelope, byte-identical to lig_synth_prove.
-struct lig_shard {
-    lig_ctx* c = nullptr;
-    lig_synth_job job;
-    lig_comm comm;
-    uint32_t rank = 0, world = 1;
-    std::vector<RowDesc> rows;                 // global plan
-    std::vector<size_t> bounds;                // world + 1 row boundaries
-    std::vector<uint64_t> wit_pos, lin_pos;    // stream position of every global row (+1 entry)
-    std::vector<uint64_t> code_ord;            // number of code-test draws before every global row (+1 entry)
-    size_t RB = 0, n_init = 0;                 // leading rows committed by the batch program, of those: init rows
-    size_t R = 0, r0 = 0, Rl = 0, rows_max = 0, ncol = 0;
-    fr *msgs = nullptr, *cw = nullptr, *send = nullptr, *recv = nullptr, *randb = nullptr, *rhalf = nullptr, *acc = nullptr,
-       *parts = nullptr, *accp = nullptr, *accg = nullptr, *dots = nullptr, *smp = nullptr, *smpg = nullptr;
-    uint32_t *sha_state = nullptr, *leaves_slice = nullptr, *leaves = nullptr, *nodes = nullptr, *data_dev = nullptr, *tri_dev = nullptr;
-    lig::f29s* coef_dev = nullptr;
-    std::vector<uint32_t> triples;             // local row indices
-    std::vector<size_t> triple_ord;            // global ordinal of each local triple
-    uint8_t *h_proof = nullptr, *h_enc = nullptr, *h_nodes = nullptr, *h_small = nullptr;
-    size_t h_proof_cap = 0;
-};
-
-static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S);
-int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, const lig_comm* comm, lig_shard** out) {
-    CHECK_CTX(c);
-    if (!job || !out || !comm || world == 0 || rank >= world) return LIG_E_ARG;
-    *out = nullptr;
-    lig_shard* S = new lig_shard();
-    S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world;
-    S->job.batch_ops = nullptr; S->job.batch_data = nullptr;
-    const int rc = shard_prepare_impl(c, job, rank, world, S);
-    if (rc != LIG_OK) { lig_shard_destroy(S); return rc; }
-    *out = S;
-    return LIG_OK;
-}
-static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S) {
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
-    if (l >= k || l < 2 || t > n || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l < k, 192 <= n and world | n");
-    S->ncol = n / world;
-    if (!plan_rows(*job, l, S->rows, S->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
-    const size_t R = S->R = S->rows.size();
-    for (S->RB = 0; S->RB < R && S->rows[S->RB].kind >= RK_INIT; S->RB++) {}
-    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0);
-    for (size_t r = 0; r < R; r++) {
-        const uint8_t kd = S->rows[r].kind;
-        S->wit_pos[r + 1] = S->wit_pos[r] + ((kd == 3 || kd >= RK_INIT) ? 0 : S->rows[r].data);   // z rows and batch rows draw nothing
-        S->lin_pos[r + 1] = S->lin_pos[r] + S->rows[r].data;
-        S->code_ord[r + 1] = S->code_ord[r] + has_code_check(kd);                                    // position in the code-test stream
-    }
-    S->bounds.assign(world + 1, R);
-    S->bounds[0] = 0;
-    for (uint32_t g = 1; g < world; g++) {
-        size_t b = (size_t)(((unsigned __int128)R * g) / world);
-        auto inside_group = [&](uint8_t kd) { return kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ; };
-        while (b < R && inside_group(S->rows[b].kind)) b++;                       // never split a triple / an equality pair
-        S->bounds[g] = std::max(b, S->bounds[g - 1]);
-    }
-    for (uint32_t g = 0; g < world; g++) S->rows_max = std::max(S->rows_max, S->bounds[g + 1] - S->bounds[g]);
-    if (!S->rows_max) S->rows_max = 1;
-    S->r0 = S->bounds[rank]; S->Rl = S->bounds[rank + 1] - S->bounds[rank];
-    const size_t Rl = S->Rl, r0 = S->r0, RM = S->rows_max;
-    {   // quadratic-test terms whose rows are local, with local row indices; triple_ord = position in the quadratic stream
-        const std::vector<uint32_t> all = quad_terms(S->rows);
-        for (size_t i = 0; i < all.size() / 3; i++) {
-            const size_t last = all[3 * i + 2];
-            if (last < r0 || last >= r0 + Rl) continue;
-            S->triples.push_back(all[3 * i] - (uint32_t)r0);
-            S->triples.push_back(all[3 * i + 1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : all[3 * i + 1] - (uint32_t)r0);
-            S->triples.push_back(all[3 * i + 2] - (uint32_t)r0);
-            S->triple_ord.push_back(i);
-        }
-    }
-    const size_t chunk = lig_trace::CHUNK, groups = (chunk + lig_trace::GROUP - 1) / lig_trace::GROUP;
-    auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
-    TRY(dm((void**)&S->msgs, (Rl ? Rl : 1) * (size_t)k * 32));
-    TRY(dm((void**)&S->cw, (Rl + 3) * (size_t)n * 32));
-    TRY(dm((void**)&S->send, RM * (size_t)n * 32));
-    TRY(dm((void**)&S->recv, RM * (size_t)n * 32));
-    TRY(dm((void**)&S->randb, chunk * (size_t)k * 32));
-    TRY(dm((void**)&S->rhalf, chunk * 2 * (size_t)k * 32));
-    TRY(dm((void**)&S->acc, 4 * (size_t)n * 32));
-    TRY(dm((void**)&S->parts, 2 * groups * (size_t)n * 32));
-    TRY(dm((void**)&S->accp, 5 * (size_t)k * 32));
-    TRY(dm((void**)&S->accg, (size_t)world * 5 * k * 32));
-    TRY(dm((void**)&S->dots, (Rl ? Rl : 1) * 32));
-    TRY(dm((void**)&S->smp, (RM + 3) * (size_t)t * 32));
-    TRY(dm((void**)&S->smpg, (size_t)world * RM * t * 32));
-    TRY(dm((void**)&S->sha_state, lig_sha_state_bytes(S->ncol)));
-    TRY(dm((void**)&S->leaves_slice, S->ncol * 32));
-    TRY(dm((void**)&S->leaves, (size_t)n * 32));
-    TRY(dm((void**)&S->nodes, lig_merkle_nodes(n) * 32));
-    TRY(dm((void**)&S->data_dev, (Rl ? Rl : 1) * sizeof(uint32_t)));
-    TRY(dm((void**)&S->tri_dev, (S->triples.size() ? S->triples.size() : 1) * sizeof(uint32_t)));
-    TRY(dm((void**)&S->coef_dev, (Rl + 2 * S->triple_ord.size() + 1) * sizeof(lig::f29s)));
-    S->h_proof_cap = ((size_t)1 << 19) + 3 * (size_t)n * 32 + (R + 3) * (size_t)t * 32;
-    HIP_TRY(c, hipHostMalloc((void**)&S->h_proof, S->h_proof_cap, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void**)&S->h_enc, 3 * (size_t)n * 32, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void**)&S->h_nodes, lig_merkle_nodes(n) * 32, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void**)&S->h_small, ((Rl ? Rl : 1) + 2 * (size_t)l + 3 * (size_t)n + 2 * world) * 32, hipHostMallocDefault));
-    {
-        std::vector<uint32_t> d(Rl);
-        for (size_t r = 0; r < Rl; r++) d[r] = S->rows[r0 + r].data;
-        if (Rl) HIP_TRY(c, hipMemcpyAsync(S->data_dev, d.data(), Rl * 4, hipMemcpyHostToDevice, c->stream));
-        if (!S->triples.empty()) HIP_TRY(c, hipMemcpyAsync(S->tri_dev, S->triples.data(), S->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    // local witness rows: same stream positions as in the single-GPU trace
-    uint32_t rk[60];
-    lig::aes256_expand_host(job->witness_key, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    size_t r_first = 0;
-    if (S->RB) {          // the batch program is small: every rank runs it and keeps the rows it owns
-        fr* all = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&all, S->RB * (size_t)k * sizeof(fr)));
-        const int rc = run_batch_program(c, *job, all);
-        const size_t lo = std::min(r0, S->RB), hi = std::min(r0 + Rl, S->RB);
-        if (rc == LIG_OK && hi > lo) (void)hipMemcpyAsync(S->msgs + (lo - r0) * (size_t)k, all + lo * (size_t)k, (hi - lo) * (size_t)k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream);
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(all);
-        if (rc != LIG_OK) return rc;
-        r_first = hi - lo;
-        lig::aes256_expand_host(job->witness_key, rk);                    // the program used the encoding key
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    for (size_t r = r_first; r < Rl;) {
-        const RowDesc d = S->rows[r0 + r];
-        if (d.kind == 0) {
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[r0 + r], S->msgs + r * k, 1, d.data, k, 0, 1, d.data);
-            r += 1;
-        } else {
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[r0 + r], S->msgs + r * k, 2, d.data, k, 0, 1, d.data);
-            lig::launch_eltwise(c->stream, LIG_OP_MUL, S->msgs + r * k, S->msgs + (r + 1) * k, S->msgs + (r + 2) * k, d.data, fr{}, 0);
-            r += 3;
-        }
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    return LIG_OK;
-}
-
-void lig_shard_destroy(lig_shard* S) {
-    if (!S) return;
-    (void)hipSetDevice(S->c->device);
-    (void)hipStreamSynchronize(S->c->stream);
-    S->c->sha.erase(S->sha_state);
-    for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
-                    (void*)S->parts, (void*)S->accp, (void*)S->accg, (void*)S->dots, (void*)S->smp, (void*)S->smpg, (void*)S->sha_state,
-                    (void*)S->leaves_slice, (void*)S->leaves, (void*)S->nodes, (void*)S->data_dev, (void*)S->tri_dev, (void*)S->coef_dev})
-        (void)hipFree(p);
-    (void)hipHostFree(S->h_proof); (void)hipHostFree(S->h_enc); (void)hipHostFree(S->h_nodes); (void)hipHostFree(S->h_small);
-    delete S;
-}
-
-int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
-    if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
-    lig_ctx* c = S->c;
-    CHECK_CTX(c);
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l, W = S->world;
-    const size_t R = S->R, Rl = S->Rl, r0 = S->r0, RM = S->rows_max, ncol = S->ncol;
-    hipStream_t s = c->stream;
-    std::memset(info, 0, sizeof *info);
-    info->rows = R + 3;
-    const auto t_begin = clk::now();
-    auto t0 = clk::now();
-    auto comm_fail = [&](int rc, const char* what) { c->err = std::string("collective failed: ") + what; return rc ? LIG_E_STATE : LIG_OK; };
-
-    // ---------------- stage 1
-    uint32_t rk[60];
-    lig::aes256_expand_host(S->job.encoding_seed, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    {   // pads of the local stream rows (batch rows carry theirs from the program); position = draws before the row
-        const size_t first = std::max(r0, S->RB), last = r0 + Rl;
-        if (last > first)
-            lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)(S->n_init + (first - S->RB)) * pad, S->msgs + (first - r0) * (size_t)k, last - first, pad, k, l, 1, pad);
-    }
-    uint64_t epos = (uint64_t)(S->n_init + (R - S->RB)) * pad;
-    fr* mask = S->cw + Rl * (size_t)n; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;           // masks: formed by every rank
-    HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, l - 1, 0, 1, 2, 0); epos += l - 1;
-    {
-        H::Fr* tmp = reinterpret_cast<H::Fr*>(S->h_small + (Rl ? Rl : 1) * 32);
-        const size_t cnt = 2 * (size_t)(l - 1);
-        HIP_TRY(c, hipMemcpyAsync(tmp, mlin, cnt * 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        H::Fr sum = H::from_u64(0);
-        for (size_t i = 1; i < cnt; i += 2) sum = H::add(sum, tmp[i]);
-        sum = H::neg(sum);
-        HIP_TRY(c, hipMemcpyAsync(mlin + 2 * (size_t)(l - 1) + 1, &sum, 32, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, l, 0, 1, 2, 0); epos += l;
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
-    if (Rl) TRY(lig_internal_encode_rows(c, S->msgs, S->cw, Rl, false));
-    TRY(lig_encode(c, mask));
-    TRY(lig_internal_encode_2k_rows(c, mlin, 2));          // mlin and mquad are adjacent rows: one pass of 31 launches
-    // column slices: block h of `send` = my rows restricted to rank h's columns
-    for (uint32_t h = 0; h < W && Rl; h++)
-        HIP_TRY(c, hipMemcpy2DAsync(S->send + (size_t)h * RM * ncol, ncol * 32, S->cw + (size_t)h * ncol, (size_t)n * 32, ncol * 32, Rl,
-                                    hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_to_all(S->comm.user, S->send, S->recv, RM * ncol * 32)) return comm_fail(rc, "all_to_all(codeword column slices)");
-    TRY(lig_sha_init(c, S->sha_state, ncol));
-    uint64_t absorbed = 0;
-    for (uint32_t g = 0; g < W; g++) {
-        const size_t rg = S->bounds[g + 1] - S->bounds[g];
-        lig::launch_sha_update_rows(s, S->sha_state, ncol, S->recv + (size_t)g * RM * ncol, ncol, rg, absorbed);
-        absorbed += rg;
-    }
-    lig::launch_sha_update_rows(s, S->sha_state, ncol, mask + (size_t)S->rank * ncol, n, 3, absorbed);
-    absorbed += 3;
-    c->sha[S->sha_state].second = absorbed;
-    TRY(lig_sha_final(c, S->sha_state, S->leaves_slice));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_gather(S->comm.user, S->leaves_slice, S->leaves, ncol * 32)) return comm_fail(rc, "all_gather(leaves)");
-    TRY(lig_merkle_build(c, S->leaves, n, S->nodes));
-    HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    uint8_t ih[32];
-    {
-        const uint8_t z[32] = {0};
-        Sha256().add(z, 32).add("Ligero", 7).finish(ih);
-        Sha256().add("LigetronStage1", 15).add(info->root, 32).add(ih, 32).finish(info->stage1_seed);
-    }
-    info->ms_stage1 = ms_since(t0);
-    t0 = clk::now();
-
-    // ---------------- stage 2
-    const size_t NTl = S->triple_ord.size();
-    {
-        std::vector<H::Fr> rc, rq;
-        const size_t NT = quad_terms(S->rows).size() / 3;
-        FieldStream code(info->stage1_seed), quad(info->stage1_seed);
-        code.next(S->code_ord[R], rc);
-        quad.next(NT, rq);
-        std::vector<lig::f29s> coef(Rl + 2 * NTl + 1);
-        const H::Fr R261sq = H::mul(R261, R261);
-        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
-        for (size_t r = 0; r < Rl; r++) if (has_code_check(S->rows[r0 + r].kind)) coef[r] = to_f29s_host(rc[S->code_ord[r0 + r]], R261);
-        for (size_t i = 0; i < NTl; i++) { coef[Rl + i] = to_f29s_host(rq[S->triple_ord[i]], R261sq); coef[Rl + NTl + i] = to_f29s_host(rq[S->triple_ord[i]], R261); }
-        HIP_TRY(c, hipMemcpyAsync(S->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
-        lig::aes256_expand_host(info->stage1_seed, rk);
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    fr* code = S->acc; fr* lin = S->acc + n; fr* quad = S->acc + 2 * (size_t)n; fr* tmp = S->acc + 3 * (size_t)n;
-    fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
-    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 3 * (size_t)n * 32, s));
-    const size_t groups = (lig_trace::CHUNK + lig_trace::GROUP - 1) / lig_trace::GROUP;
-    for (size_t b = 0; b < Rl; b += lig_trace::CHUNK) {
-        const size_t nb = std::min(lig_trace::CHUNK, Rl - b);
-        HIP_TRY(c, hipMemsetAsync(S->randb, 0, nb * (size_t)k * 32, s));
-        for (size_t r = 0; r < nb;) {          // runs of rows with equal fill are contiguous in the linear stream
-            size_t run = 1;
-            const uint32_t d = S->rows[r0 + b + r].data;
-            while (r + run < nb && S->rows[r0 + b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows(s, c->rk_dev, S->lin_pos[r0 + b + r], S->randb + r * k, run, d, k, 0, 1, d);
-            r += run;
-        }
-        TRY(lig_internal_encode_rows(c, S->randb, S->rhalf, nb, true));
-        lig::launch_rlc_rows29(s, S->cw + b * n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, linC, S->parts,
-                               S->parts + groups * (size_t)n, lig_trace::GROUP / 4);
-        lig::launch_rlc_rows29(s, S->msgs + b * k, k, 1, S->randb, k, nb, k, S->coef_dev + b, code, linH, S->parts,
-                               S->parts + groups * (size_t)n, lig_trace::GROUP / 4);
-    }
-    lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
-    lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
-    // partial sums [code (k) | lin (2k) | quad (2k)] -> every rank -> added mod p
-    HIP_TRY(c, hipMemcpyAsync(S->accp, code, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(S->accp + k, lin, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(S->accp + 3 * (size_t)k, quad, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    H::Fr* dots = reinterpret_cast<H::Fr*>(S->h_small);
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_gather(S->comm.user, S->accp, S->accg, 5 * (size_t)k * 32)) return comm_fail(rc, "all_gather(partial accumulators)");
-    HIP_TRY(c, hipMemsetAsync(S->accp, 0, 5 * (size_t)k * 32, s));
-    lig::launch_rlc_combine(s, S->accp, S->accg, W, 5 * k);
-    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 3 * (size_t)n * 32, s));
-    HIP_TRY(c, hipMemcpyAsync(code, S->accp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(lin, S->accp + k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(quad, S->accp + 3 * (size_t)k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    {   // linear-test constant = -(sum of the message-domain half of the combined accumulator: its even points)
-        lig::launch_sum_elems(s, lin, k, 2, S->dots);
-        HIP_TRY(c, hipMemcpyAsync(dots, S->dots, 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        const H::Fr sum = H::neg(dots[0]);
-        std::memcpy(info->const_sum, sum.v, 32);
-    }
-    TRY(lig_encode(c, code));
-    TRY(lig_internal_extend_2k(c, lin));
-    TRY(lig_internal_extend_2k(c, quad));
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
-    uint8_t* enc = S->h_enc;
-    const size_t enc_bytes = 3 * (size_t)n * 32;
-    HIP_TRY(c, hipMemcpyAsync(enc, S->acc, enc_bytes, hipMemcpyDeviceToHost, s));
-    H::Fr* dec = reinterpret_cast<H::Fr*>(S->h_small + ((Rl ? Rl : 1) + 2 * (size_t)l) * 32);
-    const fr* accs[3] = {code, lin, quad};
-    for (int a3 = 0; a3 < 3; a3++) {
-        HIP_TRY(c, hipMemcpyAsync(tmp, accs[a3], (size_t)n * 32, hipMemcpyDeviceToDevice, s));
-        TRY(lig_decode(c, tmp));
-        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
-    }
-    const size_t n_nodes = lig_merkle_nodes(n);
-    HIP_TRY(c, hipMemcpyAsync(S->h_nodes, S->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
-    const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
-    TRY(lig_sample_init(c, idx.data(), idx.size()));
-    auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
-    info->valid_code = 1;
-    for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
-    {
-        H::Fr a;
-        std::memcpy(a.v, info->const_sum, 32);
-        for (uint32_t i = 0; i < l; i++) a = H::add(a, dec[(size_t)n + i]);
-        info->valid_linear = is_zero(a);
-    }
-    info->valid_quad = 1;
-    for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[2 * (size_t)n + i])) info->valid_quad = 0;
-    const std::vector<uint8_t> sib = decommit(S->h_nodes, (n_nodes + 1) / 2, idx);
-    info->ms_stage2 = ms_since(t0);
-    t0 = clk::now();
-
-    // ---------------- stage 3
-    TRY(lig_gather_rows(c, S->cw, Rl + 3, S->smp));                  // local rows, then the 3 masks
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_gather(S->comm.user, S->smp, S->smpg, RM * (size_t)t * 32)) return comm_fail(rc, "all_gather(opened columns)");
-    char ver[17] = {0};
-    std::memcpy(ver, S->job.version, 16);
-    const size_t smp_bytes = (R + 3) * (size_t)t * 32;
-    const EnvelopeLayout lay = write_envelope(S->h_proof, S->h_proof_cap, ver, S->job.program_hash, S->job.generated_at, k, n, t,
-                                              info->root, sib, idx, enc, smp_bytes);
-    if (lay.total > S->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
-    uint8_t* dst = S->h_proof + lay.samples_off;
-    for (uint32_t g = 0; g < W; g++) {
-        const size_t rg = S->bounds[g + 1] - S->bounds[g];
-        if (rg) HIP_TRY(c, hipMemcpyAsync(dst, S->smpg + (size_t)g * RM * t, rg * (size_t)t * 32, hipMemcpyDeviceToHost, s));
-        dst += rg * (size_t)t * 32;
-    }
-    HIP_TRY(c, hipMemcpyAsync(dst, S->smp + Rl * (size_t)t, 3 * (size_t)t * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    *proof = S->h_proof;
-    *proof_len = lay.total;
-    info->ms_stage3 = ms_since(t0);
-    info->ms_total = ms_since(t_begin);
-    HIP_TRY(c, hipGetLastError());
-    return LIG_OK;
-}
-
-
 }  // extern "C"
-
-// =====================================================================================================================
-// Verifier (src/webgpu_verifier.cpp:263-452 with nonbatch_verifier_context, include/zkp/nonbatch_context.hpp:1081-1388)
-// for the synthetic constraint stream: re-derives both seeds and the sampled columns, re-runs the public constraint
-// stream on the 192 opened columns (column hash, code / linear / quadratic accumulators; the randomness rows are
-// re-generated and encoded, then read at the sampled positions), recommits the Merkle root from the 192 leaves and the
-// sibling hashes, decodes the prover's three polynomials, and evaluates the reference's seven acceptance predicates.
-namespace {
-
-struct PbReader {
-    const uint8_t* p; const uint8_t* end;
-    bool var(uint64_t& v) { v = 0; for (int sh = 0; p < end && sh < 70; sh += 7) { const uint8_t b = *p++; v |= (uint64_t)(b & 0x7f) << sh; if (!(b & 0x80)) return true; } return false; }
-    bool len(PbReader& sub) { uint64_t n; if (!var(n) || n > (uint64_t)(end - p)) return false; sub.p = p; sub.end = p + n; p += n; return true; }
-    bool skip(uint32_t wt) { uint64_t v; PbReader s; if (wt == 0) return var(v); if (wt == 2) return len(s); if (wt == 5) { p += 4; return p <= end; } if (wt == 1) { p += 8; return p <= end; } return false; }
-};
-bool read_digest(PbReader s, uint8_t out[32]) { uint64_t tag; PbReader b; if (!s.var(tag) || tag != 0x0a || !s.len(b) || b.end - b.p != 32) return false; std::memcpy(out, b.p, 32); return true; }
-bool read_fixed(PbReader s, const uint8_t*& data, size_t& nbytes) { data = nullptr; nbytes = 0; if (s.p == s.end) return true; uint64_t tag; PbReader b; if (!s.var(tag) || tag != 0x0a || !s.len(b)) return false; data = b.p; nbytes = (size_t)(b.end - b.p); return true; }
-
-// merkle_tree::recommit (include/zkp/merkle_tree.hpp:232-318) with the canonical sibling order
-bool recommit(size_t P, const std::vector<uint32_t>& idx, const uint8_t* leaf_digests, const std::vector<uint8_t>& sib, uint8_t root[32]) {
-    std::vector<uint8_t> cur(P * 32, 0), nxt(P * 32, 0), known(P, 0), upper(P, 0);
-    for (size_t i = 0; i < idx.size(); i++) { if (idx[i] >= P) return false; known[idx[i]] = 1; std::memcpy(&cur[32 * (size_t)idx[i]], leaf_digests + 32 * i, 32); }
-    size_t used = 0, width = P;
-    while (width > 1) {
-        std::fill(upper.begin(), upper.end(), 0);
-        for (size_t ll = 0; ll < width; ll += 2) {
-            const bool kl = known[ll], kr = known[ll + 1];
-            if (!kl && !kr) continue;
-            uint8_t pair[64];
-            if (kl) std::memcpy(pair, &cur[32 * ll], 32); else { if (32 * (used + 1) > sib.size()) return false; std::memcpy(pair, &sib[32 * used++], 32); }
-            if (kr) std::memcpy(pair + 32, &cur[32 * (ll + 1)], 32); else { if (32 * (used + 1) > sib.size()) return false; std::memcpy(pair + 32, &sib[32 * used++], 32); }
-            Sha256().add(pair, 64).finish(&nxt[32 * (ll / 2)]);
-            upper[ll / 2] = 1;
-        }
-        cur.swap(nxt); known.swap(upper);
-        width /= 2;
-    }
-    if (32 * used != sib.size()) return false;
-    std::memcpy(root, cur.data(), 32);
-    return true;
-}
-
-}  // namespace
-
-extern "C" {
-
-int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_sum[32], const uint8_t* proof, size_t proof_len,
-                     lig_verify_info* out) {
-    CHECK_CTX(c);
-    if (!job || !const_sum || !proof || !out) return LIG_E_ARG;
-    std::memset(out, 0, sizeof *out);
-    const auto t_begin = clk::now();
-    struct Stamp { lig_verify_info* o; decltype(t_begin) t0; ~Stamp() { o->ms_total = ms_since(t0); } } stamp{out, t_begin};
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
-    hipStream_t s = c->stream;
-    // ---- row plan of the public constraint stream
-    std::vector<RowDesc> rows;
-    size_t n_init = 0;
-    if (!plan_rows(*job, l, rows, n_init)) return LIG_E_ARG;
-    const size_t R = rows.size();
-    // ---- parse the envelope (proto/ligero_proof.proto; deserialize_proof, proof_serializer.hpp:193-226)
-    PbReader top{proof, proof + proof_len}, meta{nullptr, nullptr}, body{nullptr, nullptr};
-    while (top.p < top.end) {
-        uint64_t tag;
-        if (!top.var(tag)) return LIG_OK;
-        if (tag == 0x0a) { if (!top.len(meta)) return LIG_OK; }
-        else if (tag == 0x12) { if (!top.len(body)) return LIG_OK; }
-        else if (!top.skip(tag & 7)) return LIG_OK;
-    }
-    if (!body.p || !meta.p) return LIG_OK;
-    uint32_t mk = 0, mn = 0, mt = 0;
-    while (meta.p < meta.end) {
-        uint64_t tag, v;
-        if (!meta.var(tag)) return LIG_OK;
-        if ((tag & 7) == 0) { if (!meta.var(v)) return LIG_OK; if ((tag >> 3) == 6) mk = (uint32_t)v; if ((tag >> 3) == 7) mn = (uint32_t)v; if ((tag >> 3) == 8) mt = (uint32_t)v; }
-        else if (!meta.skip(tag & 7)) return LIG_OK;
-    }
-    if (mk != k || mn != n || mt != t) return LIG_OK;
-    uint8_t root[32] = {0};
-    std::vector<uint8_t> sib;
-    std::vector<uint32_t> pidx;
-    const uint8_t *pcode = nullptr, *plin = nullptr, *pquad = nullptr, *psmp = nullptr;
-    size_t cb = 0, lb = 0, qb = 0, sb = 0;
-    while (body.p < body.end) {
-        uint64_t tag; PbReader f;
-        if (!body.var(tag) || (tag & 7) != 2 || !body.len(f)) return LIG_OK;
-        switch (tag >> 3) {
-            case 1:
-                while (f.p < f.end) {
-                    uint64_t t2; PbReader x;
-                    if (!f.var(t2)) return LIG_OK;
-                    if (t2 == 0x08) { uint64_t v; if (!f.var(v)) return LIG_OK; }
-                    else if (t2 == 0x12) { if (!f.len(x) || !read_digest(x, root)) return LIG_OK; }
-                    else if (t2 == 0x1a) { uint8_t d[32]; if (!f.len(x) || !read_digest(x, d)) return LIG_OK; sib.insert(sib.end(), d, d + 32); if (sib.size() > 32u * t * 40) return LIG_OK; }
-                    else if (t2 == 0x22) { if (!f.len(x)) return LIG_OK; while (x.p < x.end) { uint64_t v; if (!x.var(v) || pidx.size() > t) return LIG_OK; pidx.push_back((uint32_t)v); } }
-                    else if (!f.skip(t2 & 7)) return LIG_OK;
-                }
-                break;
-            case 2: if (!read_fixed(f, pcode, cb)) return LIG_OK; break;
-            case 3: if (!read_fixed(f, plin, lb)) return LIG_OK; break;
-            case 4: if (!read_fixed(f, pquad, qb)) return LIG_OK; break;
-            case 5: if (!read_fixed(f, psmp, sb)) return LIG_OK; break;
-            default: break;
-        }
-    }
-    const size_t vec = (size_t)n * 32, smp_bytes = (R + 3) * (size_t)t * 32;
-    if (cb != vec || lb != vec || qb != vec || sb != smp_bytes || pidx.size() != t) return LIG_OK;
-    // every opened / accumulator element must be a canonical residue
-    auto canonical_all = [](const uint8_t* p, size_t count) { for (size_t i = 0; i < count; i++) { H::Fr v; std::memcpy(v.v, p + 32 * i, 32); if (H::geq(v, H::P)) return false; } return true; };
-    if (!canonical_all(pcode, n) || !canonical_all(plin, n) || !canonical_all(pquad, n) || !canonical_all(psmp, (R + 3) * (size_t)t)) return LIG_OK;
-    out->parsed = 1;
-    // ---- seeds and sample indices (src/webgpu_verifier.cpp:268-293)
-    uint8_t ih[32], seed1[32], seed2[32];
-    {
-        const uint8_t z[32] = {0};
-        Sha256().add(z, 32).add("Ligero", 7).finish(ih);
-        Sha256().add("LigetronStage1", 15).add(root, 32).add(ih, 32).finish(seed1);
-        Sha256().add("LigetronStage2", 15).add(root, 32).add(pcode, vec).add(plin, vec).add(pquad, vec).finish(seed2);
-    }
-    const std::vector<uint32_t> idx = sample_columns(seed2, n, t);
-    out->indices_match = idx == pidx;
-    if (!out->indices_match) return LIG_OK;
-    // ---- device buffers
-    const size_t CH = 512;
-    fr *dS = nullptr, *drand = nullptr, *drcw = nullptr, *drg = nullptr, *dacc = nullptr, *dparts = nullptr, *dpoly = nullptr;
-    uint32_t *dsha = nullptr, *dleaves = nullptr, *dtri = nullptr;
-    lig::f29s* dcoef = nullptr;
-    std::vector<void*> owned;
-    auto dm0 = [&](void** p, size_t bytes, bool zero) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
-    auto dm = [&](void** p, size_t bytes) -> int { return dm0(p, bytes, true); };
-    struct Cleanup { std::vector<void*>& v; lig_ctx* c; void* sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
-    const size_t groups = (CH + lig_trace::GROUP - 1) / lig_trace::GROUP;
-    const std::vector<uint32_t> triples = quad_terms(rows);
-    const size_t NT = triples.size() / 3;
-    TRY(dm((void**)&dS, smp_bytes));
-    TRY(dm0((void**)&drand, 2 * CH * (size_t)k * 32, false));        // double-buffered, every element written by the sampler
-    TRY(dm0((void**)&drcw, CH * (size_t)n * 32, false));
-    TRY(dm((void**)&drg, (R ? R : 1) * (size_t)t * 32));
-    TRY(dm((void**)&dacc, 3 * (size_t)t * 32));
-    TRY(dm((void**)&dparts, 2 * groups * (size_t)t * 32));
-    TRY(dm((void**)&dpoly, 3 * vec));
-    TRY(dm((void**)&dsha, lig_sha_state_bytes(t)));
-    TRY(dm((void**)&dleaves, (size_t)t * 32));
-    TRY(dm((void**)&dtri, (triples.size() ? triples.size() : 1) * 4));
-    TRY(dm((void**)&dcoef, (R + 2 * NT + 1) * sizeof(lig::f29s)));
-    Cleanup cleanup{owned, c, dsha};
-    HIP_TRY(c, hipMemcpyAsync(dS, psmp, smp_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(dpoly, pcode, vec, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(dpoly + n, plin, vec, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(dpoly + 2 * (size_t)n, pquad, vec, hipMemcpyHostToDevice, s));
-    if (!triples.empty()) HIP_TRY(c, hipMemcpyAsync(dtri, triples.data(), triples.size() * 4, hipMemcpyHostToDevice, s));
-    {
-        std::vector<H::Fr> rc, rq;
-        FieldStream code(seed1), quad(seed1);
-        size_t n_code = 0;
-        for (size_t r = 0; r < R; r++) n_code += has_code_check(rows[r].kind);
-        code.next(n_code, rc);
-        quad.next(NT, rq);
-        std::vector<lig::f29s> coef(R + 2 * NT + 1);
-        std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
-        const H::Fr R261sq = H::mul(R261, R261);
-        for (size_t r = 0, ci = 0; r < R; r++) if (has_code_check(rows[r].kind)) coef[r] = to_f29s_host(rc[ci++], R261);
-        for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
-        HIP_TRY(c, hipMemcpyAsync(dcoef, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
-        uint32_t rk[60];
-        lig::aes256_expand_host(seed1, rk);
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    // ---- column hash of the opened columns -> 192 leaves -> recommit (webgpu_verifier.cpp:309-310)
-    TRY(lig_sha_init(c, dsha, t));
-    TRY(lig_sha_update_rows(c, dsha, dS, R + 3));
-    TRY(lig_sha_final(c, dsha, dleaves));
-    std::vector<uint8_t> leaves((size_t)t * 32);
-    HIP_TRY(c, hipMemcpyAsync(leaves.data(), dleaves, leaves.size(), hipMemcpyDeviceToHost, s));
-    // ---- randomness rows of the public stream, encoded, read at the sampled positions; accumulators on 192-vectors
-    TRY(lig_sample_init(c, idx.data(), idx.size()));
-    fr* vc = dacc; fr* vl = dacc + t; fr* vq = dacc + 2 * (size_t)t;
-    // the sampler of chunk b+1 runs on the side stream under the encode of chunk b (double-buffered rows)
-    uint64_t lpos = 0;
-    hipStream_t s2 = c->stream2;
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
-    struct Events { hipEvent_t* a; hipEvent_t* b; ~Events() { for (int i = 0; i < 2; i++) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } } } events{ev_ready, ev_used};
-    for (int i = 0; i < 2; i++) { HIP_TRY(c, hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&ev_used[i], hipEventDisableTiming)); }
-    HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key upload done
-    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
-    const size_t n_chunks = (R + CH - 1) / CH;
-    auto sample_chunk = [&](size_t ci) -> int {
-        const size_t b = ci * CH, nb = std::min(CH, R - b);
-        fr* rb = drand + (ci & 1) * CH * (size_t)k;
-        if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, ev_used[ci & 1], 0));
-        for (size_t r = 0; r < nb;) {
-            size_t run = 1;
-            const uint32_t d = rows[b + r].data;
-            while (r + run < nb && rows[b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
-            lpos += (uint64_t)run * d; r += run;
-        }
-        HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2));
-        return LIG_OK;
-    };
-    if (n_chunks) TRY(sample_chunk(0));
-    for (size_t ci = 0; ci < n_chunks; ci++) {
-        const size_t b = ci * CH, nb = std::min(CH, R - b);
-        fr* rb = drand + (ci & 1) * CH * (size_t)k;
-        if (ci + 1 < n_chunks) TRY(sample_chunk(ci + 1));
-        HIP_TRY(c, hipStreamWaitEvent(s, ev_ready[ci & 1], 0));
-        TRY(lig_internal_encode_rows(c, rb, drcw, nb, false));
-        HIP_TRY(c, hipEventRecord(ev_used[ci & 1], s));
-        TRY(lig_gather_rows(c, drcw, nb, drg + b * t));
-        lig::launch_rlc_rows29(s, dS + b * t, t, 1, drg + b * t, t, nb, t, dcoef + b, vc, vl, dparts, dparts + groups * (size_t)t, lig_trace::GROUP);
-    }
-    lig::launch_quad_rows29(s, dS, t, 1, t, dtri, dcoef + R, dcoef + R + NT, NT, vq);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, dS + R * (size_t)t, nullptr, vc, t, fr{}, 0);          // opened mask columns
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, dS + (R + 1) * (size_t)t, nullptr, vl, t, fr{}, 0);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, dS + (R + 2) * (size_t)t, nullptr, vq, t, fr{}, 0);
-    std::vector<H::Fr> vacc(3 * (size_t)t);
-    HIP_TRY(c, hipMemcpyAsync(vacc.data(), dacc, vacc.size() * 32, hipMemcpyDeviceToHost, s));
-    // ---- decode the prover's polynomials (webgpu_verifier.cpp:355-393)
-    std::vector<H::Fr> dec(3 * (size_t)n);
-    for (int a = 0; a < 3; a++) {
-        TRY(lig_decode(c, dpoly + (size_t)a * n));
-        HIP_TRY(c, hipMemcpyAsync(dec.data() + (size_t)a * n, dpoly + (size_t)a * n, vec, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(c, hipStreamSynchronize(s));
-    // ---- the seven predicates (webgpu_verifier.cpp:412-442)
-    uint8_t vroot[32];
-    size_t P = 1;
-    while (P < n) P <<= 1;
-    out->valid_merkle = recommit(P, idx, leaves.data(), sib, vroot) && !std::memcmp(vroot, root, 32);
-    auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
-    out->valid_code = 1;
-    for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) out->valid_code = 0;
-    {
-        H::Fr a;
-        std::memcpy(a.v, const_sum, 32);
-        if (H::geq(a, H::P)) return LIG_OK;
-        for (uint32_t i = 0; i < l; i++) a = H::add(a, dec[(size_t)n + i]);
-        out->valid_linear = is_zero(a);
-    }
-    out->valid_quad = 1;
-    for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[2 * (size_t)n + i])) out->valid_quad = 0;
-    out->code_equal = out->linear_equal = out->quad_equal = 1;
-    for (uint32_t i = 0; i < t; i++) {
-        if (std::memcmp(pcode + 32 * (size_t)idx[i], &vacc[i], 32)) out->code_equal = 0;
-        if (std::memcmp(plin + 32 * (size_t)idx[i], &vacc[t + i], 32)) out->linear_equal = 0;
-        if (std::memcmp(pquad + 32 * (size_t)idx[i], &vacc[2 * (size_t)t + i], 32)) out->quad_equal = 0;
-    }
-    out->accept = out->valid_merkle && out->valid_code && out->valid_linear && out->valid_quad && out->code_equal && out->linear_equal && out->quad_equal;
-    HIP_TRY(c, hipGetLastError());
-    return LIG_OK;
-}
-
-}  // extern "C"
-
-// =====================================================================================================================
-// Proof file framing: gzip level 6 of the envelope (src/webgpu_prover.cpp:437-457, src/webgpu_verifier.cpp:249-253)
-#include <zlib.h>
-extern "C" {
-
-size_t lig_proof_gzip_bound(size_t len) { return (size_t)compressBound((uLong)len) + 32; }
-
-int lig_proof_gzip(const uint8_t* env, size_t len, uint8_t* out, size_t cap, size_t* out_len) {
-    if ((!env && len) || !out || !out_len) return LIG_E_ARG;
-    z_stream z;
-    std::memset(&z, 0, sizeof z);
-    if (deflateInit2(&z, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return LIG_E_NOMEM;   // 15 + 16: gzip wrapper
-    size_t in_pos = 0, out_pos = 0;
-    int rc = Z_OK;
-    while (rc != Z_STREAM_END) {                       // avail_in / avail_out are 32-bit: feed in slices
-        const size_t in_now = std::min(len - in_pos, (size_t)1 << 30), out_now = std::min(cap - out_pos, (size_t)1 << 30);
-        z.next_in = const_cast<Bytef*>(env + in_pos); z.avail_in = (uInt)in_now;
-        z.next_out = out + out_pos; z.avail_out = (uInt)out_now;
-        rc = deflate(&z, in_pos + in_now == len ? Z_FINISH : Z_NO_FLUSH);
-        in_pos += in_now - z.avail_in; out_pos += out_now - z.avail_out;
-        if (rc == Z_STREAM_ERROR || (rc != Z_STREAM_END && out_pos == cap)) { deflateEnd(&z); return rc == Z_STREAM_ERROR ? LIG_E_ARG : LIG_E_NOMEM; }
-    }
-    deflateEnd(&z);
-    *out_len = out_pos;
-    return LIG_OK;
-}
-
-size_t lig_proof_gunzip_size(const uint8_t* gz, size_t len) {
-    if (!gz || len < 18 || gz[0] != 0x1f || gz[1] != 0x8b) return 0;
-    return (size_t)gz[len - 4] | ((size_t)gz[len - 3] << 8) | ((size_t)gz[len - 2] << 16) | ((size_t)gz[len - 1] << 24);
-}
-
-int lig_proof_gunzip(const uint8_t* gz, size_t len, uint8_t* out, size_t cap, size_t* out_len) {
-    if (!gz || !out || !out_len) return LIG_E_ARG;
-    z_stream z;
-    std::memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, 15 + 16) != Z_OK) return LIG_E_NOMEM;
-    size_t in_pos = 0, out_pos = 0;
-    int rc = Z_OK;
-    while (rc != Z_STREAM_END) {
-        const size_t in_now = std::min(len - in_pos, (size_t)1 << 30), out_now = std::min(cap - out_pos, (size_t)1 << 30);
-        z.next_in = const_cast<Bytef*>(gz + in_pos); z.avail_in = (uInt)in_now;
-        z.next_out = out + out_pos; z.avail_out = (uInt)out_now;
-        rc = inflate(&z, Z_NO_FLUSH);
-        in_pos += in_now - z.avail_in; out_pos += out_now - z.avail_out;
-        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&z); return rc == Z_BUF_ERROR && out_pos == cap ? LIG_E_NOMEM : LIG_E_ARG; }
-        if (rc == Z_OK && in_now == z.avail_in && out_now == z.avail_out) { inflateEnd(&z); return out_pos == cap ? LIG_E_NOMEM : LIG_E_ARG; }   // no progress
-    }
-    inflateEnd(&z);
-    *out_len = out_pos;
-    return LIG_OK;
-}
-
-}  // extern "C"
-
