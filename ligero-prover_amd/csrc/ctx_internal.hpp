@@ -14,11 +14,7 @@ struct lig_ctx {
     int device = 0;
     uint32_t l = 0, k = 0, n = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // side stream: randomness-row forming overlapped with encodes
-    // CU-partitioned pair for stage 1: the column hash is a latency-bound chain with only n/64 waves; it gets its own
-    // 32 CUs (4 waves per SIMD there) while the row encodes run on the other 224 CUs -- co-residing the two kernels
-    // on the same CUs was measured slower than running them back to back (instruction cache + issue contention).
-    hipStream_t stream_sha = nullptr, stream_enc = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: column hash and samplers, overlapped with the encodes on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2
     std::string err;

@@ -167,31 +167,7 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     if ((rc = make_plan(c, c->plan[LIG_SIZE_2K], 2 * k, w2k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan_half, 2 * k, H::mul(w4k, w4k))) != LIG_OK) return rc;     // the subgroup <w_n^2>, order 2k
-    {
-        const char* e = std::getenv("LIG_SIDE_PRIO");
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e && std::atoi(e)) HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
-        else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    }
-    {   // Optional CU partition for stage 1 (LIG_SHA_CUS_EVERY=e: every e-th CU runs the column hash, the rest the encodes).
-        // OFF by default: measured on MI355X (profiles/r01_overlap_experiments.md) the proof time is the same with the hash
-        // on 32/64 dedicated CUs, co-resident, or merely stream-overlapped -- the chip is at its power/VALU-issue limit, so
-        // the total instruction count, not the placement, sets the time.
-        hipDeviceProp_t prop;
-        HIP_TRY(c, hipGetDeviceProperties(&prop, device));
-        const int cus = prop.multiProcessorCount;
-        const char* e = std::getenv("LIG_SHA_CUS_EVERY");
-        const int every = e ? std::atoi(e) : 0;
-        std::vector<uint32_t> m_sha((cus + 31) / 32, 0), m_enc((cus + 31) / 32, 0);
-        for (int i = 0; i < cus; i++) ((every > 0 && i % every == every - 1) ? m_sha : m_enc)[i / 32] |= 1u << (i % 32);
-        if (every <= 0 || hipExtStreamCreateWithCUMask(&c->stream_sha, (uint32_t)m_sha.size(), m_sha.data()) != hipSuccess ||
-            hipExtStreamCreateWithCUMask(&c->stream_enc, (uint32_t)m_enc.size(), m_enc.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            if (c->stream_sha) { (void)hipStreamDestroy(c->stream_sha); c->stream_sha = nullptr; }
-            c->stream_enc = nullptr;      // fall back: hash on the side stream, encodes on the main stream
-        }
-    }
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));      // side stream: column hash, samplers
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->fast = lig::encode_fast_supported(k);
@@ -212,8 +188,6 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream_sha) (void)hipStreamDestroy(c->stream_sha);
-    if (c->stream_enc) (void)hipStreamDestroy(c->stream_enc);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

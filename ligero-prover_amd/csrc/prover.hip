@@ -288,8 +288,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     // b+1 is being encoded (the hash has only n = 32768 lanes of parallelism -- 512 waves -- and would otherwise
     // leave most of the chip idle for its whole duration).  Row order = hash order is preserved by stream order.
     hipStream_t s2 = c->stream2;
-    hipStream_t s_sha = c->stream_sha ? c->stream_sha : c->stream2;      // 32 CUs of their own when CU masks are available
-    hipStream_t s_enc = c->stream_enc ? c->stream_enc : s;               // the other 224 CUs
+    hipStream_t s_sha = s2, s_enc = s;      // (dedicated CUs for the hash via CU-masked streams were measured: no gain, profiles/r01_overlap_experiments.md)
     TRY(lig_sha_init(c, T->sha_state, n));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
@@ -297,7 +296,6 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     // first chunk's encode (the hash of chunk 0 is queued behind them and has to wait for that encode anyway).
     TRY(lig_internal_encode_generic(c, mask, s_sha));
     TRY(lig_internal_encode_2k_rows(c, mlin, 2, s_sha));      // mlin and mquad are adjacent rows: one pass
-    if (s_enc != s) HIP_TRY(c, hipStreamWaitEvent(s_enc, c->ev_fork, 0));
     uint64_t absorbed = 0;
     for (const auto& ch : chunk_schedule(R, lig_tune::CHUNK, 0, 96)) {
         const size_t b = ch.first, nb = ch.second - ch.first;
@@ -316,10 +314,6 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
             lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
         }
         absorbed += nb;
-    }
-    if (s_enc != s) {                       // the main stream continues after the last encode
-        HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
-        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     }
     mark("encode message rows");
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
