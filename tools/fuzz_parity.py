@@ -1,5 +1,6 @@
 """One-off differential fuzz: random trace shapes (and random batch programs) through the HIP prover and the oracle at
-k = 512; envelopes must be identical.  python tools/fuzz_parity.py [cases] [seed]"""
+k = 512 (or LIG_FUZZ_K = 1024 / 2048 / 4096 / 8192); envelopes must be identical.  python tools/fuzz_parity.py [cases] [seed]"""
+import os
 import ctypes as C
 import random
 import sys
@@ -9,7 +10,9 @@ import hip_lib
 import oracle_lib as ol
 
 amd = hip_lib.load()
-L_, K_, N_ = 320, 512, 2048
+K_ = int(os.environ.get("LIG_FUZZ_K", "512"))
+L_, N_ = K_ - 192, 4 * K_
+SCALE = K_ // 512
 P = ol.P
 
 
@@ -45,8 +48,8 @@ def main(cases, seed):
     rng = random.Random(seed)
     c = amd.Context(L_, K_, N_)
     for i in range(cases):
-        n_lin = rng.choice([0, 1, rng.randint(0, 2000), rng.randint(0, 400000)])
-        n_quad = rng.choice([0, rng.randint(0, 1000), rng.randint(0, 120000)])
+        n_lin = rng.choice([0, 1, rng.randint(0, 2000 * SCALE), rng.randint(0, 400000 * SCALE // (SCALE * SCALE) * SCALE)])
+        n_quad = rng.choice([0, rng.randint(0, 1000 * SCALE), rng.randint(0, 120000 * SCALE // (SCALE * SCALE) * SCALE)])
         ts = rng.randint(0, 1 << 40)
         prog = random_program(rng) if rng.random() < 0.5 else None
         oj = ol.make_job(L_, K_, N_, 192, n_lin, n_quad, generated_at=ts, threads=8)
