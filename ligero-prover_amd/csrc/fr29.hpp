@@ -80,33 +80,17 @@ __device__ __forceinline__ uint32_t f29_p0_opaque() {
 
 // Montgomery product a*b/2^261 mod p.  a: lazy, limbs < 1.25 * 2^31 (top limb < 2^31); b: normalised, < p.
 // Result: normalised limbs, value < a*p/2^261 + p  (< 1.2 p for value(a) < 32 p).
-// 81 + 81 v_mad_u64_u32 chained through one 64-bit accumulator, 9 v_mul_lo_u32, 17 v_lshrrev_b64.
+// 81 + 81 v_mad_u64_u32 chained through one 64-bit accumulator, 9 v_mul_lo_u32, 17 v_lshrrev_b64.  The columns are
+// written as inline-asm blocks: left to itself hipcc starts every column in a fresh accumulator and joins it to the
+// carried sum with a v_lshl_add_u64 (17 extra quarter-rate instructions per product, to shorten a dependency chain that
+// four waves per SIMD hide anyway).
 // Column bound: 9 * (1.25*2^31 * 2^29) + 9 * 2^58 + carry < 2^64.
 __device__ __forceinline__ f29 f29_montmul(const f29& a, const f29& b) {
     uint32_t m[9];
     f29 t;
     uint64_t acc = 0;
     const uint32_t p0 = f29_p0_opaque();
-#pragma unroll
-    for (int c = 0; c < 9; c++) {
-#pragma unroll
-        for (int i = 0; i <= c; i++) acc = mad64(a.v[i], b.v[c - i], acc);
-#pragma unroll
-        for (int i = 0; i < c; i++) acc = mad64(m[i], F29_P(c - i), acc);
-        m[c] = ((uint32_t)acc * F29_N0) & F29_MASK;
-        acc = mad64(m[c], p0, acc);
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int c = 9; c < 17; c++) {
-#pragma unroll
-        for (int i = c - 8; i <= 8; i++) acc = mad64(a.v[i], b.v[c - i], acc);
-#pragma unroll
-        for (int i = c - 8; i <= 8; i++) acc = mad64(m[i], F29_P(c - i), acc);
-        t.v[c - 9] = (uint32_t)acc & F29_MASK;
-        acc >>= 29;
-    }
-    t.v[8] = (uint32_t)acc;
+#include "fr29_montmul_gen.hpp"      // the 17 columns, one chained v_mad_u64_u32 block each (tools/gen_fr29_montmul.py)
     return t;
 }
 
