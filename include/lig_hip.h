@@ -161,6 +161,10 @@ typedef struct {
     char     version[16];            /* "1.5.0" */
     const lig_batch_op *batch_ops; uint64_t n_batch_ops;      /* NULL / 0: no batch rows; read by prepare and verify only */
     const uint8_t *batch_data;     uint64_t batch_data_bytes;
+    /* public arguments of the instance after arg0 = "Ligero\0" (src/webgpu_prover.cpp:110-168): n_public_args byte strings
+     * back to back in the form the reference holds them in input_args (lig_public_arg_bytes converts the JSON forms);
+     * NULL / 0: none.  They enter the proof through instance_hash -> stage1_seed.  Copied by prepare. */
+    const uint8_t *public_args; const uint64_t *public_arg_lens; uint64_t n_public_args;
 } lig_synth_job;
 typedef struct {
     uint8_t  root[32], stage1_seed[32], stage2_seed[32], const_sum[32];
@@ -180,7 +184,13 @@ void lig_trace_destroy(lig_trace *trace);
 
 /* ==== verifier for the same synthetic stream (src/webgpu_verifier.cpp:263-452, nonbatch_verifier_context): returns
  * LIG_OK with out->accept = 1 iff the reference's seven predicates hold; a malformed envelope gives accept = 0
- * (parsed = 0), not an error.  const_sum is the public constant of the linear test (linear_sums upstream). ==== */
+ * (parsed = 0), not an error.
+ * The constant of the linear test is PUBLIC data upstream: the verifier re-runs the constraint stream and accumulates
+ * linear_sums itself (src/webgpu_verifier.cpp:318).  The synthetic stream's public statement is "the committed witness is
+ * the AES-256-CTR field stream of job->witness_key" (one linear constraint w_i = b_i per slot), so the verifier derives
+ * the constant -sum_i rho_i b_i from the job alone: it regenerates b from witness_key and the coefficients rho from the
+ * stage-1 seed.  const_sum == NULL selects that (the sound mode).  A non-NULL const_sum is used as given instead: the
+ * hook for a caller whose own constraint generator produced the rows (lig_rows_*) and therefore the constant. ==== */
 typedef struct {
     int32_t parsed, indices_match;
     int32_t valid_merkle, valid_code, valid_linear, valid_quad, code_equal, linear_equal, quad_equal;   /* webgpu_verifier.cpp:412-442 */
@@ -188,8 +198,61 @@ typedef struct {
     int32_t reserved;
     double  ms_total;                /* wall time of the call */
 } lig_verify_info;
-int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t const_sum[32], const uint8_t *proof, size_t proof_len,
+int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t *const_sum /* NULL: derived */, const uint8_t *proof, size_t proof_len,
                      lig_verify_info *out);
+
+/* ==== transcript helpers (host only, no GPU work): what a driver needs to stay byte-compatible with the reference ==== */
+enum { LIG_ARG_I64 = 0, LIG_ARG_STR = 1, LIG_ARG_HEX = 2 };
+/* one JSON "args" entry -> the bytes the reference appends to input_args (src/webgpu_prover.cpp:116-146): i64 (decimal
+ * text) = 8 little-endian bytes, str = the characters plus the terminating NUL, hex (optional 0x, odd length gets a leading
+ * 0) = the decoded bytes.  Returns LIG_E_ARG for malformed text or a too small buffer (*len = needed size). */
+int lig_public_arg_bytes(int kind, const char *text, uint8_t *out, size_t cap, size_t *len);
+/* instance_hash over arg0 = "Ligero\0" followed by the given public arguments (src/webgpu_prover.cpp:162-168) */
+int lig_instance_hash(const uint8_t *args, const uint64_t *lens, size_t n_args, uint8_t out[32]);
+/* hash_random_engine(seed) + portable_sample + sort (src/webgpu_prover.cpp:343-351): the t opened columns */
+int lig_sample_columns(const uint8_t seed[32], uint32_t n, uint32_t t, uint32_t *out_sorted);
+
+/* ==== the same three-stage prover over rows SUPPLIED BY THE CALLER: the entry a row-batching driver of the reference's
+ * constraint generator uses.  It replaces the per-row callbacks of
+ * include/zkp/nonbatch_context.hpp:445-471 (stage 1), :654-780 (stage 2) and :924-970 (stage 3); the rows are what
+ * witness_manager hands to those callbacks (include/zkp/backend/witness_manager.hpp:200-269), in commit order.
+ *   lig_rows_begin   takes the job: row kinds + the rows x k message matrix (host or device memory).  A host matrix is
+ *                    uploaded asynchronously on a copy stream, chunk by chunk, and each chunk is encoded as soon as it has
+ *                    arrived (pinned host memory makes the copy truly asynchronous; the memory must stay valid until
+ *                    lig_rows_commit returns).
+ *   lig_rows_commit  stage 1: pads of the rows flagged LIG_ROW_DRAW_PAD from the encoding stream (pad_encoding_random, in
+ *                    commit order), the three mask rows, encode, column hash, Merkle root, stage-1 seed.  The caller now
+ *                    derives its linear-test randomness from stage1_seed (the reference re-runs the guest for that).
+ *   lig_rows_prove   stage 2 + 3 with the caller's randomness rows (rows x k; the row of a batch-kind row must be zero) and
+ *                    the public constant of the linear test (linear_sums, src/webgpu_prover.cpp:307).
+ * Row kinds: LINEAR rows stand alone; QX,QY,QZ / BQX,BQY,BQZ are consecutive triples (z = x*y); EQX,EQY a consecutive
+ * pair; INIT and BIT stand alone.  Code-test coefficients are drawn per row (not for EQ rows), quadratic-test
+ * coefficients per triple / pair / bit row, from the streams keyed by stage1_seed, exactly as lig_synth_prove does. ==== */
+enum {
+    LIG_ROW_LINEAR = 0, LIG_ROW_QX = 1, LIG_ROW_QY = 2, LIG_ROW_QZ = 3, LIG_ROW_INIT = 4, LIG_ROW_BIT = 5, LIG_ROW_EQX = 6,
+    LIG_ROW_EQY = 7, LIG_ROW_BQX = 8, LIG_ROW_BQY = 9, LIG_ROW_BQZ = 10,
+    LIG_ROW_DRAW_PAD = 0x80      /* or-ed in: slots [l, k) of this row are drawn from the encoding stream by the library */
+};
+typedef struct {
+    uint64_t rows;                   /* committed rows, the 3 mask rows excluded */
+    const uint8_t *kinds;            /* one byte per row (host memory) */
+    const void *msgs;                /* rows x k elements, row-major */
+    int32_t  msgs_on_device;         /* 0: host memory (uploaded inside the timed path), 1: device memory */
+    int32_t  reserved;
+    uint8_t  encoding_seed[32];
+    uint8_t  program_hash[32];
+    int64_t  generated_at;
+    char     version[16];
+    const uint8_t *public_args; const uint64_t *public_arg_lens; uint64_t n_public_args;    /* as in lig_synth_job */
+} lig_rows_job;
+int lig_rows_begin(lig_ctx *ctx, const lig_rows_job *job, lig_trace **out);
+int lig_rows_commit(lig_trace *trace, uint8_t root[32], uint8_t stage1_seed[32]);
+int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, const uint8_t const_sum[32],
+                   const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+/* rows x k dense randomness rows on the device: row r = per_row[r] successive elements of the AES-256-CTR field stream
+ * keyed by key32 (row r starts where row r-1 ended, the first at first_elem), zeros up to k -- the linear-test
+ * coefficient rows of the synthetic stream, for callers that feed lig_rows_prove from the device. */
+int lig_rng_fill_rows(lig_ctx *ctx, const uint8_t *key32, uint64_t first_elem, const uint32_t *per_row_host, size_t rows, void *out);
 
 /* ==== proof file framing (src/webgpu_prover.cpp:437-457 writes gzip(level 6) of the serialized envelope with
  * Boost.iostreams; src/webgpu_verifier.cpp:249-253 reads it back).  Host-only helpers on zlib: the output is a standard

@@ -30,7 +30,13 @@ EXPORTS = [
     "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
     "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify",
     "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
+    "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rng_fill_rows",
+    "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
 ]
+
+ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
+ROW_DRAW_PAD = 0x80
+ARG_I64, ARG_STR, ARG_HEX = 0, 1, 2
 
 
 class VerifyInfo(C.Structure):
@@ -48,7 +54,32 @@ class SynthJob(C.Structure):
     _fields_ = [("n_linear", C.c_uint64), ("n_quad", C.c_uint64), ("encoding_seed", C.c_uint8 * 32),
                 ("witness_key", C.c_uint8 * 32), ("program_hash", C.c_uint8 * 32), ("generated_at", C.c_int64),
                 ("version", C.c_char * 16),
-                ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64)]
+                ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64),
+                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64)]
+
+    def set_public_args(self, args):
+        """args: list of byte strings in input_args form (see public_arg_bytes); kept alive on the job object"""
+        _attach_public_args(self, args)
+
+
+class RowsJob(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("kinds", C.c_void_p), ("msgs", C.c_void_p), ("msgs_on_device", C.c_int32),
+                ("reserved", C.c_int32), ("encoding_seed", C.c_uint8 * 32), ("program_hash", C.c_uint8 * 32),
+                ("generated_at", C.c_int64), ("version", C.c_char * 16),
+                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64)]
+
+    def set_public_args(self, args):
+        _attach_public_args(self, args)
+
+
+def _attach_public_args(job, args):
+    args = [bytes(a) for a in (args or [])]
+    blob = np.frombuffer(b"".join(args) or b"\0", dtype=np.uint8).copy()
+    lens = np.array([len(a) for a in args] or [0], dtype=np.uint64)
+    job._pub_keep = (blob, lens)
+    job.public_args = blob.ctypes.data if args else None
+    job.public_arg_lens = lens.ctypes.data if args else None
+    job.n_public_args = len(args)
 
 
 class ProofInfo(C.Structure):
@@ -130,6 +161,13 @@ def load_library():
     L.lig_shard_prove.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_shard_destroy.argtypes = [vp]
     L.lig_shard_destroy.restype = None
+    L.lig_rows_begin.argtypes = [vp, C.POINTER(RowsJob), C.POINTER(vp)]
+    L.lig_rows_commit.argtypes = [vp, vp, vp]
+    L.lig_rows_prove.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
+    L.lig_rng_fill_rows.argtypes = [vp, vp, u64, vp, sz, vp]
+    L.lig_public_arg_bytes.argtypes = [C.c_int, C.c_char_p, vp, sz, C.POINTER(sz)]
+    L.lig_instance_hash.argtypes = [vp, vp, sz, vp]
+    L.lig_sample_columns.argtypes = [vp, u32, u32, vp]
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -137,6 +175,40 @@ def load_library():
 
 class LigError(RuntimeError):
     pass
+
+
+# ---- host-only transcript helpers (no GPU needed)
+def public_arg_bytes(kind, text):
+    """one JSON "args" entry ({"i64": ..} / {"str": ..} / {"hex": ..}) -> the bytes the reference hashes"""
+    L = load_library()
+    kind = {"i64": ARG_I64, "str": ARG_STR, "hex": ARG_HEX}.get(kind, kind)
+    ln = C.c_size_t()
+    txt = str(text).encode()
+    L.lig_public_arg_bytes(kind, txt, None, 0, C.byref(ln))
+    buf = (C.c_uint8 * max(1, ln.value))()
+    if L.lig_public_arg_bytes(kind, txt, buf, ln.value, C.byref(ln)) != 0:
+        raise LigError("malformed public argument %r" % (text,))
+    return bytes(buf[:ln.value])
+
+
+def instance_hash(args):
+    L = load_library()
+    args = [bytes(a) for a in args]
+    blob = np.frombuffer(b"".join(args) or b"\0", dtype=np.uint8).copy()
+    lens = np.array([len(a) for a in args] or [0], dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint8)
+    if L.lig_instance_hash(_hptr(blob), _hptr(lens), len(args), _hptr(out)) != 0:
+        raise LigError("lig_instance_hash failed")
+    return out.tobytes()
+
+
+def sample_columns(seed, n, t=192):
+    L = load_library()
+    s = np.frombuffer(bytes(seed), dtype=np.uint8).copy()
+    out = np.zeros(min(t, n), dtype=np.uint32)
+    if L.lig_sample_columns(_hptr(s), n, t, _hptr(out)) != 0:
+        raise LigError("lig_sample_columns failed")
+    return out
 
 
 def _hptr(a):
@@ -254,9 +326,10 @@ class Context:
 
     # ---- batched prover over a synthetic trace
     @staticmethod
-    def make_job(n_linear, n_quad=0, synth_seed=1, generated_at=0, encoding_seed=None):
+    def make_job(n_linear, n_quad=0, synth_seed=1, generated_at=0, encoding_seed=None, public_args=None):
         import hashlib
         job = SynthJob()
+        job.set_public_args(public_args)
         job.n_linear, job.n_quad, job.generated_at = n_linear, n_quad, generated_at
         es = bytes(range(32)) if encoding_seed is None else bytes(encoding_seed)
         wk = hashlib.sha256(b"lig-synth" + int(synth_seed).to_bytes(8, "little")).digest()
@@ -311,12 +384,62 @@ class Context:
         return C.string_at(proof, ln.value), info
 
     def synth_verify(self, job, const_sum, proof):
-        """-> VerifyInfo (accept = 1 iff the reference's seven verifier predicates hold)"""
+        """-> VerifyInfo (accept = 1 iff the reference's seven verifier predicates hold).  const_sum=None: the verifier
+        derives the constant of the linear test from the public statement (the sound mode)"""
         info = VerifyInfo()
-        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy()
+        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy() if const_sum is not None else None
         pb = np.frombuffer(bytes(proof), dtype=np.uint8).copy()
         self.check(self.L.lig_synth_verify(self.h, C.byref(job), _hptr(cs), _hptr(pb), len(pb), C.byref(info)))
         return info
+
+    # ---- the same prover over rows supplied by the caller (lig_rows_*)
+    def rows_begin(self, kinds, msgs, on_device=False, encoding_seed=None, generated_at=0, public_args=None, program_hash=None):
+        """kinds: uint8 array (ROW_KINDS | ROW_DRAW_PAD); msgs: device pointer (on_device) or a (rows, k, 8) uint32 host array.
+        -> (trace, keepalive); keep `keepalive` referenced until rows_commit has returned"""
+        kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+        job = RowsJob()
+        job.rows = len(kinds)
+        job.kinds = kinds.ctypes.data if len(kinds) else None
+        if on_device:
+            job.msgs, keep = (msgs.value if hasattr(msgs, "value") else int(msgs)), (kinds,)
+        else:
+            msgs = np.ascontiguousarray(msgs, dtype=np.uint32)
+            job.msgs, keep = (msgs.ctypes.data if msgs.size else None), (kinds, msgs)
+        job.msgs_on_device = int(bool(on_device))
+        es = bytes(range(32)) if encoding_seed is None else bytes(encoding_seed)
+        ph = bytes(32) if program_hash is None else bytes(program_hash)
+        for i in range(32):
+            job.encoding_seed[i] = es[i]
+            job.program_hash[i] = ph[i]
+        job.generated_at = generated_at
+        job.version = b"1.5.0"
+        job.set_public_args(public_args)
+        t = C.c_void_p()
+        self.check(self.L.lig_rows_begin(self.h, C.byref(job), C.byref(t)))
+        return t, keep + (job,)
+
+    def rows_commit(self, trace):
+        root, seed = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+        self.check(self.L.lig_rows_commit(trace, _hptr(root), _hptr(seed)))
+        return root.tobytes(), seed.tobytes()
+
+    def rows_prove(self, trace, rands, const_sum, on_device=False, copy=True):
+        proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
+        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy()
+        if on_device:
+            rp = rands
+        else:
+            rands = np.ascontiguousarray(rands, dtype=np.uint32)
+            rp = C.c_void_p(rands.ctypes.data if rands.size else None)
+        self.check(self.L.lig_rows_prove(trace, rp, int(bool(on_device)), _hptr(cs), C.byref(proof), C.byref(ln), C.byref(info)))
+        if not copy:
+            return (C.addressof(proof.contents), ln.value), info
+        return C.string_at(proof, ln.value), info
+
+    def rng_fill_rows(self, key, first_elem, per_row, out):
+        k = np.frombuffer(bytes(key), dtype=np.uint8).copy()
+        pr = np.ascontiguousarray(per_row, dtype=np.uint32)
+        self.check(self.L.lig_rng_fill_rows(self.h, _hptr(k), first_elem, _hptr(pr), len(pr), out))
 
     def trace_destroy(self, trace):
         self.L.lig_trace_destroy(trace)

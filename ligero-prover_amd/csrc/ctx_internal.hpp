@@ -15,6 +15,7 @@ struct lig_ctx {
     uint32_t l = 0, k = 0, n = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: column hash and samplers, overlapped with the encodes on `stream`
+    hipStream_t stream3 = nullptr;            // copy stream: host rows of lig_rows_begin arrive here under the encodes
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2
     std::string err;
@@ -24,7 +25,7 @@ struct lig_ctx {
     std::vector<void*> owned;                 // device tables freed at destroy
     fr* scratch_y = nullptr; fr* scratch_z = nullptr; size_t scratch_rows = 0;
     std::unordered_map<void*, std::pair<size_t, uint64_t>> sha;   // state ptr -> (n_inst, rows absorbed)
-    uint32_t* sample_idx = nullptr; size_t sample_count = 0;
+    uint32_t* sample_idx = nullptr; size_t sample_count = 0, sample_cap = 0;
     uint32_t* rk_dev = nullptr;               // 60 AES round-key words
     fr* small_dev = nullptr;                  // staging for per-call scalars (rc/rq/tables)
     size_t small_cap = 0;
@@ -40,6 +41,8 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
 int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t on = nullptr);
 int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on = nullptr);
+// make the shared encode scratch large enough for `rows` rows per launch group (all context streams are drained first)
+int lig_internal_reserve_scratch(lig_ctx* c, size_t rows);
 
 // every entry point may be called from any host thread (bench.py proves from worker threads): the context's device is made
 // current for the calling thread first -- HIP streams and allocations are only usable with their own device current

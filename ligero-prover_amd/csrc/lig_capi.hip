@@ -18,6 +18,7 @@
 
 namespace lig {
 void aes_upload_tables();
+void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
 }
 
 namespace H = lig::host;
@@ -168,6 +169,7 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan_half, 2 * k, H::mul(w4k, w4k))) != LIG_OK) return rc;     // the subgroup <w_n^2>, order 2k
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));      // side stream: column hash, samplers
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));      // copy stream
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->fast = lig::encode_fast_supported(k);
@@ -188,6 +190,7 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -245,7 +248,10 @@ int lig_read(lig_ctx* c, void* host_dst, const void* src, size_t bytes) {
 // ---------------------------------------------------------------- transforms
 static int ensure_scratch(lig_ctx* c, size_t rows) {
     if (rows <= c->scratch_rows) return LIG_OK;
+    // the scratch is shared by every stream of the context (encodes may run on `on` streams): drain them all before freeing
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    if (c->stream3) HIP_TRY(c, hipStreamSynchronize(c->stream3));
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z);
     c->scratch_y = c->scratch_z = nullptr; c->scratch_rows = 0;
     HIP_TRY(c, hipMalloc((void**)&c->scratch_y, 2 * rows * (size_t)c->k * sizeof(fr)));   // Y and C
@@ -255,6 +261,8 @@ static int ensure_scratch(lig_ctx* c, size_t rows) {
 }
 
 }  // extern "C"
+
+int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ensure_scratch(c, rows) : ensure_scratch(c, rows < 64 ? rows : 64); }
 
 // shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
 // codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
@@ -487,10 +495,15 @@ int lig_sample_init(lig_ctx* c, const uint32_t* host_idx, size_t count) {
     CHECK_CTX(c);
     if (!host_idx || !count) return LIG_E_ARG;
     for (size_t i = 0; i < count; i++) if (host_idx[i] >= c->n) FAIL(c, LIG_E_ARG, "sample_init: index out of range");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(c->sample_idx); c->sample_idx = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&c->sample_idx, count * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemcpy(c->sample_idx, host_idx, count * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (count > c->sample_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
+        (void)hipFree(c->sample_idx); c->sample_idx = nullptr; c->sample_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->sample_idx, count * sizeof(uint32_t)));
+        c->sample_cap = count;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->sample_idx, host_idx, count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));        // host_idx may be a temporary
     c->sample_count = count;
     return LIG_OK;
 }
@@ -575,6 +588,24 @@ int lig_rng_fill(lig_ctx* c, const uint8_t* key32, uint64_t first_elem, void* ou
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     lig::launch_rng_fill(c->stream, c->rk_dev, first_elem, (fr*)out, count);
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+int lig_rng_fill_rows(lig_ctx* c, const uint8_t* key32, uint64_t first_elem, const uint32_t* per_row_host, size_t rows, void* out) {
+    CHECK_CTX(c);
+    if (!key32 || (rows && (!out || !per_row_host))) return LIG_E_ARG;
+    for (size_t r = 0; r < rows; r++) if (per_row_host[r] > c->k) FAIL(c, LIG_E_ARG, "rng_fill_rows: more elements than a row holds");
+    uint32_t rk[60];
+    lig::aes256_expand_host(key32, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t pos = first_elem;
+    for (size_t r = 0; r < rows;) {           // runs of rows with equal fill are one launch
+        size_t run = 1;
+        while (r + run < rows && per_row_host[r + run] == per_row_host[r]) run++;
+        lig::launch_rng_fill_rows_dense(c->stream, c->rk_dev, pos, (fr*)out + r * (size_t)c->k, run, per_row_host[r], c->k);
+        pos += (uint64_t)run * per_row_host[r]; r += run;
+    }
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }

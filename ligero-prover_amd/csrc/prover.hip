@@ -13,11 +13,25 @@
 // constraint stream of BASELINE.md 3: n_linear witness slots + n_quad slots of x*y=z, one dense linear-test
 // coefficient per witness.
 #include "prover_common.hpp"
+#include <cerrno>
+#include <functional>
+#include <memory>
 
 struct lig_trace {
     lig_ctx* c = nullptr;
-    lig_synth_job job;
+    lig_synth_job job;                  // synthetic jobs only (n_linear / n_quad / witness_key); pointers cleared
+    bool from_rows = false;             // rows supplied by the caller (lig_rows_*): no witness / randomness generation here
+    int state = 0;                      // lig_rows_*: 0 = begun, 1 = committed (stage 1 done)
+    uint8_t encoding_seed[32] = {0}, program_hash[32] = {0}, ih[32] = {0};
+    int64_t generated_at = 0;
+    char version[17] = {0};
     std::vector<RowDesc> rows;          // committed non-mask rows in commit order
+    std::vector<PadRun> pad_runs;       // pads drawn at commit time (pad_encoding_random), runs of consecutive rows
+    uint64_t mask_pos = 0;              // encoding-stream position of the first mask element
+    std::vector<std::pair<size_t, size_t>> sched1;     // stage-1 chunk schedule
+    const uint8_t* host_msgs = nullptr; // lig_rows_begin with host memory: uploaded chunk by chunk under the encodes
+    std::vector<hipEvent_t> ev_up;      // one per stage-1 chunk: its rows have arrived
+    lig_proof_info info1;               // stage-1 results kept between lig_rows_commit and lig_rows_prove
     size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
     fr* cw = nullptr;                   // (R+3) x n codewords, resident across the stages
@@ -124,30 +138,38 @@ int lig_run_batch_program(lig_ctx* c, const lig_synth_job& job, fr* rows_out) {
     return LIG_OK;
 }
 
-extern "C" {
-
-// plan_rows: commit order of witness_manager (witness_manager.hpp:497-503): full linear rows, full quadratic
-// triples, partial linear row, partial quadratic triple
-static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T);
-int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
-    CHECK_CTX(c);
-    if (!job || !out) return LIG_E_ARG;
-    *out = nullptr;
-    lig_trace* T = new lig_trace();
-    T->c = c; T->job = *job;
-    T->job.batch_ops = nullptr; T->job.batch_data = nullptr;       // the program is consumed here; the caller's memory is not kept
-    const int rc = synth_prepare_impl(c, job, T);
-    if (rc != LIG_OK) { lig_trace_destroy(T); return rc; }         // nothing is handed out on failure
-    *out = T;
+int lig_internal_synth_witness(lig_ctx* c, const uint8_t witness_key[32], const std::vector<RowDesc>& rows, size_t first, fr* msgs) {
+    const uint32_t k = c->k;
+    uint32_t rk[60];
+    lig::aes256_expand_host(witness_key, rk);
+    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t pos = 0;
+    const size_t R = rows.size();
+    for (size_t r = first; r < R;) {
+        const RowDesc d = rows[r];
+        if (d.kind == 0) {                      // run of linear rows with the same fill
+            size_t run = 1;
+            while (r + run < R && rows[r + run].kind == 0 && rows[r + run].data == d.data) run++;
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, pos, msgs + r * k, run, d.data, k, 0, 1, d.data);
+            pos += (uint64_t)run * d.data; r += run;
+        } else {                                 // x, y, z triple
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, pos, msgs + r * k, 2, d.data, k, 0, 1, d.data);
+            pos += 2ull * d.data;
+            lig::launch_eltwise(c->stream, LIG_OP_MUL, msgs + r * k, msgs + (r + 1) * k, msgs + (r + 2) * k, d.data, fr{}, 0);
+            r += 3;
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
-static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T) {
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
-    if (l >= k || l < 2 || t > n) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l < k and 192 <= n");
-    if (!plan_rows(*job, l, T->rows, T->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
+
+// ---------------------------------------------------------------------------------------------------------------------
+// shared by lig_synth_* and lig_rows_*: buffers of a trace whose row plan (T->rows) is known
+static int trace_alloc(lig_ctx* c, lig_trace* T) {
+    const uint32_t k = c->k, n = c->n, t = 192, l = c->l;
     const size_t R = T->R = T->rows.size();
     T->triples = quad_terms(T->rows);
-    for (T->RB = 0; T->RB < R && T->rows[T->RB].kind >= RK_INIT; T->RB++) {}
     const size_t chunk = lig_tune::CHUNK, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
@@ -173,112 +195,53 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
     for (int i = 0; i < 2; i++) {
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_ready[i], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_used[i], hipEventDisableTiming));
-        if (!T->ev_gate) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
-        for (int a3 = 0; a3 < 3; a3++) if (!T->ev_acc[a3]) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_acc[a3], hipEventDisableTiming));
     }
-    {
-        std::vector<uint32_t> d(R);
-        for (size_t r = 0; r < R; r++) d[r] = T->rows[r].data;
-        if (R) HIP_TRY(c, hipMemcpyAsync(T->data_dev, d.data(), R * 4, hipMemcpyHostToDevice, c->stream));
-        if (!T->triples.empty()) HIP_TRY(c, hipMemcpyAsync(T->tri_dev, T->triples.data(), T->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    // witness values: one draw per data slot of every linear / x / y row, in commit order; z = x*y
-    uint32_t rk[60];
-    lig::aes256_expand_host(job->witness_key, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
+    for (int a3 = 0; a3 < 3; a3++) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_acc[a3], hipEventDisableTiming));
+    if (!T->triples.empty()) HIP_TRY(c, hipMemcpyAsync(T->tri_dev, T->triples.data(), T->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
+    T->sched1 = chunk_schedule(R, lig_tune::CHUNK, 0, 96);
+    TRY(lig_internal_reserve_scratch(c, R < lig_tune::CHUNK ? (R ? R : 1) : lig_tune::CHUNK));     // sized once: never re-allocated under a running stream
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (T->RB) TRY(lig_run_batch_program(c, *job, T->msgs));
-    lig::aes256_expand_host(job->witness_key, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    uint64_t pos = 0;
-    size_t r = T->RB;
-    while (r < R) {
-        const RowDesc d = T->rows[r];
-        if (d.kind == 0) {                      // run of linear rows with the same fill
-            size_t run = 1;
-            while (r + run < R && T->rows[r + run].kind == 0 && T->rows[r + run].data == d.data) run++;
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, pos, T->msgs + r * k, run, d.data, k, 0, 1, d.data);
-            pos += (uint64_t)run * d.data; r += run;
-        } else {                                 // x, y, z triple
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, pos, T->msgs + r * k, 2, d.data, k, 0, 1, d.data);
-            pos += 2ull * d.data;
-            lig::launch_eltwise(c->stream, LIG_OP_MUL, T->msgs + r * k, T->msgs + (r + 1) * k, T->msgs + (r + 2) * k, d.data, fr{}, 0);
-            r += 3;
-        }
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
 
-void lig_trace_destroy(lig_trace* T) {
-    if (!T) return;
-    (void)hipSetDevice(T->c->device);
-    (void)hipStreamSynchronize(T->c->stream);
-    T->c->sha.erase(T->sha_state);
-    for (void* p : {(void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
-                    (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
-                    (void*)T->coef_dev})
-        (void)hipFree(p);
-    for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
-    if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
-    for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
-    (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
-    delete T;
+// instance_hash over arg0 = "Ligero\0" and the public arguments (src/webgpu_prover.cpp:110-168)
+static bool instance_hash_of(const uint8_t* args, const uint64_t* lens, uint64_t n_args, uint8_t out[32]) {
+    if (n_args && (!args || !lens)) return false;
+    std::memset(out, 0, 32);
+    Sha256().add(out, 32).add("Ligero", 7).finish(out);
+    for (uint64_t i = 0; i < n_args; i++) {
+        uint8_t prev[32];
+        std::memcpy(prev, out, 32);
+        Sha256().add(prev, 32).add(args, lens[i]).finish(out);
+        args += lens[i];
+    }
+    return true;
 }
-uint64_t lig_trace_rows(const lig_trace* T) { return T ? T->R + 3 : 0; }
 
-int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
-    if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
+// ================= stage 1: row forming (pads + masks from the encoding stream), encode, column hash, Merkle root
+static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<void(const char*)>& mark) {
     lig_ctx* c = T->c;
-    CHECK_CTX(c);
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l;
+    const uint32_t l = c->l, k = c->k, n = c->n, pad = k - l;
     const size_t R = T->R;
     hipStream_t s = c->stream;
-    std::memset(info, 0, sizeof *info);
-    info->rows = R + 3;
-    const auto t_begin = clk::now();
-    auto t0 = clk::now();
-    // LIG_TRACE=1: print a synchronised timeline of the prove call to stderr (debug aid, off by default)
-    const bool trace_on = std::getenv("LIG_TRACE") != nullptr;
-    auto t_mark = clk::now();
-    auto mark = [&](const char* what) {
-        if (!trace_on) return;
-        (void)hipStreamSynchronize(s);
-        std::fprintf(stderr, "[lig_trace] %-28s %8.3f ms\n", what, ms_since(t_mark));
-        t_mark = clk::now();
-    };
-
-    // ================= stage 1: row forming (pads + masks from the encoding stream), encode, column hash, Merkle root
     uint32_t rk[60];
-    lig::aes256_expand_host(T->job.encoding_seed, rk);
+    lig::aes256_expand_host(T->encoding_seed, rk);
     HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    uint64_t epos = 0;
-    epos = (uint64_t)T->n_init * pad;                                                              // batch init rows drew theirs in prepare
-    lig::launch_rng_fill_rows(s, c->rk_dev, epos, T->msgs + T->RB * (size_t)k, R - T->RB, pad, k, l, 1, pad);   // pad_encoding_random of every stream row
-    epos += (uint64_t)(R - T->RB) * pad;
+    const bool streamed = T->host_msgs != nullptr;       // rows arrive chunk by chunk: their pads are drawn per chunk below
+    if (!streamed)
+        for (const PadRun& pr : T->pad_runs)             // pad_encoding_random of every row that draws at commit time
+            lig::launch_rng_fill_rows(s, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
     mark("  pads");
+    uint64_t epos = T->mask_pos;
     fr* mask = T->cw + R * (size_t)n;                                                               // the 3 mask rows are formed in place
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;               // code mask: l randoms, zeros to k
     fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, l - 1, 0, 1, 2, 0); epos += l - 1;       // (0, r) x (l-1)
-    mark("  mask fills a");
-    {   // last odd slot = -(sum of the others) (witness_manager.hpp:283-297)
-        H::Fr* tmp = reinterpret_cast<H::Fr*>(T->h_small + (R ? R : 1) * 32);
-        const size_t cnt = 2 * (size_t)(l - 1);
-        HIP_TRY(c, hipMemcpyAsync(tmp, mlin, cnt * 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        H::Fr sum = H::from_u64(0);
-        for (size_t i = 1; i < cnt; i += 2) sum = H::add(sum, tmp[i]);
-        sum = H::neg(sum);
-        HIP_TRY(c, hipMemcpyAsync(mlin + 2 * (size_t)(l - 1) + 1, &sum, 32, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    mark("  mask sum on host");
+    // last odd slot = -(sum of the others) (witness_manager.hpp:283-297), on the device: no host round trip
+    lig::launch_sum_elems(s, mlin + 1, l - 1, 2, T->dots, mlin + 2 * (size_t)(l - 1) + 1);
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, l, 0, 1, 2, 0); epos += l;              // (0, r) x l
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
@@ -292,13 +255,21 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     TRY(lig_sha_init(c, T->sha_state, n));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
-    // The three mask rows do not depend on the witness: their ~60 small radix-2 launches run on the side stream under the
+    // The three mask rows do not depend on the witness: their transforms run on the side stream under the
     // first chunk's encode (the hash of chunk 0 is queued behind them and has to wait for that encode anyway).
     TRY(lig_internal_encode_generic(c, mask, s_sha));
     TRY(lig_internal_encode_2k_rows(c, mlin, 2, s_sha));      // mlin and mquad are adjacent rows: one pass
     uint64_t absorbed = 0;
-    for (const auto& ch : chunk_schedule(R, lig_tune::CHUNK, 0, 96)) {
-        const size_t b = ch.first, nb = ch.second - ch.first;
+    size_t pr_i = 0;
+    for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+        const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
+        if (streamed) {
+            HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_up[ci], 0));                   // this chunk's rows have arrived
+            for (; pr_i < T->pad_runs.size() && T->pad_runs[pr_i].first < b + nb; pr_i++) {      // runs never straddle chunks (split in begin)
+                const PadRun& pr = T->pad_runs[pr_i];
+                lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
+            }
+        }
         TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
@@ -329,16 +300,25 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, hipMemcpyDeviceToHost, s));   // for the decommitment (stage 3)
-    uint8_t ih[32];
-    {   // instance hash with no public arguments besides arg0 = "Ligero\0" (src/webgpu_prover.cpp:110-168)
-        const uint8_t z[32] = {0};
-        Sha256().add(z, 32).add("Ligero", 7).finish(ih);
-        Sha256().add("LigetronStage1", 15).add(info->root, 32).add(ih, 32).finish(info->stage1_seed);
-    }
+    Sha256().add("LigetronStage1", 15).add(info->root, 32).add(T->ih, 32).finish(info->stage1_seed);
     mark("merkle + seed");
-    info->ms_stage1 = ms_since(t0);
-    t0 = clk::now();
+    return LIG_OK;
+}
 
+// where the stage-2 randomness rows come from: generated (dense rows of the synthetic stream, from the linear stream
+// keyed by the stage-1 seed) or supplied by the caller (device pointer used in place / host rows uploaded chunk-wise)
+struct RandSource { const fr* dev = nullptr; const uint8_t* host = nullptr; };
+
+// ================= stage 2 + 3
+static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* const_sum_given, const uint8_t** proof, size_t* proof_len,
+                         lig_proof_info* info, const std::function<void(const char*)>& mark) {
+    lig_ctx* c = T->c;
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
+    const size_t R = T->R;
+    hipStream_t s = c->stream, s2 = c->stream2;
+    const bool synth = !T->from_rows;
+    auto t0 = clk::now();
+    uint32_t rk[60];
     // ================= stage 2: code / linear / quadratic accumulators over the resident codewords
     const size_t NT = T->triples.size() / 3;
     lig::aes256_expand_host(info->stage1_seed, rk);           // key of the code / linear / quadratic streams (three engines, same key)
@@ -361,8 +341,8 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemsetAsync(T->parts, 0, 3 * groups * (size_t)n * 32, s));
     HIP_TRY(c, hipMemsetAsync(T->acc, 0, 3 * (size_t)n * 32, s));
     fr* rhalf = T->rcw;                                   // chunk x 2k
-    // The randomness rows of chunk b+1 (AES sampling: LDS-bound) and their inner products with the witness rows are
-    // formed on the side stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
+    // The randomness rows of chunk b+1 (AES sampling: LDS-bound; or the upload of the caller's rows) are formed on the side
+    // stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
     const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_tune::CHUNK, 96, 0);
     const size_t n_chunks = sched2.size();
     std::vector<uint64_t> chunk_pos(n_chunks + 1, 0);
@@ -371,17 +351,23 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         for (size_t r = sched2[ci].first; r < sched2[ci].second; r++) cnt += T->rows[r].data;
         chunk_pos[ci + 1] = chunk_pos[ci] + cnt;
     }
+    auto rand_buf = [&](size_t ci) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + sched2[ci].first * (size_t)k : T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k; };
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
-        fr* rb = T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k;
+        fr* rb = rand_buf(ci);
+        if (rs.dev) { HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2)); return LIG_OK; }     // used in place
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
-        uint64_t lpos = chunk_pos[ci];
-        for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order; zeros after
-            size_t run = 1;
-            const uint32_t d = T->rows[b + r].data;
-            while (r + run < nb && T->rows[b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
-            lpos += (uint64_t)run * d; r += run;
+        if (rs.host) {
+            HIP_TRY(c, hipMemcpyAsync(rb, rs.host + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, s2));
+        } else {
+            uint64_t lpos = chunk_pos[ci];
+            for (size_t r = 0; r < nb;) {          // dense linear-test coefficients: one draw per witness slot, commit order; zeros after
+                size_t run = 1;
+                const uint32_t d = T->rows[b + r].data;
+                while (r + run < nb && T->rows[b + r + run].data == d) run++;
+                lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
+                lpos += (uint64_t)run * d; r += run;
+            }
         }
         HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2));
         return LIG_OK;
@@ -392,11 +378,11 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple -- computed on the host while the
         // side stream already samples the first randomness rows
         std::vector<H::Fr> rc, rq;
-        FieldStream code(info->stage1_seed), quad(info->stage1_seed);
+        FieldStream code_s(info->stage1_seed), quad_s(info->stage1_seed);
         size_t n_code = 0;
         for (size_t r = 0; r < R; r++) n_code += has_code_check(T->rows[r].kind);
-        code.next(n_code, rc);
-        quad.next(NT, rq);
+        code_s.next(n_code, rc);
+        quad_s.next(NT, rq);
         std::vector<lig::f29s> coef(R + 2 * NT + 1);
         std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
         const H::Fr R261sq = H::mul(R261, R261);
@@ -407,7 +393,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     }
     for (size_t ci = 0; ci < n_chunks; ci++) {
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
-        fr* rb = T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k;
+        fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
@@ -423,13 +409,14 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         lig::launch_rlc_combine(s, linC, p_linC, pg, k);
     }
     mark("stage2 rows (rng+dot+encode+rlc)");
-    lig::launch_sum_elems(s, linH, k, 1, T->dots);       // the linear-test constant is minus this sum (prover_kernels.hip)
+    lig::launch_sum_elems(s, linH, k, 1, T->dots, nullptr);       // sum of all <witness row, randomness row> (prover_kernels.hip)
     lig::launch_lin_interleave(s, lin, linH, linC, k);
     HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));
     lig::launch_quad_rows29(s, T->cw, n, 2, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
     // Each accumulator is extended to the n evaluation points, masked (nonbatch_context.hpp:739-753) and sent to the host
     // as soon as it is final; the host absorbs it into the stage-2 seed hash (a sequential SHA-256 over 3 MiB, the longest
     // host step of the proof) while the GPU extends the next one.
+    fr* mask = T->cw + R * (size_t)n; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
     uint8_t* enc = T->h_enc;
     const size_t vec_bytes = (size_t)n * 32;
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
@@ -464,10 +451,14 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
         }
         h2.finish(info->stage2_seed);
     }
-    {
+    if (const_sum_given) std::memcpy(info->const_sum, const_sum_given, 32);     // the caller's public constant (linear_sums)
+    else {
+        // synthetic stream: every witness slot carries the constraint w_i = b_i with b public (derived from witness_key), so
+        // the constant is minus the sum of all inner products <witness row, randomness row> = minus the sum of linH
         const H::Fr sum = H::neg(dots[0]);
         std::memcpy(info->const_sum, sum.v, 32);
     }
+    (void)synth;
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     mark("accumulators to host, seed hash, sampling, decodes");
     info->ms_stage2 = ms_since(t0);
@@ -480,10 +471,8 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     TRY(lig_gather_rows(c, T->cw, R + 3, T->samples));
     const size_t n_nodes = lig_merkle_nodes(n);
     const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
-    char ver[17] = {0};
-    std::memcpy(ver, T->job.version, 16);
     const size_t smp_bytes = (R + 3) * (size_t)t * 32;
-    const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, ver, T->job.program_hash, T->job.generated_at, k, n, t,
+    const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, T->version, T->program_hash, T->generated_at, k, n, t,
                                               info->root, sib, idx, enc, smp_bytes);
     if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
     HIP_TRY(c, hipMemcpyAsync(T->h_proof + lay.samples_off, T->samples, smp_bytes, hipMemcpyDeviceToHost, s));   // opened columns land in place
@@ -504,10 +493,257 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     *proof_len = lay.total;
     mark("serialize");
     info->ms_stage3 = ms_since(t0);
-    info->ms_total = ms_since(t_begin);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
 
+// LIG_TRACE=1: print a synchronised timeline of the prove call to stderr (debug aid, off by default)
+static std::function<void(const char*)> make_mark(lig_ctx* c) {
+    const bool trace_on = std::getenv("LIG_TRACE") != nullptr;
+    auto t_mark = std::make_shared<clk::time_point>(clk::now());
+    return [c, trace_on, t_mark](const char* what) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(c->stream);
+        std::fprintf(stderr, "[lig_trace] %-28s %8.3f ms\n", what, ms_since(*t_mark));
+        *t_mark = clk::now();
+    };
+}
+
+extern "C" {
+
+// plan_rows: commit order of witness_manager (witness_manager.hpp:497-503): full linear rows, full quadratic
+// triples, partial linear row, partial quadratic triple
+static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T);
+int lig_synth_prepare(lig_ctx* c, const lig_synth_job* job, lig_trace** out) {
+    CHECK_CTX(c);
+    if (!job || !out) return LIG_E_ARG;
+    *out = nullptr;
+    lig_trace* T = new lig_trace();
+    T->c = c; T->job = *job;
+    T->job.batch_ops = nullptr; T->job.batch_data = nullptr;       // the program is consumed here; the caller's memory is not kept
+    T->job.public_args = nullptr; T->job.public_arg_lens = nullptr;
+    const int rc = synth_prepare_impl(c, job, T);
+    if (rc != LIG_OK) { lig_trace_destroy(T); return rc; }         // nothing is handed out on failure
+    *out = T;
+    return LIG_OK;
+}
+static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T) {
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
+    // k - l = sample_size upstream (include/params.hpp:24-32); with fewer random pads than opened columns the proof
+    // would silently stop being zero-knowledge
+    if (l >= k || l < 2 || t > n || k - l < t) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l <= k - 192 (k - l random pads cover the 192 opened columns)");
+    if (!plan_rows(*job, l, T->rows, T->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
+    if (!instance_hash_of(job->public_args, job->public_arg_lens, job->n_public_args, T->ih)) FAIL(c, LIG_E_ARG, "public arguments: null pointer");
+    std::memcpy(T->encoding_seed, job->encoding_seed, 32);
+    std::memcpy(T->program_hash, job->program_hash, 32);
+    std::memcpy(T->version, job->version, 16);
+    T->generated_at = job->generated_at;
+    const size_t R = T->rows.size();
+    for (T->RB = 0; T->RB < R && T->rows[T->RB].kind >= RK_INIT; T->RB++) {}
+    TRY(trace_alloc(c, T));
+    // pads: init rows of the batch program drew theirs while the program ran (prepare); every stream row draws at commit time
+    if (R > T->RB) T->pad_runs.push_back({T->RB, R - T->RB, (uint64_t)T->n_init * (k - l)});
+    T->mask_pos = (uint64_t)(T->n_init + (R - T->RB)) * (k - l);
+    {
+        std::vector<uint32_t> d(R);
+        for (size_t r = 0; r < R; r++) d[r] = T->rows[r].data;
+        if (R) HIP_TRY(c, hipMemcpyAsync(T->data_dev, d.data(), R * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    // witness values: one draw per data slot of every linear / x / y row, in commit order; z = x*y
+    if (T->RB) TRY(lig_run_batch_program(c, *job, T->msgs));
+    TRY(lig_internal_synth_witness(c, job->witness_key, T->rows, T->RB, T->msgs));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+void lig_trace_destroy(lig_trace* T) {
+    if (!T) return;
+    (void)hipSetDevice(T->c->device);
+    (void)hipStreamSynchronize(T->c->stream);
+    (void)hipStreamSynchronize(T->c->stream2);
+    (void)hipStreamSynchronize(T->c->stream3);
+    T->c->sha.erase(T->sha_state);
+    for (void* p : {(void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
+                    (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
+                    (void*)T->coef_dev})
+        (void)hipFree(p);
+    for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
+    if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
+    for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
+    for (hipEvent_t e : T->ev_up) (void)hipEventDestroy(e);
+    (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
+    delete T;
+}
+uint64_t lig_trace_rows(const lig_trace* T) { return T ? T->R + 3 : 0; }
+
+int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
+    if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
+    lig_ctx* c = T->c;
+    CHECK_CTX(c);
+    if (T->from_rows) FAIL(c, LIG_E_STATE, "lig_synth_prove on a trace made by lig_rows_begin (use lig_rows_commit / lig_rows_prove)");
+    std::memset(info, 0, sizeof *info);
+    info->rows = T->R + 3;
+    const auto t_begin = clk::now();
+    const auto mark = make_mark(c);
+    TRY(prove_stage1(T, info, mark));
+    info->ms_stage1 = ms_since(t_begin);
+    TRY(prove_stage23(T, RandSource{}, nullptr, proof, proof_len, info, mark));
+    info->ms_total = ms_since(t_begin);
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rows supplied by the caller (include/lig_hip.h, lig_rows_*)
+static int rows_begin_impl(lig_ctx* c, const lig_rows_job* job, lig_trace* T) {
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l;
+    if (l >= k || l < 2 || t > n || k - l < t) FAIL(c, LIG_E_ARG, "rows job: need 2 <= l <= k - 192");
+    if (job->rows && (!job->kinds || !job->msgs)) FAIL(c, LIG_E_ARG, "rows job: null kinds / msgs");
+    if (!instance_hash_of(job->public_args, job->public_arg_lens, job->n_public_args, T->ih)) FAIL(c, LIG_E_ARG, "public arguments: null pointer");
+    std::memcpy(T->encoding_seed, job->encoding_seed, 32);
+    std::memcpy(T->program_hash, job->program_hash, 32);
+    std::memcpy(T->version, job->version, 16);
+    T->generated_at = job->generated_at;
+    T->from_rows = true;
+    const size_t R = job->rows;
+    // row kinds: groups must be complete and consecutive; which kinds draw padding from the encoding stream at the time
+    // they are formed: linear rows and the rows of a quadratic triple (witness_manager.hpp:200-269), on_batch_init rows
+    // (nonbatch_context.hpp:497-510); bit / equal / batch-quadratic rows are copies of variables and draw nothing
+    T->rows.resize(R);
+    std::vector<uint8_t> draw(R, 0);
+    std::vector<uint64_t> pos(R + 1, 0);
+    for (size_t r = 0; r < R; r++) {
+        const uint8_t kd = job->kinds[r] & 0x7f;
+        if (kd > RK_BQZ) FAIL(c, LIG_E_ARG, "rows job: unknown row kind");
+        const bool first_of_3 = kd == 1 || kd == RK_BQX, first_of_2 = kd == RK_EQX;
+        if (first_of_3 && !(r + 2 < R && (job->kinds[r + 1] & 0x7f) == kd + 1 && (job->kinds[r + 2] & 0x7f) == kd + 2)) FAIL(c, LIG_E_ARG, "rows job: incomplete x,y,z triple");
+        if (first_of_2 && !(r + 1 < R && (job->kinds[r + 1] & 0x7f) == RK_EQY)) FAIL(c, LIG_E_ARG, "rows job: incomplete equality pair");
+        const bool follower = kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ;
+        if (follower && !(r > 0 && (job->kinds[r - 1] & 0x7f) == kd - 1)) FAIL(c, LIG_E_ARG, "rows job: row of a group without its predecessor");
+        const bool draws = kd <= 3 || kd == RK_INIT;
+        if ((job->kinds[r] & LIG_ROW_DRAW_PAD) && !draws) FAIL(c, LIG_E_ARG, "rows job: LIG_ROW_DRAW_PAD on a row kind that draws no padding upstream");
+        draw[r] = (job->kinds[r] & LIG_ROW_DRAW_PAD) ? 1 : 0;
+        pos[r + 1] = pos[r] + (draws ? pad : 0);
+        T->rows[r] = RowDesc{kd, 0};
+    }
+    T->mask_pos = pos[R];
+    TRY(trace_alloc(c, T));
+    // pad runs: consecutive flagged rows whose stream positions are consecutive, never straddling a stage-1 chunk
+    for (const auto& ch : T->sched1)
+        for (size_t r = ch.first; r < ch.second;) {
+            if (!draw[r]) { r++; continue; }
+            size_t e = r + 1;
+            while (e < ch.second && draw[e] && pos[e] == pos[e - 1] + pad) e++;
+            T->pad_runs.push_back({r, e - r, pos[r]});
+            r = e;
+        }
+    if (!R) return LIG_OK;
+    if (job->msgs_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(T->msgs, job->msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        // the upload starts now, on the copy stream, one event per stage-1 chunk: lig_rows_commit encodes chunk b while chunk
+        // b+1 is still on the bus
+        T->host_msgs = (const uint8_t*)job->msgs;
+        T->ev_up.resize(T->sched1.size(), nullptr);
+        for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+            const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
+            HIP_TRY(c, hipEventCreateWithFlags(&T->ev_up[ci], hipEventDisableTiming));
+            HIP_TRY(c, hipMemcpyAsync(T->msgs + b * (size_t)k, T->host_msgs + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, c->stream3));
+            HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
+        }
+    }
+    return LIG_OK;
+}
+int lig_rows_begin(lig_ctx* c, const lig_rows_job* job, lig_trace** out) {
+    CHECK_CTX(c);
+    if (!job || !out) return LIG_E_ARG;
+    *out = nullptr;
+    lig_trace* T = new lig_trace();
+    T->c = c;
+    std::memset(&T->job, 0, sizeof T->job);
+    const int rc = rows_begin_impl(c, job, T);
+    if (rc != LIG_OK) { lig_trace_destroy(T); return rc; }
+    *out = T;
+    return LIG_OK;
+}
+int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
+    if (!T) return LIG_E_ARG;
+    lig_ctx* c = T->c;
+    CHECK_CTX(c);
+    if (!T->from_rows || T->state != 0) FAIL(c, LIG_E_STATE, "lig_rows_commit: trace is not a freshly begun rows job");
+    std::memset(&T->info1, 0, sizeof T->info1);
+    T->info1.rows = T->R + 3;
+    const auto t_begin = clk::now();
+    TRY(prove_stage1(T, &T->info1, make_mark(c)));
+    T->info1.ms_stage1 = ms_since(t_begin);
+    T->state = 1;
+    T->host_msgs = nullptr;                               // the caller's memory is no longer referenced
+    if (root) std::memcpy(root, T->info1.root, 32);
+    if (stage1_seed) std::memcpy(stage1_seed, T->info1.stage1_seed, 32);
+    return LIG_OK;
+}
+int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const uint8_t const_sum[32], const uint8_t** proof,
+                   size_t* proof_len, lig_proof_info* info) {
+    if (!T || !proof || !proof_len || !info || !const_sum) return LIG_E_ARG;
+    lig_ctx* c = T->c;
+    CHECK_CTX(c);
+    if (!T->from_rows || T->state != 1) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_commit has not run on this trace");
+    if (T->R && !rands) FAIL(c, LIG_E_ARG, "lig_rows_prove: null randomness rows");
+    {
+        H::Fr v;
+        std::memcpy(v.v, const_sum, 32);
+        if (H::geq(v, H::P)) FAIL(c, LIG_E_ARG, "lig_rows_prove: constant not reduced mod p");
+    }
+    *info = T->info1;
+    const auto t_begin = clk::now();
+    RandSource rs;
+    if (rands_on_device) rs.dev = (const fr*)rands; else rs.host = (const uint8_t*)rands;
+    TRY(prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c)));
+    info->ms_total = info->ms_stage1 + ms_since(t_begin);
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-only transcript helpers
+int lig_public_arg_bytes(int kind, const char* text, uint8_t* out, size_t cap, size_t* len) {
+    if (!text || !len) return LIG_E_ARG;
+    std::vector<uint8_t> b;
+    if (kind == LIG_ARG_I64) {
+        char* end = nullptr;
+        errno = 0;
+        const long long v = std::strtoll(text, &end, 10);
+        if (errno || end == text || *end) return LIG_E_ARG;
+        const int64_t i = (int64_t)v;
+        b.resize(8);
+        std::memcpy(b.data(), &i, 8);                      // (u8*)&i .. + sizeof(int64_t), little-endian host as upstream
+    } else if (kind == LIG_ARG_STR) {
+        b.assign(text, text + std::strlen(text) + 1);      // c_str() .. + size() + 1: the NUL is part of the argument
+    } else if (kind == LIG_ARG_HEX) {
+        std::string h(text);
+        if (h.rfind("0x", 0) == 0) h = h.substr(2);
+        if (h.size() % 2) h.insert(h.begin(), '0');
+        auto nib = [](char ch) -> int { return ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : ch >= 'A' && ch <= 'F' ? ch - 'A' + 10 : -1; };
+        for (size_t i = 0; i < h.size(); i += 2) {
+            const int hi = nib(h[i]), lo = nib(h[i + 1]);
+            if (hi < 0 || lo < 0) return LIG_E_ARG;        // boost::algorithm::unhex throws on a non-hex character
+            b.push_back((uint8_t)(hi * 16 + lo));
+        }
+    } else return LIG_E_ARG;
+    *len = b.size();
+    if (!out || cap < b.size()) return LIG_E_ARG;
+    if (!b.empty()) std::memcpy(out, b.data(), b.size());
+    return LIG_OK;
+}
+int lig_instance_hash(const uint8_t* args, const uint64_t* lens, size_t n_args, uint8_t out[32]) {
+    if (!out || !instance_hash_of(args, lens, n_args, out)) return LIG_E_ARG;
+    return LIG_OK;
+}
+int lig_sample_columns(const uint8_t seed[32], uint32_t n, uint32_t t, uint32_t* out_sorted) {
+    if (!seed || !out_sorted || !n) return LIG_E_ARG;
+    const std::vector<uint32_t> idx = sample_columns(seed, n, t);
+    std::memcpy(out_sorted, idx.data(), idx.size() * sizeof(uint32_t));
+    return LIG_OK;
+}
 
 }  // extern "C"

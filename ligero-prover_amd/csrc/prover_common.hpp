@@ -26,13 +26,19 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
                        const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
-void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out);
+void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out, fr* neg_out);
 void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
                              const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
 void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
 }  // namespace lig
+
+// (outside the anonymous namespace: these types appear in functions shared between translation units)
+// kind: 0 linear, 1 x, 2 y, 3 z of the synthetic stream; >= 4: rows committed by the batch program (RK_* below)
+struct RowDesc { uint8_t kind; uint32_t data; };
+// `count` consecutive rows from `first` whose k-l pads are element pos, pos + (k-l), ... of the encoding stream
+struct PadRun { size_t first, count; uint64_t pos; };
 
 namespace {
 
@@ -209,7 +215,7 @@ EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, con
 
 // kind: 0 linear, 1 x, 2 y, 3 z of the synthetic stream; rows committed by the batch program (lig_hip.h, lig_batch_op):
 // 4 init, 5 bit, 6 / 7 the two rows of an equality, 8 / 9 / 10 the x, y, z of a batch product or quotient
-struct RowDesc { uint8_t kind; uint32_t data; };
+
 enum : uint8_t { RK_INIT = 4, RK_BIT = 5, RK_EQX = 6, RK_EQY = 7, RK_BQX = 8, RK_BQY = 9, RK_BQZ = 10 };
 inline bool has_code_check(uint8_t kind) { return kind != RK_EQX && kind != RK_EQY; }      // nonbatch_context.hpp:811-825
 
@@ -296,3 +302,6 @@ struct lig_tune {
 
 // the batch program of a job on the device: committed rows are written to rows_out in program order (prover.hip)
 int lig_run_batch_program(lig_ctx* c, const lig_synth_job& job, fr* rows_out);
+// witness values of the synthetic stream rows [first, rows.size()) (one draw of the witness_key stream per data slot of every
+// linear / x / y row in commit order, z = x*y); row r is written to msgs + r*k.  Enqueued on the context stream.
+int lig_internal_synth_witness(lig_ctx* c, const uint8_t witness_key[32], const std::vector<RowDesc>& rows, size_t first, fr* msgs);

@@ -106,7 +106,7 @@ void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, ui
 // it on the host while generating constraints: linear_sums(), src/webgpu_prover.cpp:307).  Randomness rows are zero
 // outside their data slots, so that double sum is just the sum of the message-domain accumulator sum_r msg_r o rand_r
 // over its k positions -- no per-row inner products are needed.
-__global__ void __launch_bounds__(256) k_sum_elems(const fr* __restrict__ in, uint32_t count, uint32_t stride, fr* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_sum_elems(const fr* __restrict__ in, uint32_t count, uint32_t stride, fr* __restrict__ out, fr* neg_out) {
     __shared__ uint32_t sh[256 * 9];
     f29 a = f29_zero();
     int since = 0;
@@ -133,11 +133,15 @@ __global__ void __launch_bounds__(256) k_sum_elems(const fr* __restrict__ in, ui
         f29 x;
 #pragma unroll
         for (int i = 0; i < 9; i++) x.v[i] = sh[i * 256];
-        fr_store(out, pack29(f29_canon(x)));
+        const f29 sum = f29_canon(x);
+        fr_store(out, pack29(sum));
+        // neg_out (optional, may lie inside the buffer `in` strides over -- hence no __restrict__): (p - sum) mod p, the
+        // closing slot of the linear mask row (witness_manager.hpp:283-297)
+        if (neg_out != nullptr) fr_store(neg_out, pack29(f29_canon(f29_sub_k2(f29_zero(), sum))));
     }
 }
-void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out) {
-    hipLaunchKernelGGL(k_sum_elems, dim3(1), dim3(256), 0, s, in, count, stride, out);
+void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out, fr* neg_out) {
+    hipLaunchKernelGGL(k_sum_elems, dim3(1), dim3(256), 0, s, in, count, stride, out, neg_out);
 }
 
 // The linear-test accumulator lives on the order-2k subgroup <w_n^2> (index m <-> w_n^(2m)).  Its even points w_n^(4q) =

@@ -31,6 +31,7 @@ struct lig_shard {
     std::vector<size_t> triple_ord;            // global ordinal of each local triple
     uint8_t *h_proof = nullptr, *h_enc = nullptr, *h_nodes = nullptr, *h_small = nullptr;
     size_t h_proof_cap = 0;
+    uint8_t ih[32] = {0};
 };
 
 extern "C" {
@@ -43,6 +44,19 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
     lig_shard* S = new lig_shard();
     S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world;
     S->job.batch_ops = nullptr; S->job.batch_data = nullptr;
+    {   // instance_hash over arg0 = "Ligero\0" and the public arguments (src/webgpu_prover.cpp:110-168)
+        if (job->n_public_args && (!job->public_args || !job->public_arg_lens)) { delete S; return LIG_E_ARG; }
+        std::memset(S->ih, 0, 32);
+        Sha256().add(S->ih, 32).add("Ligero", 7).finish(S->ih);
+        const uint8_t* a = job->public_args;
+        for (uint64_t i = 0; i < job->n_public_args; i++) {
+            uint8_t prev[32];
+            std::memcpy(prev, S->ih, 32);
+            Sha256().add(prev, 32).add(a, job->public_arg_lens[i]).finish(S->ih);
+            a += job->public_arg_lens[i];
+        }
+        S->job.public_args = nullptr; S->job.public_arg_lens = nullptr;
+    }
     const int rc = shard_prepare_impl(c, job, rank, world, S);
     if (rc != LIG_OK) { lig_shard_destroy(S); return rc; }
     *out = S;
@@ -50,7 +64,7 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
 }
 static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S) {
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
-    if (l >= k || l < 2 || t > n || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l < k, 192 <= n and world | n");
+    if (l >= k || l < 2 || t > n || k - l < t || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | n");
     S->ncol = n / world;
     if (!plan_rows(*job, l, S->rows, S->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
     const size_t R = S->R = S->rows.size();
@@ -196,17 +210,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, l - 1, 0, 1, 2, 0); epos += l - 1;
-    {
-        H::Fr* tmp = reinterpret_cast<H::Fr*>(S->h_small + (Rl ? Rl : 1) * 32);
-        const size_t cnt = 2 * (size_t)(l - 1);
-        HIP_TRY(c, hipMemcpyAsync(tmp, mlin, cnt * 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        H::Fr sum = H::from_u64(0);
-        for (size_t i = 1; i < cnt; i += 2) sum = H::add(sum, tmp[i]);
-        sum = H::neg(sum);
-        HIP_TRY(c, hipMemcpyAsync(mlin + 2 * (size_t)(l - 1) + 1, &sum, 32, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
+    lig::launch_sum_elems(s, mlin + 1, l - 1, 2, S->dots, mlin + 2 * (size_t)(l - 1) + 1);      // closing slot = -(sum of the others), on the device
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, l, 0, 1, 2, 0); epos += l;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
@@ -235,12 +239,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     TRY(lig_merkle_build(c, S->leaves, n, S->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    uint8_t ih[32];
-    {
-        const uint8_t z[32] = {0};
-        Sha256().add(z, 32).add("Ligero", 7).finish(ih);
-        Sha256().add("LigetronStage1", 15).add(info->root, 32).add(ih, 32).finish(info->stage1_seed);
-    }
+    Sha256().add("LigetronStage1", 15).add(info->root, 32).add(S->ih, 32).finish(info->stage1_seed);
     info->ms_stage1 = ms_since(t0);
     t0 = clk::now();
 
@@ -298,7 +297,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(lin, S->accp + k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(quad, S->accp + 3 * (size_t)k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     {   // linear-test constant = -(sum of the message-domain half of the combined accumulator: its even points)
-        lig::launch_sum_elems(s, lin, k, 2, S->dots);
+        lig::launch_sum_elems(s, lin, k, 2, S->dots, nullptr);
         HIP_TRY(c, hipMemcpyAsync(dots, S->dots, 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         const H::Fr sum = H::neg(dots[0]);

@@ -46,10 +46,11 @@ bool recommit(size_t P, const std::vector<uint32_t>& idx, const uint8_t* leaf_di
 
 extern "C" {
 
-int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_sum[32], const uint8_t* proof, size_t proof_len,
+int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_sum, const uint8_t* proof, size_t proof_len,
                      lig_verify_info* out) {
     CHECK_CTX(c);
-    if (!job || !const_sum || !proof || !out) return LIG_E_ARG;
+    if (!job || !proof || !out) return LIG_E_ARG;
+    if (job->n_public_args && (!job->public_args || !job->public_arg_lens)) return LIG_E_ARG;
     std::memset(out, 0, sizeof *out);
     const auto t_begin = clk::now();
     struct Stamp { lig_verify_info* o; decltype(t_begin) t0; ~Stamp() { o->ms_total = ms_since(t0); } } stamp{out, t_begin};
@@ -114,8 +115,16 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     // ---- seeds and sample indices (src/webgpu_verifier.cpp:268-293)
     uint8_t ih[32], seed1[32], seed2[32];
     {
-        const uint8_t z[32] = {0};
-        Sha256().add(z, 32).add("Ligero", 7).finish(ih);
+        // instance_hash over arg0 = "Ligero\0" and the job's public arguments (src/webgpu_verifier.cpp mirrors webgpu_prover.cpp:110-168)
+        std::memset(ih, 0, 32);
+        Sha256().add(ih, 32).add("Ligero", 7).finish(ih);
+        const uint8_t* a = job->public_args;
+        for (uint64_t i = 0; i < job->n_public_args; i++) {
+            uint8_t prev[32];
+            std::memcpy(prev, ih, 32);
+            Sha256().add(prev, 32).add(a, job->public_arg_lens[i]).finish(ih);
+            a += job->public_arg_lens[i];
+        }
         Sha256().add("LigetronStage1", 15).add(root, 32).add(ih, 32).finish(seed1);
         Sha256().add("LigetronStage2", 15).add(root, 32).add(pcode, vec).add(plin, vec).add(pquad, vec).finish(seed2);
     }
@@ -130,7 +139,8 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     std::vector<void*> owned;
     auto dm0 = [&](void** p, size_t bytes, bool zero) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
     auto dm = [&](void** p, size_t bytes) -> int { return dm0(p, bytes, true); };
-    struct Cleanup { std::vector<void*>& v; lig_ctx* c; void* sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
+    struct Cleanup { std::vector<void*>& v; lig_ctx* c; uint32_t*& sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
+    Cleanup cleanup{owned, c, dsha};            // constructed before the first allocation: a failing TRY below frees what exists
     const size_t groups = (CH + lig_tune::GROUP - 1) / lig_tune::GROUP;
     const std::vector<uint32_t> triples = quad_terms(rows);
     const size_t NT = triples.size() / 3;
@@ -145,7 +155,19 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     TRY(dm((void**)&dleaves, (size_t)t * 32));
     TRY(dm((void**)&dtri, (triples.size() ? triples.size() : 1) * 4));
     TRY(dm((void**)&dcoef, (R + 2 * NT + 1) * sizeof(lig::f29s)));
-    Cleanup cleanup{owned, c, dsha};
+    // The constant of the linear test is derived from public data (lig_hip.h): the public targets b of the synthetic
+    // statement (= the witness_key stream, regenerated here like lig_synth_prepare does) against the same coefficient rows.
+    const bool derive = const_sum == nullptr;
+    size_t RBv = 0;
+    while (RBv < R && rows[RBv].kind >= RK_INIT) RBv++;
+    fr *dW = nullptr, *dpl = nullptr, *dsum = nullptr;
+    const size_t pgroups = (CH + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4);
+    if (derive) {
+        TRY(dm((void**)&dW, (R ? R : 1) * (size_t)k * 32));
+        TRY(dm((void**)&dpl, (pgroups + 1) * (size_t)k * 32));
+        TRY(dm((void**)&dsum, 32));
+    }
+    if (derive) TRY(lig_internal_synth_witness(c, job->witness_key, rows, RBv, dW));    // before the stage-1 key is installed below
     HIP_TRY(c, hipMemcpyAsync(dS, psmp, smp_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(dpoly, pcode, vec, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(dpoly + n, plin, vec, hipMemcpyHostToDevice, s));
@@ -208,6 +230,7 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
         if (ci + 1 < n_chunks) TRY(sample_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, drcw, nb, false));
+        if (derive) lig::launch_rlc_accumulate29(s, dW + b * k, k, 1, rb, k, nb, k, nullptr, nullptr, dpl + k, lig_tune::GROUP / 4);   // sum_r b_r o rho_r
         HIP_TRY(c, hipEventRecord(ev_used[ci & 1], s));
         TRY(lig_gather_rows(c, drcw, nb, drg + b * t));
         lig::launch_rlc_rows29(s, dS + b * t, t, 1, drg + b * t, t, nb, t, dcoef + b, vc, vl, dparts, dparts + groups * (size_t)t, lig_tune::GROUP);
@@ -218,6 +241,12 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, dS + (R + 2) * (size_t)t, nullptr, vq, t, fr{}, 0);
     std::vector<H::Fr> vacc(3 * (size_t)t);
     HIP_TRY(c, hipMemcpyAsync(vacc.data(), dacc, vacc.size() * 32, hipMemcpyDeviceToHost, s));
+    H::Fr derived = H::from_u64(0);
+    if (derive) {
+        lig::launch_rlc_combine(s, dpl, dpl + k, (uint32_t)pgroups, k);
+        lig::launch_sum_elems(s, dpl, k, 1, dsum, nullptr);
+        HIP_TRY(c, hipMemcpyAsync(&derived, dsum, 32, hipMemcpyDeviceToHost, s));
+    }
     // ---- decode the prover's polynomials (webgpu_verifier.cpp:355-393)
     std::vector<H::Fr> dec(3 * (size_t)n);
     for (int a = 0; a < 3; a++) {
@@ -235,8 +264,8 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t const_s
     for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) out->valid_code = 0;
     {
         H::Fr a;
-        std::memcpy(a.v, const_sum, 32);
-        if (H::geq(a, H::P)) return LIG_OK;
+        if (derive) a = H::neg(derived);
+        else { std::memcpy(a.v, const_sum, 32); if (H::geq(a, H::P)) return LIG_OK; }
         for (uint32_t i = 0; i < l; i++) a = H::add(a, dec[(size_t)n + i]);
         out->valid_linear = is_zero(a);
     }

@@ -272,6 +272,19 @@ void lo_instance_hash_default(uint8_t out[32]) {
     lo_sha256_final(&s, out);
 }
 
+/* webgpu_prover.cpp:110-168: instance_hash = hash(instance_hash, input_args[i]) over the public arguments, starting
+ * from the zero digest; a vector<u8> argument is fed byte by byte (hash.hpp:75-80), i.e. as its bytes */
+void lo_instance_hash(const uint8_t *args, const uint64_t *lens, size_t n_args, uint8_t out[32]) {
+    lo_instance_hash_default(out);
+    for (size_t i = 0; i < n_args; i++) {
+        lo_sha256 s; lo_sha256_init(&s);
+        lo_sha256_update(&s, out, 32);
+        lo_sha256_update(&s, args, lens[i]);
+        lo_sha256_final(&s, out);
+        args += lens[i];
+    }
+}
+
 /* ------------------------------------------------------------------ column sampling
  * hash_random_engine<sha256> (include/zkp/random.hpp:87-146): refill #0 = SHA256(le64(0)) (the seed is
  * absorbed only AFTER the first flush), refill #c = SHA256(seed || le64(c)); bytes are handed out from
@@ -289,6 +302,10 @@ static uint8_t hre_next(hre_t *e) {
         e->offset = 31;
     }
     return e->buf[e->offset--];
+}
+void lo_hash_engine_bytes(const uint8_t seed[32], size_t count, uint8_t *out) {
+    hre_t e; hre_init(&e, seed);
+    for (size_t i = 0; i < count; i++) out[i] = hre_next(&e);
 }
 /* Restatement of boost::random::detail::generate_uniform_int for an engine with range [0,255]
  * (brange = 255) and an unsigned 64-bit working type -- Boost.Random is NOT vendored in the reference

@@ -6,14 +6,28 @@
  * load this library, and only as the checker / CPU baseline.  The HIP product
  * (ligero-prover_amd/csrc) never links or calls it.
  *
- * Parity status: the reference cannot be compiled here (Dawn/wabt/Boost/
- * protobuf/GMP headers are absent) and ships no golden vectors
- * for NTT outputs, SHA leaves, Merkle roots, sample indices or proof bytes.
- * The only reference-held known-answer tests on this path are the five
- * powmod cases of tests/webgpu/test_powmod.cpp, which this oracle reproduces
- * (tests/test_oracle_kat.py).  Everything else is "parity unpinned" by the
- * reference and is pinned instead against independent definitions (Python
- * big-int Lagrange interpolation, hashlib SHA-256, OpenSSL AES-256-CTR CLI,
+ * Parity status.  The reference as a whole cannot be compiled here (Dawn/wabt/
+ * Boost/protobuf-generated code/GMP headers are absent) and
+ * ships no golden vectors for NTT outputs, SHA leaves, Merkle roots, sample
+ * indices or proof bytes.  What IS pinned to reference code or vectors:
+ *   - montgomery_mul + limb layout: the five powmod cases of
+ *     tests/webgpu/test_powmod.cpp (tests/test_oracle.py);
+ *   - the transcript: the reference's own headers include/zkp/hash.hpp,
+ *     random.hpp, merkle_tree.hpp and params.hpp compile with OpenSSL alone and
+ *     are built into oracle/_ref/libref_transcript.so (ref_transcript.cpp,
+ *     Makefile target _ref): hash_random_engine byte streams, both seed byte
+ *     streams, instance_hash with i64 / str / hex arguments, the AES-256-CTR
+ *     engine's refills, Merkle build / decommit set / recommit.  Vectors
+ *     generated from it are committed (tests/golden/ref_transcript.json,
+ *     tests/golden/make_ref_transcript.py) and checked against this oracle;
+ *   - the proof envelope: serialised with the protobuf runtime from descriptors
+ *     equal to the files under proto/ (tests/golden/make_ref_envelope.py) and compared
+ *     byte for byte with lo_serialize_proof.
+ * Still "parity unpinned": Boost's uniform_int_distribution (not vendored
+ * upstream, absent here; restated from boost/random/uniform_int_distribution.hpp
+ * generate_uniform_int) and therefore the 192 sample indices; NTT outputs,
+ * SHA leaves and the AES field sampler are pinned against independent
+ * definitions (Python big-int Lagrange interpolation, hashlib, OpenSSL CLI,
  * FIPS-197 / FIPS-180 vectors) in tests/.
  *
  * Every function cites the reference file:line (relative to the upstream
@@ -111,6 +125,10 @@ void lo_stage1_seed(const uint8_t root[32], const uint8_t instance_hash[32], uin
 void lo_stage2_seed(const uint8_t root[32], const lo_fr *code, const lo_fr *lin, const lo_fr *quad,
                     size_t n, uint8_t out[32]);
 void lo_instance_hash_default(uint8_t out[32]);               /* only arg0 = "Ligero\0" */
+/* instance_hash chained over arg0 = "Ligero\0" and n_args further public arguments (webgpu_prover.cpp:162-168) */
+void lo_instance_hash(const uint8_t *args, const uint64_t *lens, size_t n_args, uint8_t out[32]);
+/* `count` bytes of hash_random_engine<sha256>(seed) (include/zkp/random.hpp:87-146) */
+void lo_hash_engine_bytes(const uint8_t seed[32], size_t count, uint8_t *out);
 void lo_sample_indices(const uint8_t seed[32], uint32_t n, uint32_t t, uint32_t *out_sorted);
 
 /* ---- proof envelope (proto/{common,ligero_proof}.proto, proof_serializer.hpp:166-191) ---- */
@@ -155,6 +173,9 @@ typedef struct {
     int      threads;
     const lo_batch_op *batch_ops; uint64_t n_batch_ops;        /* optional batch program (NULL / 0: none) */
     const uint8_t *batch_data;    uint64_t batch_data_bytes;
+    /* public arguments after arg0 = "Ligero\0" (src/webgpu_prover.cpp:110-168), byte strings back to back in the form the
+     * reference holds them in input_args (i64 = 8 LE bytes, str with its NUL, hex decoded); NULL / 0: none */
+    const uint8_t *public_args; const uint64_t *public_arg_lens; uint64_t n_public_args;
 } lo_job;
 
 typedef struct {
@@ -171,8 +192,15 @@ typedef struct {
 
 void lo_synth_key(uint64_t seed, uint8_t key[32]);            /* SHA256("lig-synth" || le64(seed)) */
 size_t lo_job_rows(const lo_job *j);                          /* committed rows incl. masks */
+void lo_row_kinds(const lo_job *j, uint8_t *kinds);           /* kind of every non-mask row in commit order (0 linear, 1-3 x/y/z, 4.. batch rows) */
 int  lo_prove(const lo_job *j, lo_proof *out);                /* reference-structured 3-stage prover */
+/* const_sum == NULL: the verifier derives the constant of the linear test from the public statement of the synthetic
+ * stream (the witness_key stream b and the coefficients rho of the stage-1 seed: -sum rho_i b_i), as the reference's
+ * verifier accumulates linear_sums from the public constraint stream (src/webgpu_verifier.cpp:318) */
 int  lo_verify(const lo_job *j, const lo_fr *const_sum, const uint8_t *proof, size_t len);   /* 1 = accept */
+/* the dense stage-2 randomness rows of the synthetic stream ((rows - 3) x k: one linear-stream draw per data slot in
+ * commit order, zeros elsewhere and for batch rows) and the constant -sum <witness row, randomness row> */
+void lo_rand_rows(const lo_job *j, const uint8_t stage1_seed[32], lo_fr *rands, lo_fr *const_sum);
 void lo_proof_free(lo_proof *p);
 /* row former exposed for tests: fills rows[(rows) * k] message rows in commit order (masks: code row k elems,
  * linear/quad masks 2k elems are returned separately) */

@@ -141,6 +141,7 @@ static void batch_run(const lo_job *j, lo_rng *enc, lo_fr *rows) {
 #undef COMMIT
     free(vars); free(tmp);
 }
+void lo_row_kinds(const lo_job *j, uint8_t *kinds) { rowdesc *d; size_t R = plan_rows(j, &d); for (size_t r = 0; r < R; r++) kinds[r] = (uint8_t)d[r].kind; free(d); }
 size_t lo_job_rows(const lo_job *j) { rowdesc *d; size_t r = plan_rows(j, &d); free(d); return r + 3; }
 
 /* process_reset_linear_row / _quadratic_rows / process_masks (witness_manager.hpp:200-321).
@@ -252,6 +253,26 @@ static size_t batch_len(const rowdesc *d, size_t b, size_t R, size_t B) {
 /* dense stage-2 randomness rows: one linear-stream draw per data slot, in commit order */
 static void rand_row(lo_rng *lin, lo_fr *row, uint32_t data, uint32_t k) { memset(row, 0, sizeof(lo_fr) * k); lo_rng_fill(lin, row, data); }
 
+void lo_rand_rows(const lo_job *j, const uint8_t stage1_seed[32], lo_fr *rands, lo_fr *const_sum) {
+    const uint32_t k = j->k;
+    rowdesc *d; size_t R = plan_rows(j, &d);
+    lo_fr *rows = NULL, *mc = NULL, *ml = NULL, *mq = NULL, *rr = malloc(sizeof(lo_fr) * k);
+    if (const_sum) {
+        rows = malloc(sizeof(lo_fr) * (R ? R : 1) * k);
+        mc = malloc(sizeof(lo_fr) * k); ml = malloc(sizeof(lo_fr) * 2 * k); mq = malloc(sizeof(lo_fr) * 2 * k);
+        lo_form_rows(j, rows, mc, ml, mq);
+    }
+    lo_rng lin; lo_rng_init(&lin, stage1_seed);
+    lo_fr csum; lo_fr_from_u64(&csum, 0);
+    for (size_t r = 0; r < R; r++) {
+        lo_fr *dst = rands ? rands + r * k : rr;
+        rand_row(&lin, dst, d[r].data, k);
+        if (const_sum) for (uint32_t i = 0; i < d[r].data; i++) { lo_fr pr; lo_fr_mul(&pr, &rows[r * k + i], &dst[i]); lo_fr_add(&csum, &csum, &pr); }
+    }
+    if (const_sum) lo_fr_neg(const_sum, &csum);
+    free(rows); free(mc); free(ml); free(mq); free(rr); free(d);
+}
+
 int lo_prove(const lo_job *j, lo_proof *P) {
     memset(P, 0, sizeof *P);
     const uint32_t l = j->l, k = j->k, n = j->n, t = j->t;
@@ -291,7 +312,7 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     lo_colsha_final(st, leaves, n);
     lo_merkle_build(leaves, n, nodes);
     memcpy(P->root, nodes, 32);
-    uint8_t ih[32]; lo_instance_hash_default(ih);
+    uint8_t ih[32]; lo_instance_hash(j->public_args, j->public_arg_lens, j->n_public_args, ih);
     lo_stage1_seed(P->root, ih, P->stage1_seed);
     P->t_stage1 = now_s() - t0;
 
@@ -446,7 +467,7 @@ int lo_verify(const lo_job *j, const lo_fr *const_sum, const uint8_t *proof, siz
         lo_fr *S = malloc(sizeof(lo_fr) * (R + 3) * t);
         memcpy(pc, code, 32ull * n); memcpy(pl, lin, 32ull * n); memcpy(pq, quad, 32ull * n); memcpy(S, smp, 32ull * (R + 3) * t);
         uint8_t ih[32], s1[32], s2[32];
-        lo_instance_hash_default(ih); lo_stage1_seed(root, ih, s1); lo_stage2_seed(root, pc, pl, pq, n, s2);
+        lo_instance_hash(j->public_args, j->public_arg_lens, j->n_public_args, ih); lo_stage1_seed(root, ih, s1); lo_stage2_seed(root, pc, pl, pq, n, s2);
         uint32_t *si = malloc(sizeof(uint32_t) * t);
         lo_sample_indices(s2, n, t, si);
         if (memcmp(si, idx, sizeof(uint32_t) * t)) ok = 0;
@@ -491,6 +512,8 @@ int lo_verify(const lo_job *j, const lo_fr *const_sum, const uint8_t *proof, siz
         }
         /* the verifier recomputes the constant sum from the public constraint stream (linear_sums,
          * webgpu_verifier.cpp:318); in the synthetic stream it is a public input of the statement */
+        lo_fr derived;
+        if (!const_sum) { lo_rand_rows(j, s1, NULL, &derived); const_sum = &derived; }
         lo_decode(c, pl); { lo_fr acc = *const_sum; for (uint32_t i = 0; i < l; i++) lo_fr_add(&acc, &acc, &pl[i]); if (!lo_fr_is_zero(&acc)) ok = 0; }
         lo_decode(c, pc); for (uint32_t i = k; i < n; i++) if (!lo_fr_is_zero(&pc[i])) ok = 0;
         lo_decode(c, pq); for (uint32_t i = 0; i < l; i++) if (!lo_fr_is_zero(&pq[i])) ok = 0;

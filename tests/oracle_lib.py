@@ -27,7 +27,17 @@ class Job(C.Structure):
                 ("n_linear", C.c_uint64), ("n_quad", C.c_uint64),
                 ("encoding_seed", C.c_uint8 * 32), ("witness_key", C.c_uint8 * 32),
                 ("generated_at", C.c_int64), ("threads", C.c_int),
-                ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64)]
+                ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64),
+                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64)]
+
+    def set_public_args(self, args):
+        args = [bytes(a) for a in (args or [])]
+        blob = np.frombuffer(b"".join(args) or b"\0", dtype=np.uint8).copy()
+        lens = np.array([len(a) for a in args] or [0], dtype=np.uint64)
+        self._pub_keep = (blob, lens)
+        self.public_args = blob.ctypes.data if args else None
+        self.public_arg_lens = lens.ctypes.data if args else None
+        self.n_public_args = len(args)
 
 
 class Proof(C.Structure):
@@ -77,6 +87,9 @@ def lib():
         L.lo_stage1_seed.argtypes = [C.c_void_p] * 3
         L.lo_stage2_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lo_instance_hash_default.argtypes = [C.c_void_p]
+        L.lo_instance_hash.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lo_hash_engine_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lo_rand_rows.argtypes = [C.POINTER(Job), C.c_void_p, C.c_void_p, C.c_void_p]
         L.lo_sample_indices.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lo_synth_key.argtypes = [C.c_uint64, C.c_void_p]
         L.lo_job_rows.restype = C.c_size_t
@@ -220,8 +233,52 @@ def keystream(key, first_block, nblocks):
     return out.tobytes()
 
 
-def make_job(l, k, n, t, n_linear, n_quad=0, synth_seed=1, generated_at=0, threads=1):
+def instance_hash(args):
+    args = [bytes(a) for a in args]
+    blob = np.frombuffer(b"".join(args) or b"\0", dtype=np.uint8).copy()
+    lens = np.array([len(a) for a in args] or [0], dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint8)
+    lib().lo_instance_hash(ptr(blob), ptr(lens), len(args), ptr(out))
+    return out.tobytes()
+
+
+def hash_engine_bytes(seed, count):
+    s = np.frombuffer(bytes(seed), dtype=np.uint8).copy()
+    out = np.zeros(count, dtype=np.uint8)
+    lib().lo_hash_engine_bytes(ptr(s), count, ptr(out))
+    return out.tobytes()
+
+
+def rand_rows(job, stage1_seed):
+    """-> ((R, k, 8) dense stage-2 randomness rows, const_sum bytes)"""
+    R = lib().lo_job_rows(C.byref(job)) - 3
+    out = np.zeros((max(R, 1), job.k, 8), dtype=np.uint32)
+    cs = np.zeros(8, dtype=np.uint32)
+    s = np.frombuffer(bytes(stage1_seed), dtype=np.uint8).copy()
+    lib().lo_rand_rows(C.byref(job), ptr(s), ptr(out), ptr(cs))
+    return out[:R], cs.tobytes()
+
+
+def row_kinds(job):
+    R = lib().lo_job_rows(C.byref(job)) - 3
+    out = np.zeros(max(R, 1), dtype=np.uint8)
+    lib().lo_row_kinds.argtypes = [C.POINTER(Job), C.c_void_p]
+    lib().lo_row_kinds(C.byref(job), ptr(out))
+    return out[:R]
+
+
+def form_rows(job):
+    """-> ((R, k, 8) message rows in commit order incl. pads, mask_code (k,8), mask_lin (2k,8), mask_quad (2k,8))"""
+    R = lib().lo_job_rows(C.byref(job)) - 3
+    rows = np.zeros((max(R, 1), job.k, 8), dtype=np.uint32)
+    mc, ml, mq = (np.zeros((m * job.k, 8), dtype=np.uint32) for m in (1, 2, 2))
+    lib().lo_form_rows(C.byref(job), ptr(rows), ptr(mc), ptr(ml), ptr(mq))
+    return rows[:R], mc, ml, mq
+
+
+def make_job(l, k, n, t, n_linear, n_quad=0, synth_seed=1, generated_at=0, threads=1, public_args=None):
     j = Job()
+    j.set_public_args(public_args)
     j.l, j.k, j.n, j.t = l, k, n, t
     j.n_linear, j.n_quad = n_linear, n_quad
     for i in range(32):

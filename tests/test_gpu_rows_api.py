@@ -1,0 +1,199 @@
+"""GPU: the caller-rows prover entry (lig_rows_begin / lig_rows_commit / lig_rows_prove), public arguments, the
+verifier's derived linear constant, and configs[2] at full size.
+
+A row-batching driver of the reference's constraint generator hands the backend (a) the rows witness_manager forms
+(include/zkp/backend/witness_manager.hpp:200-269), (b) after the stage-1 seed is known, the per-witness randomness rows
+and the public constant of the linear test (include/zkp/nonbatch_context.hpp:654-780, src/webgpu_prover.cpp:307).
+Here the oracle plays that driver: lo_form_rows / lo_rand_rows are fed through the rows entry and the envelope must be
+byte-identical to the oracle's reference-structured prover.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hip_lib
+import oracle_lib as ol
+import test_batch_rows as tb
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    return hip_lib.load()
+
+
+def oracle_prove(job):
+    pr = ol.Proof()
+    assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) == 0
+    out = dict(proof=bytes(pr.proof[:pr.proof_len]), root=bytes(pr.root), seed1=bytes(pr.stage1_seed), seed2=bytes(pr.stage2_seed),
+               const_sum=bytes(pr.const_sum), rows=pr.rows, valid=(pr.valid_code, pr.valid_linear, pr.valid_quad))
+    ol.lib().lo_proof_free(C.byref(pr))
+    return out
+
+
+PUB = [(42).to_bytes(8, "little"), b"statement\0", bytes.fromhex("00ff10")]
+
+
+@pytest.mark.parametrize("l,k,n,n_linear,n_quad,prog,pub", [
+    (320, 512, 2048, 700, 0, None, None),
+    (320, 512, 2048, 640, 330, None, PUB),
+    (320, 512, 2048, 0, 0, None, None),                       # masks only
+    (320, 512, 2048, 320 * 600 + 5, 320 + 9, None, None),     # > one 512-row chunk, a triple across the boundary region
+    (320, 512, 2048, 100, 0, "demo", PUB),                    # batch rows (init / equal / product / bit rows) ahead of the stream
+    (8000, 8192, 32768, 3 * 8000 + 123, 8000 + 5, None, None),
+])
+@pytest.mark.parametrize("mode", ["host_rows_library_pads", "device_rows_own_pads"])
+def test_rows_entry_equals_oracle(amd, l, k, n, n_linear, n_quad, prog, pub, mode):
+    job = ol.make_job(l, k, n, 192, n_linear, n_quad, generated_at=77, threads=8, public_args=pub)
+    if prog:
+        tb.demo_program().attach(job)
+    want = oracle_prove(job)
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job).copy()
+    R = rows.shape[0]
+    c = amd.Context(l, k, n)
+    try:
+        if mode == "host_rows_library_pads":
+            # the driver leaves the padding slots of every row that draws padding upstream to the library
+            msgs = rows.copy()
+            draws = (kinds <= 3) | (kinds == amd.ROW_KINDS["INIT"])
+            msgs[draws, l:] = 0xDEADBEEF                       # whatever is there must be overwritten
+            kinds[draws] |= amd.ROW_DRAW_PAD
+            tr, keep = c.rows_begin(kinds, msgs, on_device=False, generated_at=77, public_args=pub)
+        else:
+            d_msgs = c.upload(rows) if R else c.malloc(32)
+            tr, keep = c.rows_begin(kinds, d_msgs, on_device=True, generated_at=77, public_args=pub)
+        root, seed1 = c.rows_commit(tr)
+        assert root == want["root"] and seed1 == want["seed1"]
+        rands, const_sum = ol.rand_rows(job, seed1)            # the driver's second pass: randomness rows + public constant
+        assert const_sum == want["const_sum"]
+        if mode == "host_rows_library_pads":
+            proof, info = c.rows_prove(tr, rands, const_sum, on_device=False)
+        else:
+            d_r = c.upload(rands) if R else c.malloc(32)
+            proof, info = c.rows_prove(tr, d_r, const_sum, on_device=True)
+        c.trace_destroy(tr)
+        assert info.rows == want["rows"]
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert bytes(info.stage2_seed) == want["seed2"]
+        assert proof == want["proof"]
+        # both verifiers accept it, deriving the constant from the public statement themselves
+        hjob = amd.Context.make_job(n_linear, n_quad, generated_at=77, public_args=pub)
+        if prog:
+            tb.demo_program().attach(hjob)
+        assert c.synth_verify(hjob, None, proof).accept == 1
+        buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+        assert ol.lib().lo_verify(C.byref(job), None, buf, len(proof)) == 1
+    finally:
+        c.close()
+
+
+def test_rows_entry_rejects_malformed_jobs(amd):
+    l, k, n = 320, 512, 2048
+    c = amd.Context(l, k, n)
+    try:
+        msgs = np.zeros((3, k, 8), dtype=np.uint32)
+        for kinds in ([1, 2], [2, 3, 0], [0, 3], [6], [7, 0], [8, 9], [11], [5 | 0x80], [6 | 0x80, 7]):
+            with pytest.raises(amd.LigError):
+                c.rows_begin(np.array(kinds, dtype=np.uint8), msgs[:len(kinds)])
+        tr, keep = c.rows_begin(np.array([0], dtype=np.uint8), msgs[:1])
+        with pytest.raises(amd.LigError):                      # prove before commit
+            c.rows_prove(tr, msgs[:1], bytes(32))
+        c.rows_commit(tr)
+        with pytest.raises(amd.LigError):                      # constant not reduced
+            c.rows_prove(tr, msgs[:1], b"\xff" * 32)
+        with pytest.raises(amd.LigError):                      # commit twice
+            c.rows_commit(tr)
+        # a wrong public constant is not an error: the prover's self-check reports it
+        proof, info = c.rows_prove(tr, msgs[:1], (5).to_bytes(32, "little"))
+        assert info.valid_linear == 0 and info.valid_code == 1
+        c.trace_destroy(tr)
+    finally:
+        c.close()
+    with pytest.raises(amd.LigError):                          # k - l < 192: fewer random pads than opened columns
+        c2 = amd.Context(400, 512, 2048)
+        try:
+            c2.synth_prepare(100)
+        finally:
+            c2.close()
+
+
+def test_public_args_and_derived_linear_constant(amd):
+    """instance_hash with public arguments enters both seeds; the verifier derives the constant of the linear test from the
+    public statement (witness_key stream) -- a proof for another statement fails exactly the linear predicate"""
+    l, k, n, nl, nq = 320, 512, 2048, 2000, 400
+    c = amd.Context(l, k, n)
+    try:
+        job = amd.Context.make_job(nl, nq, generated_at=9, public_args=PUB)
+        tr = c.synth_prepare_job(job)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        want = oracle_prove(ol.make_job(l, k, n, 192, nl, nq, generated_at=9, threads=8, public_args=PUB))
+        assert proof == want["proof"]
+        plain = oracle_prove(ol.make_job(l, k, n, 192, nl, nq, generated_at=9, threads=8))
+        assert plain["root"] == want["root"] and plain["seed1"] != want["seed1"]        # args enter after the commitment
+        v = c.synth_verify(job, None, proof)
+        assert v.accept == 1
+        assert c.synth_verify(job, bytes(info.const_sum), proof).accept == 1          # caller-supplied constant still works
+        # same rows, other public arguments: the code / linear / quadratic coefficients differ -> not accepted
+        assert c.synth_verify(amd.Context.make_job(nl, nq, generated_at=9), None, proof).accept == 0
+        # another public statement (witness_key): everything but the linear predicate still holds
+        other = amd.Context.make_job(nl, nq, synth_seed=2, generated_at=9, public_args=PUB)
+        vo = c.synth_verify(other, None, proof)
+        assert (vo.accept, vo.valid_linear, vo.valid_merkle, vo.valid_code, vo.valid_quad, vo.code_equal, vo.linear_equal, vo.quad_equal) == \
+            (0, 0, 1, 1, 1, 1, 1, 1)
+        ojob = ol.make_job(l, k, n, 192, nl, nq, synth_seed=2, generated_at=9, threads=8, public_args=PUB)
+        buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+        assert ol.lib().lo_verify(C.byref(ojob), None, buf, len(proof)) == 0
+    finally:
+        c.close()
+
+
+def test_full_size_600_rows_against_oracle_on_host_cores(amd):
+    """k = 8192 beyond one 512-row launch chunk: multi-chunk encode, the randomness double-buffer ring, the hash gate
+    (nb > 4) and the 96-row schedule tails, all compared byte for byte with the oracle run on this box's host cores"""
+    l, k, n = 8000, 8192, 32768
+    nl, nq = 600 * 8000 + 77, 8 * 8000 + 5            # 601 linear rows + 27 quadratic rows = 628 rows + 3 masks
+    c = amd.Context(l, k, n)
+    try:
+        tr = c.synth_prepare(nl, nq, generated_at=5)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        job = amd.Context.make_job(nl, nq, generated_at=5)
+        assert c.synth_verify(job, None, proof).accept == 1
+    finally:
+        c.close()
+    want = oracle_prove(ol.make_job(l, k, n, 192, nl, nq, generated_at=5, threads=os.cpu_count() or 8))
+    assert info.rows == want["rows"] == 631
+    assert hashlib.sha256(proof).hexdigest() == hashlib.sha256(want["proof"]).hexdigest()
+    assert proof == want["proof"]
+
+
+def test_configs2_full_size_proof_equals_oracle_pin(amd):
+    """the exact bench.py job (2^24 linear constraints, k = 8192, synthetic seed 1, encoding seed 0..31, generated_at 0):
+    the envelope's SHA-256, root, seeds and constant equal tests/golden/full_pin_2p24.json, which the oracle's
+    reference-structured prover produced (tests/golden/make_full_pin.py)"""
+    with open(os.path.join(GOLD, "full_pin_2p24.json")) as f:
+        pin = json.load(f)
+    c = amd.Context(pin["l"], pin["k"], pin["n"])
+    try:
+        tr = c.synth_prepare(pin["n_linear"], pin["n_quad"], synth_seed=pin["synth_seed"], generated_at=pin["generated_at"])
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        assert info.rows == pin["rows"] and len(proof) == pin["proof_len"]
+        assert bytes(info.root).hex() == pin["root"]
+        assert bytes(info.stage1_seed).hex() == pin["stage1_seed"]
+        assert bytes(info.stage2_seed).hex() == pin["stage2_seed"]
+        assert bytes(info.const_sum).hex() == pin["const_sum"]
+        assert hashlib.sha256(proof).hexdigest() == pin["proof_sha256"]
+        assert list(amd.sample_columns(bytes(info.stage2_seed), pin["n"])) == pin["sample_idx"]
+        job = amd.Context.make_job(pin["n_linear"], pin["n_quad"], synth_seed=pin["synth_seed"], generated_at=pin["generated_at"])
+        assert c.synth_verify(job, None, proof).accept == 1
+    finally:
+        c.close()

@@ -1,0 +1,178 @@
+"""CPU-only: the transcript and the envelope pinned to the REFERENCE's own code.
+
+* tests/golden/ref_transcript.json was produced by oracle/_ref/libref_transcript.so = the reference's
+  include/zkp/{hash,random,merkle_tree}.hpp + params.hpp compiled in the build container (oracle/ref_transcript.cpp,
+  tests/golden/make_ref_transcript.py).  The oracle's restatement (oracle/hash.c) and the product's host transcript
+  (liblig_hip.so: lig_instance_hash, lig_sample_columns' byte engine through the shared code path) must reproduce it.
+* tests/golden/ref_envelope.json was produced by the protobuf runtime from descriptors parsed out of the reference's
+  proto/*.proto (tests/golden/make_ref_envelope.py); the oracle's hand-written encoder must give the same bytes.
+* when oracle/_ref/libref_transcript.so is present (build container, or shipped to the GPU box as a built file) the same
+  comparisons also run live on fresh random inputs.
+Still unpinned by reference code: Boost's uniform_int_distribution (absent here), see DESIGN.md section 5.
+"""
+import ctypes as C
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hip_lib
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+REF_SO = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_transcript.so")
+ARG0 = b"Ligero\0"
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def load_script(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(GOLD, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def xof(tag, n):
+    out, c = b"", 0
+    while len(out) < n:
+        out += hashlib.sha256(tag + c.to_bytes(4, "little")).digest()
+        c += 1
+    return out[:n]
+
+
+def limbs(b):
+    return np.frombuffer(b, dtype=np.uint32).reshape(-1, 8).copy()
+
+
+def oracle_stage1(root, ih):
+    out = np.zeros(32, dtype=np.uint8)
+    r, i = (np.frombuffer(x, dtype=np.uint8).copy() for x in (root, ih))
+    ol.lib().lo_stage1_seed(ol.ptr(r), ol.ptr(i), ol.ptr(out))
+    return out.tobytes()
+
+
+def oracle_stage2(root, code, lin, quad):
+    out = np.zeros(32, dtype=np.uint8)
+    r = np.frombuffer(root, dtype=np.uint8).copy()
+    c, l, q = limbs(code), limbs(lin), limbs(quad)
+    ol.lib().lo_stage2_seed(ol.ptr(r), ol.ptr(c), ol.ptr(l), ol.ptr(q), c.shape[0], ol.ptr(out))
+    return out.tobytes()
+
+
+def canonical_order(pairs):
+    """(heap position, digest) pairs -> the serializer's sibling order (include/zkp/proof_serializer.hpp:82-117:
+    levels bottom-up, left to right inside a level)"""
+    return [d for _, d in sorted(pairs, key=lambda pd: (-(int(pd[0]) + 1).bit_length(), int(pd[0])))]
+
+
+def check_merkle_case(case, leaves):
+    n, idx = case["n_leaves"], case["idx"]
+    lv = np.frombuffer(b"".join(leaves), dtype=np.uint8).reshape(n, 32).copy()
+    nodes = ol.merkle_build(lv)
+    assert nodes.shape[0] == case["nodes"]
+    assert nodes[0].tobytes().hex() == case["root"]
+    assert hashlib.sha256(nodes.tobytes()).hexdigest() == case["nodes_sha256"]
+    sib = ol.merkle_decommit(nodes, n, idx)
+    want = canonical_order([(p, bytes.fromhex(d)) for p, d in case["decommit"]])
+    assert [s.tobytes() for s in sib] == want
+    # the reference's recommit accepted its own decommitment; the oracle's recommit must rebuild the same root from ours
+    assert case["recommit_root"] == case["root"]
+    P = nodes.shape[0] // 2 + 1
+    leafd = np.ascontiguousarray(nodes[P - 1 + np.array(idx)])
+    root = np.zeros(32, dtype=np.uint8)
+    ok = ol.lib().lo_merkle_recommit(n, ol.ptr(np.array(idx, dtype=np.uint32)), len(idx), ol.ptr(leafd),
+                                     ol.ptr(np.ascontiguousarray(sib)), sib.shape[0], ol.ptr(root))
+    assert ok and root.tobytes().hex() == case["root"]
+
+
+def test_transcript_vs_reference_compiled_vectors():
+    g = gold("ref_transcript.json")
+    hip = hip_lib.load()
+    # hash_random_engine (include/zkp/random.hpp:87-146): 200 bytes = 7 refills; refill 0 ignores the seed
+    for v in g["hash_engine"]:
+        assert ol.hash_engine_bytes(bytes.fromhex(v["seed"]), 200).hex() == v["bytes"]
+    assert len({v["bytes"][:64] for v in g["hash_engine"]}) == 1 and len({v["bytes"][64:] for v in g["hash_engine"]}) == 3
+    # instance_hash (src/webgpu_prover.cpp:110-168) with i64 / str / hex arguments: oracle and the product's host helper
+    for v in g["instance_hash"]:
+        args = [bytes.fromhex(a) for a in v["args"]]
+        assert ol.instance_hash(args).hex() == v["hash"]
+        assert hip.instance_hash(args).hex() == v["hash"]
+    by_name = {v["name"]: v for v in g["instance_hash"]}
+    assert [a.hex() for a in (hip.public_arg_bytes("i64", 42), hip.public_arg_bytes("str", "hello"), hip.public_arg_bytes("hex", "0xabc"))] == \
+        [by_name["i64"]["args"][0], by_name["str"]["args"][0], by_name["hex"]["args"][0]]
+    assert hip.public_arg_bytes("i64", -1).hex() == by_name["i64_neg"]["args"][0]
+    # both seed byte streams (hash.hpp:44-118: the literal with its NUL, digests raw, vector<u32> as LE bytes)
+    for v in g["stage1_seed"]:
+        assert oracle_stage1(bytes.fromhex(v["root"]), bytes.fromhex(v["instance_hash"])).hex() == v["seed"]
+    for v in g["stage2_seed"]:
+        vecs = [xof(t.encode(), 32 * v["n_elems"]) for t in v["xof_tags"]]
+        assert oracle_stage2(bytes.fromhex(v["root"]), *vecs).hex() == v["seed"]
+    # aes256ctr_engine<uint64_t> (random.hpp:29-84): one continuing CTR stream across the 16 KiB refills
+    for v in g["aes_engine_u64"]:
+        ks = ol.keystream(bytes.fromhex(v["key"]), 0, (2048 * 2 + 4) * 8 // 16)
+        w = [int.from_bytes(ks[8 * i:8 * i + 8], "little") for i in range(2048 * 2 + 4)]
+        assert w[:4] == v["first4"] and w[2046:2050] == v["around_refill_1"] and w[4094:4098] == v["around_refill_2"]
+        assert hashlib.sha256(ks).hexdigest() == v["sha256_le64"]
+    # Merkle build / decommit / recommit (include/zkp/merkle_tree.hpp:155-375)
+    for case in g["merkle"]:
+        n = case["n_leaves"]
+        check_merkle_case(case, [xof(b"leaf%d_%d" % (n, i), 32) for i in range(n)])
+
+
+def test_envelope_vs_protobuf_runtime_vectors():
+    g = gold("ref_envelope.json")
+    mk = load_script("make_ref_envelope") if importlib.util.find_spec("google.protobuf") else None
+    for c in g["cases"]:
+        tag = c["name"].encode()
+        idx = sorted(set(int.from_bytes(xof(tag + b"idx", 4 * c["n_idx"])[4 * i:4 * i + 4], "little") % c["n"] for i in range(c["n_idx"])))
+        sib = b"".join(xof(tag + b"sib%d" % i, 32) for i in range(c["n_sib"]))
+        code, lin, quad = (limbs(xof(tag + t, 32 * c["n"])) for t in (b"code", b"lin", b"quad"))
+        smp = xof(tag + b"smp", 32 * c["rows"] * c["t"])
+        smp_a = limbs(smp) if smp else np.zeros((1, 8), dtype=np.uint32)
+        sib_a = np.frombuffer(sib or b"\0", dtype=np.uint8).copy()
+        idx_a = np.array(idx or [0], dtype=np.uint32)
+        ph, root = (np.frombuffer(xof(tag + t, 32), dtype=np.uint8).copy() for t in (b"ph", b"root"))
+        L = ol.lib()
+        L.lo_serialize_proof.restype = C.c_size_t
+        L.lo_serialize_proof.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4 + [C.c_size_t]
+        args = (c["version"].encode(), ol.ptr(ph), c["generated_at"], c["k"], c["n"], c["t"], ol.ptr(root), ol.ptr(sib_a), c["n_sib"],
+                ol.ptr(idx_a), len(idx), ol.ptr(code), ol.ptr(lin), ol.ptr(quad), ol.ptr(smp_a), c["rows"] * c["t"])
+        need = L.lo_serialize_proof(None, 0, *args)
+        assert need == c["length"], c["name"]
+        buf = np.zeros(need, dtype=np.uint8)
+        L.lo_serialize_proof(ol.ptr(buf), need, *args)
+        assert hashlib.sha256(buf.tobytes()).hexdigest() == c["sha256"], c["name"]
+        assert buf.tobytes()[:96].hex() == c["head"]
+        if mk is not None and os.path.isdir(mk.PROTO_DIR):            # build container: also live against the runtime
+            assert mk.serialize(mk.build_pool(), c) == buf.tobytes()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref is built only where the upstream tree exists")
+def test_transcript_live_against_reference_build():
+    mk = load_script("make_ref_transcript")
+    L = mk.load()
+    rng = np.random.default_rng(20260928)
+    for _ in range(20):
+        seed = rng.bytes(32)
+        cnt = int(rng.integers(1, 400))
+        assert ol.hash_engine_bytes(seed, cnt) == mk.engine_bytes(L, seed, cnt)
+        args = [rng.bytes(int(rng.integers(0, 40))) for _ in range(int(rng.integers(0, 5)))]
+        assert ol.instance_hash(args) == mk.instance_hash(L, [ARG0] + args)
+        root, ih = rng.bytes(32), rng.bytes(32)
+        assert oracle_stage1(root, ih) == mk.stage1(L, root, ih)
+        nel = int(rng.integers(1, 300))
+        vecs = [rng.bytes(32 * nel) for _ in range(3)]
+        assert oracle_stage2(root, *vecs) == mk.stage2(L, root, *vecs)
+    for n in (1, 2, 5, 64, 100, 512):
+        leaves = [rng.bytes(32) for _ in range(n)]
+        idx = sorted(set(int(x) for x in rng.integers(0, n, size=min(n, 7))))
+        check_merkle_case(mk.merkle(L, leaves, idx), leaves)
