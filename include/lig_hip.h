@@ -247,8 +247,13 @@ typedef struct {
 } lig_rows_job;
 int lig_rows_begin(lig_ctx *ctx, const lig_rows_job *job, lig_trace **out);
 int lig_rows_commit(lig_trace *trace, uint8_t root[32], uint8_t stage1_seed[32]);
-int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, const uint8_t const_sum[32],
+/* const_sum == NULL: the constant is taken to be -sum_r <row_r, rand_r> (returned in info->const_sum) -- for statements that
+ * are the rows themselves, like the synthetic stream; the prover's own linear self-check is then vacuous. */
+int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, const uint8_t *const_sum,
                    const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+/* the next trace of the same shape (same kinds, seeds, metadata) with new message rows, reusing every buffer of `trace`
+ * (no allocation on the proving path of a service); same upload semantics as lig_rows_begin */
+int lig_rows_restart(lig_trace *trace, const void *msgs, int msgs_on_device);
 /* rows x k dense randomness rows on the device: row r = per_row[r] successive elements of the AES-256-CTR field stream
  * keyed by key32 (row r starts where row r-1 ended, the first at first_elem), zeros up to k -- the linear-test
  * coefficient rows of the synthetic stream, for callers that feed lig_rows_prove from the device. */

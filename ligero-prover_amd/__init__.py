@@ -30,7 +30,7 @@ EXPORTS = [
     "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
     "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify",
     "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
-    "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rng_fill_rows",
+    "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
 ]
 
@@ -163,6 +163,7 @@ def load_library():
     L.lig_shard_destroy.restype = None
     L.lig_rows_begin.argtypes = [vp, C.POINTER(RowsJob), C.POINTER(vp)]
     L.lig_rows_commit.argtypes = [vp, vp, vp]
+    L.lig_rows_restart.argtypes = [vp, vp, C.c_int]
     L.lig_rows_prove.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_rng_fill_rows.argtypes = [vp, vp, u64, vp, sz, vp]
     L.lig_public_arg_bytes.argtypes = [C.c_int, C.c_char_p, vp, sz, C.POINTER(sz)]
@@ -418,6 +419,10 @@ class Context:
         self.check(self.L.lig_rows_begin(self.h, C.byref(job), C.byref(t)))
         return t, keep + (job,)
 
+    def rows_restart(self, trace, msgs, on_device=False):
+        p = msgs if on_device else C.c_void_p(msgs if isinstance(msgs, int) else msgs.ctypes.data)
+        self.check(self.L.lig_rows_restart(trace, p, int(bool(on_device))))
+
     def rows_commit(self, trace):
         root, seed = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)
         self.check(self.L.lig_rows_commit(trace, _hptr(root), _hptr(seed)))
@@ -425,7 +430,7 @@ class Context:
 
     def rows_prove(self, trace, rands, const_sum, on_device=False, copy=True):
         proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
-        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy()
+        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy() if const_sum is not None else None
         if on_device:
             rp = rands
         else:

@@ -594,6 +594,33 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     return LIG_OK;
 }
 
+// message rows of a rows job -> T->msgs.  Device rows: one copy on the main stream.  Host rows: the upload starts now, on
+// the copy stream, one event per stage-1 chunk: lig_rows_commit encodes chunk b while chunk b+1 is still on the bus.
+static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device) {
+    const uint32_t k = c->k;
+    const size_t R = T->R;
+    T->host_msgs = nullptr;
+    if (!R) return LIG_OK;
+    if (on_device) {
+        HIP_TRY(c, hipMemcpyAsync(T->msgs, msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
+        return LIG_OK;
+    }
+    T->host_msgs = (const uint8_t*)msgs;
+    if (T->ev_up.empty()) {
+        T->ev_up.resize(T->sched1.size(), nullptr);
+        for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // the previous proof of this trace may still be reading T->msgs on the main stream (stage 2): order the upload behind it
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+    for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+        const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
+        HIP_TRY(c, hipMemcpyAsync(T->msgs + b * (size_t)k, T->host_msgs + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, c->stream3));
+        HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
+    }
+    return LIG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // rows supplied by the caller (include/lig_hip.h, lig_rows_*)
 static int rows_begin_impl(lig_ctx* c, const lig_rows_job* job, lig_trace* T) {
@@ -638,22 +665,7 @@ static int rows_begin_impl(lig_ctx* c, const lig_rows_job* job, lig_trace* T) {
             T->pad_runs.push_back({r, e - r, pos[r]});
             r = e;
         }
-    if (!R) return LIG_OK;
-    if (job->msgs_on_device) {
-        HIP_TRY(c, hipMemcpyAsync(T->msgs, job->msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        // the upload starts now, on the copy stream, one event per stage-1 chunk: lig_rows_commit encodes chunk b while chunk
-        // b+1 is still on the bus
-        T->host_msgs = (const uint8_t*)job->msgs;
-        T->ev_up.resize(T->sched1.size(), nullptr);
-        for (size_t ci = 0; ci < T->sched1.size(); ci++) {
-            const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
-            HIP_TRY(c, hipEventCreateWithFlags(&T->ev_up[ci], hipEventDisableTiming));
-            HIP_TRY(c, hipMemcpyAsync(T->msgs + b * (size_t)k, T->host_msgs + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, c->stream3));
-            HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
-        }
-    }
-    return LIG_OK;
+    return rows_load(c, T, job->msgs, job->msgs_on_device != 0);
 }
 int lig_rows_begin(lig_ctx* c, const lig_rows_job* job, lig_trace** out) {
     CHECK_CTX(c);
@@ -666,6 +678,15 @@ int lig_rows_begin(lig_ctx* c, const lig_rows_job* job, lig_trace** out) {
     if (rc != LIG_OK) { lig_trace_destroy(T); return rc; }
     *out = T;
     return LIG_OK;
+}
+int lig_rows_restart(lig_trace* T, const void* msgs, int msgs_on_device) {
+    if (!T) return LIG_E_ARG;
+    lig_ctx* c = T->c;
+    CHECK_CTX(c);
+    if (!T->from_rows) FAIL(c, LIG_E_STATE, "lig_rows_restart: not a rows trace");
+    if (T->R && !msgs) FAIL(c, LIG_E_ARG, "lig_rows_restart: null rows");
+    T->state = 0;
+    return rows_load(c, T, msgs, msgs_on_device != 0);
 }
 int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
     if (!T) return LIG_E_ARG;
@@ -685,12 +706,12 @@ int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
 }
 int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const uint8_t const_sum[32], const uint8_t** proof,
                    size_t* proof_len, lig_proof_info* info) {
-    if (!T || !proof || !proof_len || !info || !const_sum) return LIG_E_ARG;
+    if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = T->c;
     CHECK_CTX(c);
     if (!T->from_rows || T->state != 1) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_commit has not run on this trace");
     if (T->R && !rands) FAIL(c, LIG_E_ARG, "lig_rows_prove: null randomness rows");
-    {
+    if (const_sum) {
         H::Fr v;
         std::memcpy(v.v, const_sum, 32);
         if (H::geq(v, H::P)) FAIL(c, LIG_E_ARG, "lig_rows_prove: constant not reduced mod p");
@@ -701,6 +722,7 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     if (rands_on_device) rs.dev = (const fr*)rands; else rs.host = (const uint8_t*)rands;
     TRY(prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c)));
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
+    T->state = 2;
     return LIG_OK;
 }
 

@@ -78,11 +78,20 @@ def test_rows_entry_equals_oracle(amd, l, k, n, n_linear, n_quad, prog, pub, mod
         else:
             d_r = c.upload(rands) if R else c.malloc(32)
             proof, info = c.rows_prove(tr, d_r, const_sum, on_device=True)
-        c.trace_destroy(tr)
         assert info.rows == want["rows"]
         assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
         assert bytes(info.stage2_seed) == want["seed2"]
         assert proof == want["proof"]
+        # the next trace of the same shape reuses every buffer (lig_rows_restart); with const_sum = NULL the library reports
+        # the constant that fits the rows, which for an honest driver is the public one
+        if mode == "host_rows_library_pads":
+            c.rows_restart(tr, msgs, on_device=False)
+        else:
+            c.rows_restart(tr, d_msgs, on_device=True)
+        assert c.rows_commit(tr) == (root, seed1)
+        proof2, info2 = c.rows_prove(tr, rands if mode == "host_rows_library_pads" else d_r, None, on_device=mode != "host_rows_library_pads")
+        assert proof2 == proof and bytes(info2.const_sum) == want["const_sum"]
+        c.trace_destroy(tr)
         # both verifiers accept it, deriving the constant from the public statement themselves
         hjob = amd.Context.make_job(n_linear, n_quad, generated_at=77, public_args=pub)
         if prog:
