@@ -188,13 +188,12 @@ class RowsFromHostWorkload:
         ctx.check(ctx.L.lig_read(ctx.h, C.c_void_p(self.host.data_ptr()), d, R * K_ * 32))
         ctx.free(d)
         kinds = np.full(R, pkg.ROW_KINDS["LINEAR"] | pkg.ROW_DRAW_PAD, dtype=np.uint8)
-        self.traces, self.keep, self.rands = [], [], []
+        self.traces, self.keep = [], []
         for c in self.ctxs:
             t, keep = self._begin(c, kinds)
             self.traces.append(t)
             self.keep.append(keep)
-            self.rands.append(c.malloc(R * K_ * 32))
-        self.first = [True] * inflight
+        self.loaded = [True] * inflight          # lig_rows_begin started the first upload
         self.last = None
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=inflight)
@@ -211,24 +210,31 @@ class RowsFromHostWorkload:
         job.generated_at = 0
         job.version = b"1.5.0"
         job.set_public_args(None)
+        job.dense_rands_per_row = self.per_row.ctypes.data      # the synthetic stream's dense coefficient rows: sampled on the device
         t = C.c_void_p()
         c.check(c.L.lig_rows_begin(c.h, C.byref(job), C.byref(t)))
         return t, (kinds, job)
 
-    def _one(self, i):
+    def _loop(self, i, steps):
+        """commit(s) -> restart(s+1) -> prove(s): the upload of the next trace runs under the proof of the current one"""
         c, t = self.ctxs[i], self.traces[i]
-        if not self.first[i]:
-            c.check(c.L.lig_rows_restart(t, C.c_void_p(self.host.data_ptr()), 0))
-        self.first[i] = False
-        _, seed1 = c.rows_commit(t)
-        c.rng_fill_rows(seed1, 0, self.per_row, self.rands[i])
-        (addr, length), info = c.rows_prove(t, self.rands[i], None, on_device=True, copy=False)
-        if not (info.valid_code and info.valid_linear and info.valid_quad):
-            raise SystemExit("prover self-check failed")
-        return (addr, length)
+        host = C.c_void_p(self.host.data_ptr())
+        out = None
+        for s_ in range(steps):
+            if not self.loaded[i]:
+                c.check(c.L.lig_rows_restart(t, host, 0))
+            c.rows_commit(t)
+            self.loaded[i] = s_ + 1 < steps
+            if self.loaded[i]:
+                c.check(c.L.lig_rows_restart(t, host, 0))
+            (addr, length), info = c.rows_prove(t, None, None, copy=False)
+            if not (info.valid_code and info.valid_linear and info.valid_quad):
+                raise SystemExit("prover self-check failed")
+            out = (addr, length)
+        return out
 
     def run(self, steps):
-        self.last = list(self.pool.map(lambda i: [self._one(i) for _ in range(steps)][-1], range(self.inflight)))[0]
+        self.last = list(self.pool.map(lambda i: self._loop(i, steps), range(self.inflight)))[0]
 
     def proof_sha256(self):
         return hashlib.sha256(C.string_at(self.last[0], self.last[1])).hexdigest()

@@ -244,6 +244,10 @@ typedef struct {
     int64_t  generated_at;
     char     version[16];
     const uint8_t *public_args; const uint64_t *public_arg_lens; uint64_t n_public_args;    /* as in lig_synth_job */
+    /* optional (NULL: none): the linear-test randomness rows are the DENSE rows of the synthetic stream -- row r = this many
+     * successive elements of the stream keyed by stage1_seed, zeros up to k -- so lig_rows_prove(rands = NULL) may
+     * generate them on the device (sampled under the encodes, as lig_synth_prove does) instead of reading them */
+    const uint32_t *dense_rands_per_row;
 } lig_rows_job;
 int lig_rows_begin(lig_ctx *ctx, const lig_rows_job *job, lig_trace **out);
 int lig_rows_commit(lig_trace *trace, uint8_t root[32], uint8_t stage1_seed[32]);
@@ -252,7 +256,9 @@ int lig_rows_commit(lig_trace *trace, uint8_t root[32], uint8_t stage1_seed[32])
 int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, const uint8_t *const_sum,
                    const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
 /* the next trace of the same shape (same kinds, seeds, metadata) with new message rows, reusing every buffer of `trace`
- * (no allocation on the proving path of a service); same upload semantics as lig_rows_begin */
+ * (no allocation on the proving path of a service); same upload semantics as lig_rows_begin.  It may be called right
+ * after lig_rows_commit, BEFORE lig_rows_prove of the committed trace: the new rows then go to a second message matrix
+ * and arrive while the current trace is being proved (commit(i) -> restart(i+1) -> prove(i) -> commit(i+1) -> ...). */
 int lig_rows_restart(lig_trace *trace, const void *msgs, int msgs_on_device);
 /* rows x k dense randomness rows on the device: row r = per_row[r] successive elements of the AES-256-CTR field stream
  * keyed by key32 (row r starts where row r-1 ended, the first at first_elem), zeros up to k -- the linear-test

@@ -66,7 +66,8 @@ class RowsJob(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("kinds", C.c_void_p), ("msgs", C.c_void_p), ("msgs_on_device", C.c_int32),
                 ("reserved", C.c_int32), ("encoding_seed", C.c_uint8 * 32), ("program_hash", C.c_uint8 * 32),
                 ("generated_at", C.c_int64), ("version", C.c_char * 16),
-                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64)]
+                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64),
+                ("dense_rands_per_row", C.c_void_p)]
 
     def set_public_args(self, args):
         _attach_public_args(self, args)
@@ -394,7 +395,8 @@ class Context:
         return info
 
     # ---- the same prover over rows supplied by the caller (lig_rows_*)
-    def rows_begin(self, kinds, msgs, on_device=False, encoding_seed=None, generated_at=0, public_args=None, program_hash=None):
+    def rows_begin(self, kinds, msgs, on_device=False, encoding_seed=None, generated_at=0, public_args=None, program_hash=None,
+                   dense_rands_per_row=None):
         """kinds: uint8 array (ROW_KINDS | ROW_DRAW_PAD); msgs: device pointer (on_device) or a (rows, k, 8) uint32 host array.
         -> (trace, keepalive); keep `keepalive` referenced until rows_commit has returned"""
         kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
@@ -415,6 +417,10 @@ class Context:
         job.generated_at = generated_at
         job.version = b"1.5.0"
         job.set_public_args(public_args)
+        if dense_rands_per_row is not None:
+            dr = np.ascontiguousarray(dense_rands_per_row, dtype=np.uint32)
+            job.dense_rands_per_row = dr.ctypes.data if len(dr) else None
+            keep = keep + (dr,)
         t = C.c_void_p()
         self.check(self.L.lig_rows_begin(self.h, C.byref(job), C.byref(t)))
         return t, keep + (job,)
@@ -431,7 +437,9 @@ class Context:
     def rows_prove(self, trace, rands, const_sum, on_device=False, copy=True):
         proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
         cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy() if const_sum is not None else None
-        if on_device:
+        if rands is None:
+            rp = None
+        elif on_device:
             rp = rands
         else:
             rands = np.ascontiguousarray(rands, dtype=np.uint32)

@@ -21,6 +21,10 @@ struct lig_ctx {
     std::string err;
     lig::NttPlan plan[3];
     lig::EncodePlan ep;
+    // two-launch single-row transforms: [LIG_SIZE_K | LIG_SIZE_2K | LIG_SIZE_N][forward | inverse], the inverse on <w_n^2>
+    lig::TiledPlan tplan[3][2], tplan_half_inv;
+    bool tiled = false;
+    fr* tiled_scratch[2] = {nullptr, nullptr};   // 3 rows of n elements each: [0] main stream, [1] side stream
     bool fast = false;
     std::vector<void*> owned;                 // device tables freed at destroy
     fr* scratch_y = nullptr; fr* scratch_z = nullptr; size_t scratch_rows = 0;

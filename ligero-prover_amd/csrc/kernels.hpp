@@ -31,6 +31,17 @@ struct EncodePlan {
     f29s* kinv = nullptr;       // k^-1, 1 entry
 };
 
+// Tables of the two-launch single-row transforms (ntt_tiled.hip): N = A * B, Montgomery radix 2^261, 48-byte entries.
+struct TiledPlan {
+    uint32_t N = 0, log2N = 0, log2A = 0, log2B = 0;
+    f29s* tw_a = nullptr;       // DIT stage twiddles of the size-A transform (root w^B): span M' at M'/2-1
+    f29s* tw_b = nullptr;       // same for the size-B transform (root w^A)
+    f29s* mid = nullptr;        // [A][B]: w^(k1*n2), times N^-1 for an inverse transform
+};
+bool tiled_supported(uint32_t log2N);
+void ntt_tiled(hipStream_t s, const TiledPlan& tp, const fr* in, size_t in_stride, fr* out, size_t out_stride, size_t rows, fr* scratch,
+               uint32_t fold = 0);
+
 // ---- ntt_generic.hip
 void ntt_generic_forward(hipStream_t s, const NttPlan& pl, fr* buf, size_t rows, size_t row_stride);
 void ntt_generic_inverse(hipStream_t s, const NttPlan& pl, fr* buf, size_t rows, size_t row_stride);

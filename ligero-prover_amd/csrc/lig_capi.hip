@@ -148,6 +148,33 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
     return LIG_OK;
 }
 
+// ---- tables of the two-launch single-row transforms (ntt_tiled.hip)
+static int make_tiled_plan(lig_ctx* c, lig::TiledPlan& tp, uint32_t N, const H::Fr& root, bool inverse) {
+    const H::Fr w = inverse ? H::inv(root) : root;
+    tp.N = N; tp.log2N = ilog2u(N); tp.log2A = tp.log2N / 2; tp.log2B = tp.log2N - tp.log2A;
+    const uint32_t A = 1u << tp.log2A, B = 1u << tp.log2B;
+    auto stage_table = [&](const H::Fr& rho, uint32_t S) {      // span M at entry M/2-1: rho^(j*S/M), j < M/2
+        std::vector<H::Fr> pw = powers_plain(rho, S / 2);
+        std::vector<lig::f29s> t(S);
+        for (uint32_t M = 2; M <= S; M <<= 1)
+            for (uint32_t j = 0; j < M / 2; j++) t[(M / 2 - 1) + j] = to_f29s(pw[(size_t)j * (S / M)]);
+        t[S - 1] = to_f29s(H::from_u64(1));
+        return t;
+    };
+    int rc;
+    if ((rc = upload29(c, stage_table(H::pow_u64(w, B), A), &tp.tw_a)) != LIG_OK) return rc;
+    if ((rc = upload29(c, stage_table(H::pow_u64(w, A), B), &tp.tw_b)) != LIG_OK) return rc;
+    std::vector<lig::f29s> mid((size_t)N);
+    const H::Fr scale = inverse ? H::inv(H::from_u64(N)) : H::from_u64(1);
+    H::Fr base = H::from_u64(1);                                  // w^k1
+    for (uint32_t k1 = 0; k1 < A; k1++) {
+        H::Fr cur = scale;
+        for (uint32_t n2 = 0; n2 < B; n2++) { mid[(size_t)k1 * B + n2] = to_f29s(cur); cur = H::mul(cur, base); }
+        base = H::mul(base, w);
+    }
+    return upload29(c, mid, &tp.mid);
+}
+
 extern "C" {
 
 const char* lig_version(void) { return "lig_hip 0.1 (gfx950)"; }
@@ -174,6 +201,19 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->fast = lig::encode_fast_supported(k);
     if (c->fast && (rc = make_encode_plan(c, wk, w4k)) != LIG_OK) return rc;
+    c->tiled = lig::tiled_supported(ilog2u(k)) && lig::tiled_supported(ilog2u(n));
+    if (c->tiled) {
+        const H::Fr roots[3] = {wk, w2k, w4k};
+        const uint32_t sizes[3] = {k, 2 * k, n};
+        for (int w3 = 0; w3 < 3; w3++)
+            for (int inv = 0; inv < 2; inv++)
+                if ((rc = make_tiled_plan(c, c->tplan[w3][inv], sizes[w3], roots[w3], inv != 0)) != LIG_OK) return rc;
+        if ((rc = make_tiled_plan(c, c->tplan_half_inv, 2 * k, H::mul(w4k, w4k), true)) != LIG_OK) return rc;
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(c, hipMalloc((void**)&c->tiled_scratch[i], 3 * (size_t)n * sizeof(fr)));
+            c->owned.push_back(c->tiled_scratch[i]);
+        }
+    }
     HIP_TRY(c, hipMalloc((void**)&c->rk_dev, 60 * sizeof(uint32_t)));
     lig::aes_upload_tables();
     HIP_TRY(c, hipDeviceSynchronize());
@@ -320,8 +360,17 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
 }
 // values of a degree-<2k polynomial on <w_n^2> (buf[0..2k), rest of the n-buffer zero) -> its values on all n points
 // encode_2k of `rows` consecutive n-element buffers in one pass of the radix-2 kernels (the two degree-<2k mask rows)
+// scratch of the tiled transforms: one per context stream that runs them
+static fr* tiled_scratch_for(lig_ctx* c, hipStream_t st) { return c->tiled_scratch[st == c->stream2 ? 1 : 0]; }
+
 int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t on) {
     hipStream_t st = on ? on : c->stream;
+    if (c->tiled && rows <= 3) {
+        lig::ntt_tiled(st, c->tplan[LIG_SIZE_2K][1], (fr*)buf, c->n, (fr*)buf, c->n, rows, tiled_scratch_for(c, st));
+        lig::ntt_tiled(st, c->tplan[LIG_SIZE_N][0], (fr*)buf, c->n, (fr*)buf, c->n, rows, tiled_scratch_for(c, st));
+        HIP_TRY(c, hipGetLastError());
+        return LIG_OK;
+    }
     lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_2K], (fr*)buf, rows, c->n);
     lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)buf, rows, c->n);
     HIP_TRY(c, hipGetLastError());
@@ -330,12 +379,24 @@ int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t 
 // encode of one n-element buffer with the radix-2 kernels only (no shared scratch: safe next to a batched encode on another stream)
 int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on) {
     hipStream_t st = on ? on : c->stream;
+    if (c->tiled) {
+        lig::ntt_tiled(st, c->tplan[LIG_SIZE_K][1], (fr*)buf, c->n, (fr*)buf, c->n, 1, tiled_scratch_for(c, st));
+        lig::ntt_tiled(st, c->tplan[LIG_SIZE_N][0], (fr*)buf, c->n, (fr*)buf, c->n, 1, tiled_scratch_for(c, st));
+        HIP_TRY(c, hipGetLastError());
+        return LIG_OK;
+    }
     lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
     lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
 int lig_internal_extend_2k(lig_ctx* c, void* buf) {
+    if (c->tiled) {
+        lig::ntt_tiled(c->stream, c->tplan_half_inv, (fr*)buf, c->n, (fr*)buf, c->n, 1, c->tiled_scratch[0]);
+        lig::ntt_tiled(c->stream, c->tplan[LIG_SIZE_N][0], (fr*)buf, c->n, (fr*)buf, c->n, 1, c->tiled_scratch[0]);
+        HIP_TRY(c, hipGetLastError());
+        return LIG_OK;
+    }
     lig::ntt_generic_inverse(c->stream, c->plan_half, (fr*)buf, 1, c->n);
     lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
     HIP_TRY(c, hipGetLastError());
@@ -362,24 +423,26 @@ int lig_encode(lig_ctx* c, void* buf) {
         fr* mcopy = c->scratch_z + 3 * (size_t)c->k;
         HIP_TRY(c, hipMemcpyAsync(mcopy, buf, (size_t)c->k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream));
         lig::encode_rows_fast(c->stream, c->ep, mcopy, (fr*)buf, c->scratch_y, c->scratch_z, 1, nullptr, nullptr);
-    } else {
-        lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
-        lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
-    }
+    } else return lig_internal_encode_generic(c, buf, nullptr);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
 int lig_encode_2k(lig_ctx* c, void* buf) {
     CHECK_CTX(c);
     if (!buf) return LIG_E_ARG;
-    lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_2K], (fr*)buf, 1, c->n);
-    lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
-    HIP_TRY(c, hipGetLastError());
-    return LIG_OK;
+    return lig_internal_encode_2k_rows(c, buf, 1, nullptr);
 }
 int lig_decode(lig_ctx* c, void* buf) {
     CHECK_CTX(c);
     if (!buf) return LIG_E_ARG;
+    if (c->tiled) {
+        // INTT_n; coefficients k..2k-1 folded onto 0..k-1 while the size-k forward transform loads them (N of the fold taken
+        // from the 2k config: half = k, engine.cpp:782-786); buf[k..n) keeps the raw coefficients
+        lig::ntt_tiled(c->stream, c->tplan[LIG_SIZE_N][1], (fr*)buf, c->n, (fr*)buf, c->n, 1, c->tiled_scratch[0]);
+        lig::ntt_tiled(c->stream, c->tplan[LIG_SIZE_K][0], (fr*)buf, c->n, (fr*)buf, c->n, 1, c->tiled_scratch[0], c->k);
+        HIP_TRY(c, hipGetLastError());
+        return LIG_OK;
+    }
     lig::ntt_generic_inverse(c->stream, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
     lig::ntt_generic_fold(c->stream, (fr*)buf, c->k, 1, c->n);      // N taken from the 2k config: half = k (engine.cpp:782-786)
     lig::ntt_generic_forward(c->stream, c->plan[LIG_SIZE_K], (fr*)buf, 1, c->n);
@@ -389,6 +452,11 @@ int lig_decode(lig_ctx* c, void* buf) {
 int lig_ntt(lig_ctx* c, void* buf, int which, int inverse) {
     CHECK_CTX(c);
     if (!buf || which < 0 || which > 2) return LIG_E_ARG;
+    if (c->tiled) {
+        lig::ntt_tiled(c->stream, c->tplan[which][inverse ? 1 : 0], (fr*)buf, c->n, (fr*)buf, c->n, 1, c->tiled_scratch[0]);
+        HIP_TRY(c, hipGetLastError());
+        return LIG_OK;
+    }
     if (inverse) lig::ntt_generic_inverse(c->stream, c->plan[which], (fr*)buf, 1, c->n);
     else lig::ntt_generic_forward(c->stream, c->plan[which], (fr*)buf, 1, c->n);
     HIP_TRY(c, hipGetLastError());

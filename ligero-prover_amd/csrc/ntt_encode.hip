@@ -31,42 +31,10 @@
 //   whose limbs dominate the subtrahend's limbs and whose value dominates its value.
 #include "fr29.hpp"
 #include "kernels.hpp"
+#include "tile_dft.hpp"
 #include <cstdlib>
 
 namespace lig {
-
-__device__ __forceinline__ constexpr int brev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
-
-// Radix-8 DIT butterfly in registers.  In: a[p] = input number brev3(p), normalised limbs, value < 3p.
-// Out: a[j] = sum_i in[i] * w^(i*j), lazy (limbs < 2^31 + 8, value < 28p).  w1,w2,w3 = w, w^2, w^3 (Montgomery form).
-__device__ __forceinline__ void radix8_dit(f29 (&a)[8], const f29& w1, const f29& w2, const f29& w3) {
-    f29 t, u;
-    // span 2, twiddle 1.  u: limbs < 2^30, < 6p.  v = x - y + 4p: limbs < 2^31, < 7p.
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-        u = f29_add(a[i], a[i + 1]);
-        a[i + 1] = f29_sub_k4(a[i], a[i + 1]);
-        a[i] = u;
-    }
-    // span 4.  pairs (0,2),(4,6): twiddle 1, subtrahend limbs < 2^30, < 6p -> + 8p.  pairs (1,3),(5,7): twiddle w^2.
-#pragma unroll
-    for (int b = 0; b < 8; b += 4) {
-        u = f29_add(a[b], a[b + 2]);               // limbs < 2^31, < 12p
-        a[b + 2] = f29_sub_k8(a[b], a[b + 2]);     // limbs < 3.5 * 2^30, < 14p
-        a[b] = u;
-        t = f29_montmul(a[b + 3], w2);             // input limbs < 2^31
-        u = f29_add(a[b + 1], t);                  // limbs < 2.5 * 2^30, < 8.2p
-        a[b + 3] = f29_sub_k2(a[b + 1], t);        // limbs < 3 * 2^30, < 9p
-        a[b + 1] = u;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = f29_qnorm(a[i]);
-    // span 8.  pair (0,4): twiddle 1, subtrahend limbs < 2^29+8, < 12p -> + 16p.  others: w, w^2, w^3.
-    u = f29_add(a[0], a[4]); a[4] = f29_sub_k16(a[0], a[4]); a[0] = u;                 // < 24p | limbs < 2^31+8, < 28p
-    t = f29_montmul(a[5], w1); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
-    t = f29_montmul(a[6], w2); u = f29_add(a[2], t); a[6] = f29_sub_k2(a[2], t); a[2] = u;
-    t = f29_montmul(a[7], w3); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
-}
 
 // ---------------------------------------------------------------------------------------------------- K1
 template <int LOG2B>
@@ -88,104 +56,6 @@ __global__ void __launch_bounds__(256, 2) k_encode_in(const fr* __restrict__ msg
 #define LIG_SEAM(J1) fr_store(y + (size_t)(J1) * B + i2, pack29(f29_montmul(a[J1], f29_load_tab(seam_inv + (size_t)(J1) * B + i2))))
     LIG_SEAM(1); LIG_SEAM(2); LIG_SEAM(3); LIG_SEAM(4); LIG_SEAM(5); LIG_SEAM(6); LIG_SEAM(7);
 #undef LIG_SEAM
-}
-
-// ---------------------------------------------------------------------------------------------------- tile transform
-// LDS exchange buffer: element `pos` of the tile = limbs 0-3 | limbs 4-7 | limb 8 in three planes.
-template <int LOG2B>
-struct TileLds {
-    static constexpr uint32_t B = 1u << LOG2B;
-    uint4 lo[B];
-    uint4 hi[B];
-    uint32_t top[B];
-};
-template <int LOG2B>
-__device__ __forceinline__ void lds_put(TileLds<LOG2B>& L, uint32_t pos, const f29& x) {
-    L.lo[pos] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    L.hi[pos] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-    L.top[pos] = x.v[8];
-}
-template <int LOG2B>
-__device__ __forceinline__ f29 lds_get(const TileLds<LOG2B>& L, uint32_t pos) {
-    const uint4 a = L.lo[pos], b = L.hi[pos];
-    f29 r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    r.v[8] = L.top[pos];
-    return r;
-}
-
-// Synchronisation between a step's LDS writes and the next step's reads.  The next step reads inside blocks of SPAN
-// elements; a wave owns 256 consecutive elements (64 lanes x 4), so for SPAN <= 256 -- or a workgroup that is a single
-// wave -- the exchange never leaves the wave: LDS instructions of one wave execute in order, only the compiler has to be
-// kept from reordering them.  (A step re-writes exactly the positions it read, so nothing is needed between its own reads
-// and writes.)  For B = 1024 this leaves ONE s_barrier per tile transform instead of eight.
-template <uint32_t SPAN, uint32_t THREADS>
-__device__ __forceinline__ void tile_sync() {
-    if constexpr (SPAN <= 256 || THREADS <= 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    else __syncthreads();
-}
-
-// One radix-2^2 DIT step (spans M/2 and M, M = 4^(S+1)) of the size-B transform.  Thread t owns positions
-// base + q*Q (Q = M/4).  tw: the stage of span M' starts at entry M'/2 - 1 (M'/2 entries rho^(j*B/M')).
-template <int LOG2B, int S>
-__device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
-    constexpr int STEPS = LOG2B / 2;
-    constexpr uint32_t M = 4u << (2 * S), Q = M >> 2;
-    const uint32_t p = t & (Q - 1);
-    const uint32_t base = (t / Q) * M + p;
-    if constexpr (S > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = lds_get(L, base + q * Q);
-    }
-    f29 t1, t3, u;
-    if constexpr (S == 0) {
-        // spans 2 and 4: twiddles 1 | 1, W_4^1.  inputs normalised, < 3p.
-        u = f29_add(x[0], x[1]); x[1] = f29_sub_k4(x[0], x[1]); x[0] = u;         // u: limbs < 2^30, < 6p; v: limbs < 2^31, < 7p
-        u = f29_add(x[2], x[3]); x[3] = f29_sub_k4(x[2], x[3]); x[2] = u;
-        t3 = f29_montmul(x[3], f29_load_tab(tw + 2));                               // W_4^1
-        u = f29_add(x[0], x[2]); x[2] = f29_sub_k8(x[0], x[2]); x[0] = u;           // < 12p | limbs < 3.5*2^30, < 14p
-        u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 3*2^30, < 9p
-    } else {
-        // operands at rest: limbs < 2^29 + 8.  every output gains at most 4p.
-        const f29 wa = f29_load_tab(tw + (Q - 1) + p);                               // W_{M/2}^p
-        t1 = f29_montmul(x[1], wa);
-        t3 = f29_montmul(x[3], wa);
-        u = f29_add(x[0], t1); x[1] = f29_sub_k2(x[0], t1); x[0] = u;               // limbs < 2^30+8 | < 1.5*2^30+8
-        u = f29_add(x[2], t3); x[3] = f29_sub_k2(x[2], t3); x[2] = u;
-        t1 = f29_montmul(x[2], f29_load_tab(tw + (2 * Q - 1) + p));                 // W_M^p
-        t3 = f29_montmul(x[3], f29_load_tab(tw + (2 * Q - 1) + p + Q));             // W_M^(p+Q)
-        u = f29_add(x[0], t1); x[2] = f29_sub_k2(x[0], t1); x[0] = u;               // limbs < 2^31 + 8
-        u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 2.5*2^30 + 8
-    }
-    if constexpr (S + 1 < STEPS) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
-        tile_sync<4 * M, (1u << LOG2B) / 4>();
-        tile_step<LOG2B, S + 1>(x, tw, L, t);
-    } else if constexpr (LOG2B & 1) {
-        // B = 2 * 4^STEPS: the radix-4 steps have built the two half-size transforms; one radix-2 stage of span B joins
-        // them.  Thread t owns positions t + q*B/4 from here on (the exit ownership), i.e. the pairs (t, t + B/2) and
-        // (t + B/4, t + 3B/4) with twiddles W_B^t and W_B^(t + B/4).
-        constexpr uint32_t B = 1u << LOG2B, T = B / 4;
-#pragma unroll
-        for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
-        tile_sync<B, T>();
-#pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = lds_get(L, t + q * T);
-        const f29 ta = f29_montmul(x[2], f29_load_tab(tw + (B / 2 - 1) + t));
-        const f29 tb = f29_montmul(x[3], f29_load_tab(tw + (B / 2 - 1) + t + T));
-        u = f29_add(x[0], ta); x[2] = f29_sub_k2(x[0], ta); x[0] = u;               // at-rest operands: + at most 2p
-        u = f29_add(x[1], tb); x[3] = f29_sub_k2(x[1], tb); x[1] = u;
-    }
-}
-// Size-B DIT transform.  Entry: x[q] = input number brev(4t + q) (bit-reversed load), normalised, < 3p.
-// Exit: x[q] = output number t + q*B/4 (natural order, the coalesced ownership pattern), lazy:
-// limbs < 2.5*2^30 + 8, value < 14p + 4p*(STEPS-1) + 2p <= 30p.
-template <int LOG2B>
-__device__ __forceinline__ void tile_dft(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
-    static_assert(LOG2B >= 4 && LOG2B <= 10, "tile length 16 .. 1024 (36 bytes of LDS per element, static LDS <= 64 KiB)");
-    tile_step<LOG2B, 0>(x, tw, L, t);
 }
 
 // ---------------------------------------------------------------------------------------------------- K2a

@@ -20,8 +20,11 @@
 struct lig_trace {
     lig_ctx* c = nullptr;
     lig_synth_job job;                  // synthetic jobs only (n_linear / n_quad / witness_key); pointers cleared
-    bool from_rows = false;             // rows supplied by the caller (lig_rows_*): no witness / randomness generation here
-    int state = 0;                      // lig_rows_*: 0 = begun, 1 = committed (stage 1 done)
+    bool from_rows = false;             // rows supplied by the caller (lig_rows_*): no witness generation here
+    bool loaded = false, committed = false;   // lig_rows_*: rows for the next commit are loaded / stage 1 done, proof pending
+    bool dense_rands = false;           // lig_rows_job.dense_rands_per_row given: randomness rows may be generated here
+    fr* msgs_alt = nullptr;             // second message matrix: the next trace is uploaded while the current one is proved
+    bool alt_pending = false;           // the rows for the next commit are (arriving) in msgs_alt
     uint8_t encoding_seed[32] = {0}, program_hash[32] = {0}, ih[32] = {0};
     int64_t generated_at = 0;
     char version[17] = {0};
@@ -565,7 +568,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream2);
     (void)hipStreamSynchronize(T->c->stream3);
     T->c->sha.erase(T->sha_state);
-    for (void* p : {(void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
+    for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);
@@ -600,9 +603,19 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
     const uint32_t k = c->k;
     const size_t R = T->R;
     T->host_msgs = nullptr;
+    T->loaded = true;
+    T->alt_pending = false;
     if (!R) return LIG_OK;
+    fr* dst = T->msgs;
+    if (T->committed) {
+        // the committed trace still needs its rows for stage 2: the next trace goes to the second matrix and is swapped in
+        // by lig_rows_commit -- its upload runs under lig_rows_prove of the current one
+        if (!T->msgs_alt) HIP_TRY(c, hipMalloc((void**)&T->msgs_alt, R * (size_t)k * 32));
+        dst = T->msgs_alt;
+        T->alt_pending = true;
+    }
     if (on_device) {
-        HIP_TRY(c, hipMemcpyAsync(T->msgs, msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dst, msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
         return LIG_OK;
     }
     T->host_msgs = (const uint8_t*)msgs;
@@ -610,12 +623,10 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         T->ev_up.resize(T->sched1.size(), nullptr);
         for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // the previous proof of this trace may still be reading T->msgs on the main stream (stage 2): order the upload behind it
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+    // (every earlier reader of `dst` has finished: lig_rows_prove returns only after its stream work is done)
     for (size_t ci = 0; ci < T->sched1.size(); ci++) {
         const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
-        HIP_TRY(c, hipMemcpyAsync(T->msgs + b * (size_t)k, T->host_msgs + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, c->stream3));
+        HIP_TRY(c, hipMemcpyAsync(dst + b * (size_t)k, T->host_msgs + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, c->stream3));
         HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
     }
     return LIG_OK;
@@ -652,8 +663,11 @@ static int rows_begin_impl(lig_ctx* c, const lig_rows_job* job, lig_trace* T) {
         if ((job->kinds[r] & LIG_ROW_DRAW_PAD) && !draws) FAIL(c, LIG_E_ARG, "rows job: LIG_ROW_DRAW_PAD on a row kind that draws no padding upstream");
         draw[r] = (job->kinds[r] & LIG_ROW_DRAW_PAD) ? 1 : 0;
         pos[r + 1] = pos[r] + (draws ? pad : 0);
-        T->rows[r] = RowDesc{kd, 0};
+        const uint32_t dense = job->dense_rands_per_row ? job->dense_rands_per_row[r] : 0;
+        if (dense > k || (dense && kd > 3)) FAIL(c, LIG_E_ARG, "rows job: dense_rands_per_row out of range or on a batch row");
+        T->rows[r] = RowDesc{kd, dense};
     }
+    T->dense_rands = job->dense_rands_per_row != nullptr;
     T->mask_pos = pos[R];
     TRY(trace_alloc(c, T));
     // pad runs: consecutive flagged rows whose stream positions are consecutive, never straddling a stage-1 chunk
@@ -685,20 +699,23 @@ int lig_rows_restart(lig_trace* T, const void* msgs, int msgs_on_device) {
     CHECK_CTX(c);
     if (!T->from_rows) FAIL(c, LIG_E_STATE, "lig_rows_restart: not a rows trace");
     if (T->R && !msgs) FAIL(c, LIG_E_ARG, "lig_rows_restart: null rows");
-    T->state = 0;
+    if (T->loaded && T->host_msgs) HIP_TRY(c, hipStreamSynchronize(c->stream3));      // an upload nobody committed: let it finish first
     return rows_load(c, T, msgs, msgs_on_device != 0);
 }
 int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
     if (!T) return LIG_E_ARG;
     lig_ctx* c = T->c;
     CHECK_CTX(c);
-    if (!T->from_rows || T->state != 0) FAIL(c, LIG_E_STATE, "lig_rows_commit: trace is not a freshly begun rows job");
+    if (!T->from_rows || !T->loaded) FAIL(c, LIG_E_STATE, "lig_rows_commit: no rows loaded (lig_rows_begin / lig_rows_restart)");
+    if (T->committed) FAIL(c, LIG_E_STATE, "lig_rows_commit: the committed trace has not been proved yet");
+    if (T->alt_pending) { std::swap(T->msgs, T->msgs_alt); T->alt_pending = false; }
     std::memset(&T->info1, 0, sizeof T->info1);
     T->info1.rows = T->R + 3;
     const auto t_begin = clk::now();
     TRY(prove_stage1(T, &T->info1, make_mark(c)));
     T->info1.ms_stage1 = ms_since(t_begin);
-    T->state = 1;
+    T->committed = true;
+    T->loaded = false;
     T->host_msgs = nullptr;                               // the caller's memory is no longer referenced
     if (root) std::memcpy(root, T->info1.root, 32);
     if (stage1_seed) std::memcpy(stage1_seed, T->info1.stage1_seed, 32);
@@ -709,8 +726,8 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     if (!T || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = T->c;
     CHECK_CTX(c);
-    if (!T->from_rows || T->state != 1) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_commit has not run on this trace");
-    if (T->R && !rands) FAIL(c, LIG_E_ARG, "lig_rows_prove: null randomness rows");
+    if (!T->from_rows || !T->committed) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_commit has not run on this trace");
+    if (T->R && !rands && !T->dense_rands) FAIL(c, LIG_E_ARG, "lig_rows_prove: null randomness rows");
     if (const_sum) {
         H::Fr v;
         std::memcpy(v.v, const_sum, 32);
@@ -718,11 +735,11 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     }
     *info = T->info1;
     const auto t_begin = clk::now();
-    RandSource rs;
-    if (rands_on_device) rs.dev = (const fr*)rands; else rs.host = (const uint8_t*)rands;
+    RandSource rs;                                        // default: generated from the dense counts of the job
+    if (rands && rands_on_device) rs.dev = (const fr*)rands; else if (rands) rs.host = (const uint8_t*)rands;
     TRY(prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c)));
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
-    T->state = 2;
+    T->committed = false;
     return LIG_OK;
 }
 

@@ -103,6 +103,35 @@ def test_rows_entry_equals_oracle(amd, l, k, n, n_linear, n_quad, prog, pub, mod
         c.close()
 
 
+def test_rows_entry_pipelined_restart_and_dense_rands(amd):
+    """commit(i) -> restart(i+1) -> prove(i): the next trace is uploaded into the second message matrix while the current
+    one is proved; the dense randomness rows of the synthetic stream are generated on the device (dense_rands_per_row).
+    Two different traces alternate; every envelope equals the oracle's for its trace."""
+    l, k, n = 320, 512, 2048
+    nl = 320 * 700 + 11                                        # 701 rows: two stage-1 chunks
+    jobs = [ol.make_job(l, k, n, 192, nl, 0, synth_seed=s, generated_at=3, threads=8) for s in (1, 2)]
+    want = [oracle_prove(j) for j in jobs]
+    rows = [ol.form_rows(j)[0].copy() for j in jobs]
+    kinds = ol.row_kinds(jobs[0]) | amd.ROW_DRAW_PAD
+    per_row = np.full(len(kinds), l, dtype=np.uint32)
+    per_row[-1] = nl % l
+    c = amd.Context(l, k, n)
+    try:
+        tr, keep = c.rows_begin(kinds, rows[0], generated_at=3, dense_rands_per_row=per_row)
+        for i in range(5):
+            root, seed1 = c.rows_commit(tr)
+            assert root == want[i % 2]["root"]
+            if i < 4:
+                c.rows_restart(tr, rows[(i + 1) % 2])          # prefetch under the proof of trace i
+            proof, info = c.rows_prove(tr, None, None)
+            assert proof == want[i % 2]["proof"] and bytes(info.const_sum) == want[i % 2]["const_sum"]
+        with pytest.raises(amd.LigError):                      # nothing loaded any more
+            c.rows_commit(tr)
+        c.trace_destroy(tr)
+    finally:
+        c.close()
+
+
 def test_rows_entry_rejects_malformed_jobs(amd):
     l, k, n = 320, 512, 2048
     c = amd.Context(l, k, n)
@@ -119,6 +148,8 @@ def test_rows_entry_rejects_malformed_jobs(amd):
             c.rows_prove(tr, msgs[:1], b"\xff" * 32)
         with pytest.raises(amd.LigError):                      # commit twice
             c.rows_commit(tr)
+        with pytest.raises(amd.LigError):                      # no randomness rows and no dense counts
+            c.rows_prove(tr, None, bytes(32))
         # a wrong public constant is not an error: the prover's self-check reports it
         proof, info = c.rows_prove(tr, msgs[:1], (5).to_bytes(32, "little"))
         assert info.valid_linear == 0 and info.valid_code == 1
