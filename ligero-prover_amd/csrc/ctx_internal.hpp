@@ -31,6 +31,10 @@ struct lig_ctx {
     std::unordered_map<void*, std::pair<size_t, uint64_t>> sha;   // state ptr -> (n_inst, rows absorbed)
     uint32_t* sample_idx = nullptr; size_t sample_count = 0, sample_cap = 0;
     uint32_t* rk_dev = nullptr;               // 60 AES round-key words
+    // small host -> device transfers on the proving path (round keys, coefficients, sample indices) go through a pinned
+    // staging ring read by a copy KERNEL: a hipMemcpy H2D would queue behind the multi-hundred-MB row uploads of
+    // lig_rows_* on the DMA engine and stall the proof for their whole duration (measured: stage 2 5.6 -> 15.4 ms)
+    uint8_t* stage_host = nullptr; uint8_t* stage_dev = nullptr; size_t stage_cap = 0, stage_pos = 0;
     fr* small_dev = nullptr;                  // staging for per-call scalars (rc/rq/tables)
     size_t small_cap = 0;
     uint32_t* tri_dev = nullptr; size_t tri_cap = 0;
@@ -43,8 +47,12 @@ struct lig_ctx {
 
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on = nullptr);
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
+// decode_ntt_device of `src` (n elements, left intact) into `dst` (n elements, != src), on the context stream
+int lig_internal_decode_to(lig_ctx* c, const void* src, void* dst);
 int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t on = nullptr);
 int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on = nullptr);
+// dst (device) <- src (host, any memory), `bytes` a multiple of 4, enqueued on `st`; src may be reused as soon as this returns
+int lig_internal_upload_small(lig_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);
 // make the shared encode scratch large enough for `rows` rows per launch group (all context streams are drained first)
 int lig_internal_reserve_scratch(lig_ctx* c, size_t rows);
 

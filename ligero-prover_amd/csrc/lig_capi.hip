@@ -148,6 +148,35 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
     return LIG_OK;
 }
 
+// ---- small uploads without the DMA engine (ctx_internal.hpp)
+__global__ void k_copy_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int lig_internal_upload_small(lig_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return LIG_OK;
+    if (bytes & 3) FAIL(c, LIG_E_ARG, "upload_small: size not a multiple of 4");
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > c->stage_cap) {               // larger than the ring (or no ring): plain copy
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        return LIG_OK;
+    }
+    if (c->stage_pos + need > c->stage_cap) {
+        // wrap: everything that still reads the ring must have finished (proofs are synchronous per context, so this is
+        // a formality -- once per ~40 proofs)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
+        c->stage_pos = 0;
+    }
+    std::memcpy(c->stage_host + c->stage_pos, src, bytes);
+    const size_t words = bytes / 4;
+    const uint32_t blocks = (uint32_t)((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
+    hipLaunchKernelGGL(k_copy_u32, dim3(blocks ? blocks : 1), dim3(256), 0, st, (uint32_t*)dst, (const uint32_t*)(c->stage_dev + c->stage_pos), words);
+    c->stage_pos += need;
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
 // ---- tables of the two-launch single-row transforms (ntt_tiled.hip)
 static int make_tiled_plan(lig_ctx* c, lig::TiledPlan& tp, uint32_t N, const H::Fr& root, bool inverse) {
     const H::Fr w = inverse ? H::inv(root) : root;
@@ -215,6 +244,9 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
         }
     }
     HIP_TRY(c, hipMalloc((void**)&c->rk_dev, 60 * sizeof(uint32_t)));
+    c->stage_cap = (size_t)16 << 20;
+    HIP_TRY(c, hipHostMalloc((void**)&c->stage_host, c->stage_cap, hipHostMallocDefault));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->stage_dev, c->stage_host, 0));
     lig::aes_upload_tables();
     HIP_TRY(c, hipDeviceSynchronize());
     return LIG_OK;
@@ -227,6 +259,7 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (void* p : c->owned) (void)hipFree(p);
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z); (void)hipFree(c->sample_idx);
     (void)hipFree(c->rk_dev); (void)hipFree(c->small_dev); (void)hipFree(c->tri_dev);
+    if (c->stage_host) (void)hipHostFree(c->stage_host);
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -389,6 +422,16 @@ int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on) {
     lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)buf, 1, c->n);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
+}
+int lig_internal_decode_to(lig_ctx* c, const void* src, void* dst) {
+    if (c->tiled) {
+        lig::ntt_tiled(c->stream, c->tplan[LIG_SIZE_N][1], (const fr*)src, c->n, (fr*)dst, c->n, 1, c->tiled_scratch[0]);
+        lig::ntt_tiled(c->stream, c->tplan[LIG_SIZE_K][0], (fr*)dst, c->n, (fr*)dst, c->n, 1, c->tiled_scratch[0], c->k);
+        HIP_TRY(c, hipGetLastError());
+        return LIG_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)c->n * sizeof(fr), hipMemcpyDeviceToDevice, c->stream));
+    return lig_decode(c, dst);
 }
 int lig_internal_extend_2k(lig_ctx* c, void* buf) {
     if (c->tiled) {
@@ -570,8 +613,8 @@ int lig_sample_init(lig_ctx* c, const uint32_t* host_idx, size_t count) {
         HIP_TRY(c, hipMalloc((void**)&c->sample_idx, count * sizeof(uint32_t)));
         c->sample_cap = count;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->sample_idx, host_idx, count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));        // host_idx may be a temporary
+    int rc_up = lig_internal_upload_small(c, c->sample_idx, host_idx, count * sizeof(uint32_t), c->stream);
+    if (rc_up != LIG_OK) return rc_up;
     c->sample_count = count;
     return LIG_OK;
 }
@@ -653,8 +696,7 @@ int lig_rng_fill(lig_ctx* c, const uint8_t* key32, uint64_t first_elem, void* ou
     if (!key32 || (!out && count)) return LIG_E_ARG;
     uint32_t rk[60];
     lig::aes256_expand_host(key32, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_up = lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, c->stream); if (rc_up != LIG_OK) return rc_up; }
     lig::launch_rng_fill(c->stream, c->rk_dev, first_elem, (fr*)out, count);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
@@ -665,8 +707,7 @@ int lig_rng_fill_rows(lig_ctx* c, const uint8_t* key32, uint64_t first_elem, con
     for (size_t r = 0; r < rows; r++) if (per_row_host[r] > c->k) FAIL(c, LIG_E_ARG, "rng_fill_rows: more elements than a row holds");
     uint32_t rk[60];
     lig::aes256_expand_host(key32, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc_up = lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, c->stream); if (rc_up != LIG_OK) return rc_up; }
     uint64_t pos = first_elem;
     for (size_t r = 0; r < rows;) {           // runs of rows with equal fill are one launch
         size_t run = 1;

@@ -32,6 +32,7 @@ void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ue
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
 void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
+void launch_copy_from_host(hipStream_t s, uint8_t* dst_dev, const uint8_t* src_mapped, size_t bytes);
 }  // namespace lig
 
 // (outside the anonymous namespace: these types appear in functions shared between translation units)

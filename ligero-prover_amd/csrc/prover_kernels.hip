@@ -158,4 +158,23 @@ void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* acc
     hipLaunchKernelGGL(k_lin_interleave, dim3((2 * k + 255) / 256), dim3(256), 0, s, out, accH, accC, k);
 }
 
+// ---------------------------------------------------------------------------------------------- row upload
+// dst (HBM) <- src (pinned host memory mapped into the device address space), 16-byte aligned, bytes % 16 == 0.
+// 64 workgroups keep ~1 MiB of reads in flight, enough to cover the PCIe round trip; the kernel sits on 64 of the 256 CUs
+// with one wave slot each and is issue-idle almost all the time.
+__global__ void __launch_bounds__(256) k_copy_from_host(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {      // four independent loads per thread in flight
+        const uint4 a = src[i], b = src[i + stride];
+        const uint4 c2 = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c2; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+void launch_copy_from_host(hipStream_t s, uint8_t* dst_dev, const uint8_t* src_mapped, size_t bytes) {
+    if (!bytes) return;
+    hipLaunchKernelGGL(k_copy_from_host, dim3(64), dim3(256), 0, s, (uint4*)dst_dev, (const uint4*)src_mapped, bytes / 16);
+}
+
 }  // namespace lig
