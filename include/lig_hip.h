@@ -274,12 +274,18 @@ int    lig_proof_gzip(const uint8_t *envelope, size_t len, uint8_t *out, size_t 
 size_t lig_proof_gunzip_size(const uint8_t *gz, size_t len);           /* ISIZE trailer; 0 if not a gzip member */
 int    lig_proof_gunzip(const uint8_t *gz, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 
-/* ==== one trace sharded over the GPUs of a node (configs[3]).  Rows are dealt to ranks in contiguous
- * blocks; the column hash is column-partitioned after ONE all-to-all of codeword column slices; leaves, partial
- * stage-2 sums (k + 2k + 2k values per rank, added mod p locally) and opened columns are all-gathered.  The collectives
- * are callbacks on device pointers supplied by the caller (torch.distributed over RCCL in
- * ligero-prover_amd/dist.py); they must return 0 once the data is in place.  Every rank obtains the same envelope,
- * byte-identical to lig_synth_prove of the same job. ==== */
+/* ==== one trace sharded over the GPUs of a node (configs[3]).  Rows are dealt to ranks block-cyclically
+ * (global chunk g of <= 512 rows belongs to rank g mod world, chunks never split an x,y,z triple), so that after exchange
+ * round c every rank holds the W consecutive global chunks cW .. cW+W-1 restricted to ITS columns: the column hash is
+ * column-partitioned (rank h owns columns [h n/W, (h+1) n/W)) and absorbs the rows in global order while the next round
+ * is still being encoded and exchanged.  One all-to-all of codeword column slices per round; leaves, partial stage-2 sums
+ * (k + 2k + 2k values per rank, added mod p locally: RCCL has no modular reduction) and opened columns are all-gathered.
+ * Every rank obtains the same envelope, byte-identical to lig_synth_prove of the same job.
+ *
+ * Collectives: lig_rccl_comm_create gives the RCCL communicator of the product (librccl over xGMI: grouped
+ * ncclSend/ncclRecv and ncclAllGather enqueued on HIP streams of the context, nothing blocks the host).  The plain
+ * callbacks exist so that tests can run the same sharded logic over gloo on CPU-staged buffers: they are called after
+ * the context stream has been drained and must return 0 once the data is in place. ==== */
 typedef struct lig_shard lig_shard;
 typedef struct {
     void *user;
@@ -287,7 +293,17 @@ typedef struct {
     int (*all_to_all)(void *user, const void *send_dev, void *recv_dev, size_t block_bytes);
     /* `recv` = world blocks of `bytes` in rank order */
     int (*all_gather)(void *user, const void *send_dev, void *recv_dev, size_t bytes);
+    /* optional stream-ordered forms (NULL: not available): the collective is enqueued on `hip_stream`; the data is in
+     * place for work enqueued on that stream afterwards */
+    int (*all_to_all_on)(void *user, const void *send_dev, void *recv_dev, size_t block_bytes, void *hip_stream);
+    int (*all_gather_on)(void *user, const void *send_dev, void *recv_dev, size_t bytes, void *hip_stream);
 } lig_comm;
+/* RCCL communicator: rank 0 calls lig_rccl_unique_id and hands the 128 bytes to every rank through the launcher's
+ * rendezvous (torch.distributed / MPI / a file); every rank then calls lig_rccl_comm_create with its context. */
+enum { LIG_RCCL_ID_BYTES = 128 };
+int  lig_rccl_unique_id(uint8_t out[LIG_RCCL_ID_BYTES]);
+int  lig_rccl_comm_create(lig_ctx *ctx, const uint8_t id[LIG_RCCL_ID_BYTES], uint32_t rank, uint32_t world, lig_comm *out);
+void lig_rccl_comm_destroy(lig_comm *comm);
 int  lig_shard_prepare(lig_ctx *ctx, const lig_synth_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
 int  lig_shard_prove(lig_shard *shard, const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
 void lig_shard_destroy(lig_shard *shard);

@@ -32,6 +32,7 @@ EXPORTS = [
     "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
     "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
+    "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy",
 ]
 
 ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
@@ -46,8 +47,13 @@ class VerifyInfo(C.Structure):
 A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
+A2A_ON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
 class Comm(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN)]
+    """lig_comm: host-synchronous callbacks (tests over gloo) and, when made by lig_rccl_comm_create, the stream-ordered RCCL forms"""
+    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN),
+                ("all_to_all_on", A2A_ON_FN), ("all_gather_on", A2A_ON_FN)]
 
 
 class SynthJob(C.Structure):
@@ -170,6 +176,10 @@ def load_library():
     L.lig_public_arg_bytes.argtypes = [C.c_int, C.c_char_p, vp, sz, C.POINTER(sz)]
     L.lig_instance_hash.argtypes = [vp, vp, sz, vp]
     L.lig_sample_columns.argtypes = [vp, u32, u32, vp]
+    L.lig_rccl_unique_id.argtypes = [vp]
+    L.lig_rccl_comm_create.argtypes = [vp, vp, u32, u32, C.POINTER(Comm)]
+    L.lig_rccl_comm_destroy.argtypes = [C.POINTER(Comm)]
+    L.lig_rccl_comm_destroy.restype = None
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -341,6 +351,21 @@ class Context:
             job.program_hash[i] = 0
         job.version = b"1.5.0"
         return job
+
+    # ---- RCCL communicator of the sharded prover (csrc/comm_rccl.hip)
+    def rccl_unique_id(self):
+        out = np.zeros(128, dtype=np.uint8)
+        self.check(self.L.lig_rccl_unique_id(_hptr(out)))
+        return out.tobytes()
+
+    def rccl_comm(self, unique_id, rank, world):
+        comm = Comm()
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        self.check(self.L.lig_rccl_comm_create(self.h, _hptr(uid), rank, world, C.byref(comm)))
+        return comm
+
+    def rccl_comm_destroy(self, comm):
+        self.L.lig_rccl_comm_destroy(C.byref(comm))
 
     # ---- one trace sharded over ranks (comm: a Comm built by dist.Group.make_comm)
     def shard_prepare(self, job, rank, world, comm):

@@ -4,35 +4,58 @@
 // =====================================================================================================================
 // One trace sharded over the GPUs of a node (BASELINE.json configs[3]).
 //
-// Rows are dealt to ranks in contiguous blocks (never splitting an x,y,z triple); every rank forms, encodes and keeps
-// only its own rows.  Leaf_j hashes ALL rows in commit order, so the hash is column-partitioned: after one all-to-all of
-// codeword column slices rank h owns columns [h*n/W, (h+1)*n/W) of every row, hashes them in rank (= row) order and the
-// n/W leaves per rank are all-gathered; the Merkle tree is then built redundantly on every rank.  The stage-2 tests are
-// sums over rows: every rank accumulates its rows on the low-degree domains (k + 2k + 2k values), the partial sums are
-// all-gathered and added mod p locally (RCCL has no modular reduction).  Opened columns are all-gathered in row order.
-// The collectives are supplied by the caller (lig_comm: torch.distributed over RCCL/xGMI in ligero-prover_amd/dist.py),
-// this file only sees device pointers.  Every rank ends with the same envelope, byte-identical to lig_synth_prove.
+// The committed rows are cut into G = W * rounds global chunks (<= 512 rows, equal sizes, never splitting an x,y,z
+// triple or an equality pair) and dealt block-cyclically: chunk g belongs to rank g mod W, so the local rows of a rank are
+// its chunks r, r+W, r+2W, ...; every rank forms, encodes and keeps only those.  leaf_j hashes ALL rows in commit order, so
+// the hash is column-partitioned (rank h owns columns [h*n/W, (h+1)*n/W)): in round c every rank sends the column slices
+// of its c-th chunk to their owners -- ONE all-to-all per round -- and receives the W consecutive global chunks
+// cW .. cW+W-1 restricted to its columns, in rank order = commit order.  The column hash therefore runs in commit order
+// from the first round on, on the side stream, while the main stream encodes round c+1 and the copy stream exchanges it:
+//     main:  encode(c)   pack(c)   encode(c+1)  pack(c+1)  ...
+//     comm:                        exchange(c)             exchange(c+1)
+//     hash:                                     hash(c)                 hash(c+1)
+// n/W leaves per rank are all-gathered, the Merkle tree is built redundantly.  The stage-2 tests are sums over rows: every
+// rank accumulates its rows on the low-degree domains (k + 2k + 2k values), the partial sums are all-gathered and added
+// mod p locally (RCCL has no modular reduction).  Opened columns are all-gathered and laid out in commit order.
+// Collectives: lig_comm (include/lig_hip.h) -- RCCL over xGMI from comm_rccl.hip (stream-ordered), or host-synchronous
+// callbacks (tests over gloo).  Every rank ends with the same envelope, byte-identical to lig_synth_prove.
 struct lig_shard {
     lig_ctx* c = nullptr;
     lig_synth_job job;
     lig_comm comm;
     uint32_t rank = 0, world = 1;
     std::vector<RowDesc> rows;                 // global plan
-    std::vector<size_t> bounds;                // world + 1 row boundaries
+    std::vector<size_t> gb;                    // G + 1 global chunk boundaries
+    std::vector<size_t> lrow0;                 // local row offset of my c-th chunk (rounds + 1 entries)
+    std::vector<size_t> grow;                  // global row of every local row
     std::vector<uint64_t> wit_pos, lin_pos;    // stream position of every global row (+1 entry)
-    std::vector<uint64_t> code_ord;            // number of code-test draws before every global row (+1 entry)
+    std::vector<uint64_t> code_ord, pad_ord;   // code-test draws / pad draws before every global row (+1 entry)
     size_t RB = 0, n_init = 0;                 // leading rows committed by the batch program, of those: init rows
-    size_t R = 0, r0 = 0, Rl = 0, rows_max = 0, ncol = 0;
+    size_t R = 0, Rl = 0, rows_max = 0, ncol = 0, rounds = 0, G = 0, ch_cap = 0;
     fr *msgs = nullptr, *cw = nullptr, *send = nullptr, *recv = nullptr, *randb = nullptr, *rhalf = nullptr, *acc = nullptr,
        *parts = nullptr, *accp = nullptr, *accg = nullptr, *dots = nullptr, *smp = nullptr, *smpg = nullptr;
-    uint32_t *sha_state = nullptr, *leaves_slice = nullptr, *leaves = nullptr, *nodes = nullptr, *data_dev = nullptr, *tri_dev = nullptr;
+    uint32_t *sha_state = nullptr, *leaves_slice = nullptr, *leaves = nullptr, *nodes = nullptr, *tri_dev = nullptr;
     lig::f29s* coef_dev = nullptr;
     std::vector<uint32_t> triples;             // local row indices
     std::vector<size_t> triple_ord;            // global ordinal of each local triple
     uint8_t *h_proof = nullptr, *h_enc = nullptr, *h_nodes = nullptr, *h_small = nullptr;
     size_t h_proof_cap = 0;
     uint8_t ih[32] = {0};
+    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr}, ev_hash[2] = {nullptr, nullptr};
+    bool exchange_even_alone = false;          // LIG_SHARD_FORCE_EXCHANGE: run pack + all-to-all with world == 1 too (tests)
+    size_t chunk_rows(size_t g) const { return g < G ? gb[g + 1] - gb[g] : 0; }
 };
+
+namespace lig {
+// out[h][r][j] = cw[r][h*ncol + j]: the column slices of `rows` codewords, one block of cap_rows x ncol per destination rank
+__global__ void __launch_bounds__(256) k_pack_slices(const fr* __restrict__ cw, size_t n, fr* __restrict__ out, size_t rows, size_t ncol, size_t cap_rows) {
+    const size_t total = rows * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / n, j = i - r * n, h = j / ncol;
+        fr_store(out + (h * cap_rows + r) * ncol + (j - h * ncol), fr_load(cw + i));
+    }
+}
+}  // namespace lig
 
 extern "C" {
 
@@ -40,6 +63,7 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
 int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, const lig_comm* comm, lig_shard** out) {
     CHECK_CTX(c);
     if (!job || !out || !comm || world == 0 || rank >= world) return LIG_E_ARG;
+    if (!comm->all_to_all || !comm->all_gather) return LIG_E_ARG;
     *out = nullptr;
     lig_shard* S = new lig_shard();
     S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world;
@@ -63,105 +87,121 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
     return LIG_OK;
 }
 static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S) {
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, W = world;
     if (l >= k || l < 2 || t > n || k - l < t || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | n");
     S->ncol = n / world;
+    S->exchange_even_alone = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
     if (!plan_rows(*job, l, S->rows, S->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
     const size_t R = S->R = S->rows.size();
     for (S->RB = 0; S->RB < R && S->rows[S->RB].kind >= RK_INIT; S->RB++) {}
-    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0);
+    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0); S->pad_ord.assign(R + 1, 0);
     for (size_t r = 0; r < R; r++) {
         const uint8_t kd = S->rows[r].kind;
         S->wit_pos[r + 1] = S->wit_pos[r] + ((kd == 3 || kd >= RK_INIT) ? 0 : S->rows[r].data);   // z rows and batch rows draw nothing
         S->lin_pos[r + 1] = S->lin_pos[r] + S->rows[r].data;
         S->code_ord[r + 1] = S->code_ord[r] + has_code_check(kd);                                    // position in the code-test stream
+        S->pad_ord[r + 1] = S->pad_ord[r] + ((kd <= 3 || kd == RK_INIT) ? 1 : 0);                   // rows that draw k-l pads upstream
     }
-    S->bounds.assign(world + 1, R);
-    S->bounds[0] = 0;
-    for (uint32_t g = 1; g < world; g++) {
-        size_t b = (size_t)(((unsigned __int128)R * g) / world);
-        auto inside_group = [&](uint8_t kd) { return kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ; };
+    // global chunks: rounds = ceil(R / (W * CHUNK)), G = W * rounds chunks of (nearly) equal size
+    S->rounds = std::max<size_t>(1, (R + W * lig_tune::CHUNK - 1) / (W * lig_tune::CHUNK));
+    S->G = S->rounds * W;
+    const size_t target = std::max<size_t>(1, (R + S->G - 1) / S->G);
+    S->gb.assign(S->G + 1, R);
+    S->gb[0] = 0;
+    auto inside_group = [&](uint8_t kd) { return kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ; };
+    for (size_t g = 1; g < S->G; g++) {
+        size_t b = std::min(R, S->gb[g - 1] + target);
         while (b < R && inside_group(S->rows[b].kind)) b++;                       // never split a triple / an equality pair
-        S->bounds[g] = std::max(b, S->bounds[g - 1]);
+        S->gb[g] = b;
     }
-    for (uint32_t g = 0; g < world; g++) S->rows_max = std::max(S->rows_max, S->bounds[g + 1] - S->bounds[g]);
+    for (size_t g = 0; g < S->G; g++) S->ch_cap = std::max(S->ch_cap, S->chunk_rows(g));
+    if (!S->ch_cap) S->ch_cap = 1;
+    S->lrow0.assign(S->rounds + 1, 0);
+    for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+        const size_t g = cidx * W + rank;
+        for (size_t r = S->gb[g]; r < S->gb[g + 1]; r++) S->grow.push_back(r);
+        S->lrow0[cidx + 1] = S->grow.size();
+    }
+    const size_t Rl = S->Rl = S->grow.size();
+    for (uint32_t h = 0; h < W; h++) {
+        size_t cnt = 0;
+        for (size_t cidx = 0; cidx < S->rounds; cidx++) cnt += S->chunk_rows(cidx * W + h);
+        S->rows_max = std::max(S->rows_max, cnt);
+    }
     if (!S->rows_max) S->rows_max = 1;
-    S->r0 = S->bounds[rank]; S->Rl = S->bounds[rank + 1] - S->bounds[rank];
-    const size_t Rl = S->Rl, r0 = S->r0, RM = S->rows_max;
+    const size_t RM = S->rows_max;
+    std::vector<size_t> local_of(R, (size_t)-1);
+    for (size_t lr = 0; lr < Rl; lr++) local_of[S->grow[lr]] = lr;
     {   // quadratic-test terms whose rows are local, with local row indices; triple_ord = position in the quadratic stream
         const std::vector<uint32_t> all = quad_terms(S->rows);
         for (size_t i = 0; i < all.size() / 3; i++) {
             const size_t last = all[3 * i + 2];
-            if (last < r0 || last >= r0 + Rl) continue;
-            S->triples.push_back(all[3 * i] - (uint32_t)r0);
-            S->triples.push_back(all[3 * i + 1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : all[3 * i + 1] - (uint32_t)r0);
-            S->triples.push_back(all[3 * i + 2] - (uint32_t)r0);
+            if (local_of[last] == (size_t)-1) continue;
+            S->triples.push_back((uint32_t)local_of[all[3 * i]]);
+            S->triples.push_back(all[3 * i + 1] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)local_of[all[3 * i + 1]]);
+            S->triples.push_back((uint32_t)local_of[last]);
             S->triple_ord.push_back(i);
         }
     }
-    const size_t chunk = lig_tune::CHUNK, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
+    const size_t chunk = S->ch_cap, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&S->msgs, (Rl ? Rl : 1) * (size_t)k * 32));
     TRY(dm((void**)&S->cw, (Rl + 3) * (size_t)n * 32));
-    TRY(dm((void**)&S->send, RM * (size_t)n * 32));
-    TRY(dm((void**)&S->recv, RM * (size_t)n * 32));
+    TRY(dm((void**)&S->send, 2 * chunk * (size_t)n * 32));          // double-buffered: W blocks of chunk x ncol each
+    TRY(dm((void**)&S->recv, 2 * chunk * (size_t)n * 32));
     TRY(dm((void**)&S->randb, chunk * (size_t)k * 32));
     TRY(dm((void**)&S->rhalf, chunk * 2 * (size_t)k * 32));
     TRY(dm((void**)&S->acc, 4 * (size_t)n * 32));
     TRY(dm((void**)&S->parts, 2 * groups * (size_t)n * 32));
     TRY(dm((void**)&S->accp, 5 * (size_t)k * 32));
     TRY(dm((void**)&S->accg, (size_t)world * 5 * k * 32));
-    TRY(dm((void**)&S->dots, (Rl ? Rl : 1) * 32));
+    TRY(dm((void**)&S->dots, 32));
     TRY(dm((void**)&S->smp, (RM + 3) * (size_t)t * 32));
     TRY(dm((void**)&S->smpg, (size_t)world * RM * t * 32));
     TRY(dm((void**)&S->sha_state, lig_sha_state_bytes(S->ncol)));
     TRY(dm((void**)&S->leaves_slice, S->ncol * 32));
     TRY(dm((void**)&S->leaves, (size_t)n * 32));
     TRY(dm((void**)&S->nodes, lig_merkle_nodes(n) * 32));
-    TRY(dm((void**)&S->data_dev, (Rl ? Rl : 1) * sizeof(uint32_t)));
     TRY(dm((void**)&S->tri_dev, (S->triples.size() ? S->triples.size() : 1) * sizeof(uint32_t)));
     TRY(dm((void**)&S->coef_dev, (Rl + 2 * S->triple_ord.size() + 1) * sizeof(lig::f29s)));
     S->h_proof_cap = ((size_t)1 << 19) + 3 * (size_t)n * 32 + (R + 3) * (size_t)t * 32;
     HIP_TRY(c, hipHostMalloc((void**)&S->h_proof, S->h_proof_cap, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&S->h_enc, 3 * (size_t)n * 32, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&S->h_nodes, lig_merkle_nodes(n) * 32, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void**)&S->h_small, ((Rl ? Rl : 1) + 2 * (size_t)l + 3 * (size_t)n + 2 * world) * 32, hipHostMallocDefault));
-    {
-        std::vector<uint32_t> d(Rl);
-        for (size_t r = 0; r < Rl; r++) d[r] = S->rows[r0 + r].data;
-        if (Rl) HIP_TRY(c, hipMemcpyAsync(S->data_dev, d.data(), Rl * 4, hipMemcpyHostToDevice, c->stream));
-        if (!S->triples.empty()) HIP_TRY(c, hipMemcpyAsync(S->tri_dev, S->triples.data(), S->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipHostMalloc((void**)&S->h_small, (1 + 3 * (size_t)n) * 32, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&S->ev_enc[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&S->ev_comm[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&S->ev_hash[i], hipEventDisableTiming));
     }
+    if (!S->triples.empty()) HIP_TRY(c, hipMemcpyAsync(S->tri_dev, S->triples.data(), S->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(lig_internal_reserve_scratch(c, chunk));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     // local witness rows: same stream positions as in the single-GPU trace
     uint32_t rk[60];
-    lig::aes256_expand_host(job->witness_key, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    size_t r_first = 0;
     if (S->RB) {          // the batch program is small: every rank runs it and keeps the rows it owns
         fr* all = nullptr;
         HIP_TRY(c, hipMalloc((void**)&all, S->RB * (size_t)k * sizeof(fr)));
-        const int rc = lig_run_batch_program(c, *job, all);
-        const size_t lo = std::min(r0, S->RB), hi = std::min(r0 + Rl, S->RB);
-        if (rc == LIG_OK && hi > lo) (void)hipMemcpyAsync(S->msgs + (lo - r0) * (size_t)k, all + lo * (size_t)k, (hi - lo) * (size_t)k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream);
+        int rc = lig_run_batch_program(c, *job, all);
+        for (size_t lr = 0; lr < Rl && rc == LIG_OK; lr++)
+            if (S->grow[lr] < S->RB && hipMemcpyAsync(S->msgs + lr * (size_t)k, all + S->grow[lr] * (size_t)k, (size_t)k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = LIG_E_HIP;
         (void)hipStreamSynchronize(c->stream);
         (void)hipFree(all);
         if (rc != LIG_OK) return rc;
-        r_first = hi - lo;
-        lig::aes256_expand_host(job->witness_key, rk);                    // the program used the encoding key
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    for (size_t r = r_first; r < Rl;) {
-        const RowDesc d = S->rows[r0 + r];
+    lig::aes256_expand_host(job->witness_key, rk);
+    TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, c->stream));
+    for (size_t lr = 0; lr < Rl;) {
+        const size_t gr = S->grow[lr];
+        const RowDesc d = S->rows[gr];
+        if (d.kind >= RK_INIT) { lr++; continue; }
         if (d.kind == 0) {
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[r0 + r], S->msgs + r * k, 1, d.data, k, 0, 1, d.data);
-            r += 1;
-        } else {
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[r0 + r], S->msgs + r * k, 2, d.data, k, 0, 1, d.data);
-            lig::launch_eltwise(c->stream, LIG_OP_MUL, S->msgs + r * k, S->msgs + (r + 1) * k, S->msgs + (r + 2) * k, d.data, fr{}, 0);
-            r += 3;
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[gr], S->msgs + lr * k, 1, d.data, k, 0, 1, d.data);
+            lr += 1;
+        } else {          // x, y, z are consecutive locally as well: chunks never split a triple
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[gr], S->msgs + lr * k, 2, d.data, k, 0, 1, d.data);
+            lig::launch_eltwise(c->stream, LIG_OP_MUL, S->msgs + lr * k, S->msgs + (lr + 1) * k, S->msgs + (lr + 2) * k, d.data, fr{}, 0);
+            lr += 3;
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -173,11 +213,15 @@ void lig_shard_destroy(lig_shard* S) {
     if (!S) return;
     (void)hipSetDevice(S->c->device);
     (void)hipStreamSynchronize(S->c->stream);
+    (void)hipStreamSynchronize(S->c->stream2);
+    (void)hipStreamSynchronize(S->c->stream3);
     S->c->sha.erase(S->sha_state);
     for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
                     (void*)S->parts, (void*)S->accp, (void*)S->accg, (void*)S->dots, (void*)S->smp, (void*)S->smpg, (void*)S->sha_state,
-                    (void*)S->leaves_slice, (void*)S->leaves, (void*)S->nodes, (void*)S->data_dev, (void*)S->tri_dev, (void*)S->coef_dev})
+                    (void*)S->leaves_slice, (void*)S->leaves, (void*)S->nodes, (void*)S->tri_dev, (void*)S->coef_dev})
         (void)hipFree(p);
+    for (int i = 0; i < 2; i++)
+        for (hipEvent_t e : {S->ev_enc[i], S->ev_comm[i], S->ev_hash[i]}) if (e) (void)hipEventDestroy(e);
     (void)hipHostFree(S->h_proof); (void)hipHostFree(S->h_enc); (void)hipHostFree(S->h_nodes); (void)hipHostFree(S->h_small);
     delete S;
 }
@@ -187,25 +231,37 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig_ctx* c = S->c;
     CHECK_CTX(c);
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l, W = S->world;
-    const size_t R = S->R, Rl = S->Rl, r0 = S->r0, RM = S->rows_max, ncol = S->ncol;
-    hipStream_t s = c->stream;
+    const size_t R = S->R, Rl = S->Rl, RM = S->rows_max, ncol = S->ncol, CAP = S->ch_cap;
+    hipStream_t s = c->stream, s_hash = c->stream2, s_comm = c->stream3;
     std::memset(info, 0, sizeof *info);
     info->rows = R + 3;
     const auto t_begin = clk::now();
     auto t0 = clk::now();
-    auto comm_fail = [&](int rc, const char* what) { c->err = std::string("collective failed: ") + what; return rc ? LIG_E_STATE : LIG_OK; };
+    const bool ordered = S->comm.all_to_all_on != nullptr && S->comm.all_gather_on != nullptr;
+    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos) c->err = std::string("collective failed: ") + what; return (int)LIG_E_STATE; };
+    // all-gather in stream order on `st` (RCCL) or host-synchronously after draining `st`
+    auto all_gather = [&](const void* src, void* dst, size_t bytes, hipStream_t st, const char* what) -> int {
+        if (ordered) { if (S->comm.all_gather_on(S->comm.user, src, dst, bytes, st)) return comm_fail(what); return LIG_OK; }
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (S->comm.all_gather(S->comm.user, src, dst, bytes)) return comm_fail(what);
+        return LIG_OK;
+    };
 
     // ---------------- stage 1
     uint32_t rk[60];
     lig::aes256_expand_host(S->job.encoding_seed, rk);
-    HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    {   // pads of the local stream rows (batch rows carry theirs from the program); position = draws before the row
-        const size_t first = std::max(r0, S->RB), last = r0 + Rl;
-        if (last > first)
-            lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)(S->n_init + (first - S->RB)) * pad, S->msgs + (first - r0) * (size_t)k, last - first, pad, k, l, 1, pad);
+    TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, s));
+    // pads of the local rows that draw them at commit time (batch init rows carry theirs from the program): the position
+    // of a row's pads = number of pad-drawing rows before it in commit order; runs of consecutive rows = one launch
+    for (size_t lr = 0; lr < Rl;) {
+        const size_t gr = S->grow[lr];
+        if (S->rows[gr].kind > 3) { lr++; continue; }
+        size_t run = 1;
+        while (lr + run < Rl && S->grow[lr + run] == gr + run && S->rows[gr + run].kind <= 3) run++;
+        lig::launch_rng_fill_rows(s, c->rk_dev, S->pad_ord[gr] * pad, S->msgs + lr * (size_t)k, run, pad, k, l, 1, pad);
+        lr += run;
     }
-    uint64_t epos = (uint64_t)(S->n_init + (R - S->RB)) * pad;
+    uint64_t epos = S->pad_ord[R] * pad;
     fr* mask = S->cw + Rl * (size_t)n; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;           // masks: formed by every rank
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;
@@ -214,28 +270,62 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, l, 0, 1, 2, 0); epos += l;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mquad, 1, 2 * pad, 0, 2 * l, 1, 0); epos += 2 * pad;
-    if (Rl) TRY(lig_internal_encode_rows(c, S->msgs, S->cw, Rl, false));
-    TRY(lig_encode(c, mask));
-    TRY(lig_internal_encode_2k_rows(c, mlin, 2));          // mlin and mquad are adjacent rows: one pass of 31 launches
-    // column slices: block h of `send` = my rows restricted to rank h's columns
-    for (uint32_t h = 0; h < W && Rl; h++)
-        HIP_TRY(c, hipMemcpy2DAsync(S->send + (size_t)h * RM * ncol, ncol * 32, S->cw + (size_t)h * ncol, (size_t)n * 32, ncol * 32, Rl,
-                                    hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_to_all(S->comm.user, S->send, S->recv, RM * ncol * 32)) return comm_fail(rc, "all_to_all(codeword column slices)");
     TRY(lig_sha_init(c, S->sha_state, ncol));
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+    HIP_TRY(c, hipStreamWaitEvent(s_hash, c->ev_fork, 0));
+    HIP_TRY(c, hipStreamWaitEvent(s_comm, c->ev_fork, 0));
+    // the three mask rows do not depend on the witness: encoded on the hash stream under the first round's encode
+    TRY(lig_internal_encode_generic(c, mask, s_hash));
+    TRY(lig_internal_encode_2k_rows(c, mlin, 2, s_hash));
+    const bool exchange = W > 1 || S->exchange_even_alone;
+    const size_t blk_elems = CAP * ncol;                         // one block of the exchange buffers (per rank pair and round)
     uint64_t absorbed = 0;
-    for (uint32_t g = 0; g < W; g++) {
-        const size_t rg = S->bounds[g + 1] - S->bounds[g];
-        lig::launch_sha_update_rows(s, S->sha_state, ncol, S->recv + (size_t)g * RM * ncol, ncol, rg, absorbed);
-        absorbed += rg;
+    for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+        const int pb = (int)(cidx & 1);
+        const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
+        fr* sendb = S->send + (size_t)pb * CAP * n; fr* recvb = S->recv + (size_t)pb * CAP * n;
+        if (nb) TRY(lig_internal_encode_rows(c, S->msgs + lb * (size_t)k, S->cw + lb * (size_t)n, nb, false, s));
+        if (exchange) {
+            if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s, S->ev_comm[pb], 0));          // send buffer free again (exchange c-2 done)
+            if (nb) hipLaunchKernelGGL(lig::k_pack_slices, dim3(2048), dim3(256), 0, s, S->cw + lb * (size_t)n, (size_t)n, sendb, nb, ncol, CAP);
+        }
+        HIP_TRY(c, hipEventRecord(S->ev_enc[pb], s));
+        if (exchange) {
+            if (ordered) {
+                HIP_TRY(c, hipStreamWaitEvent(s_comm, S->ev_enc[pb], 0));
+                if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s_comm, S->ev_hash[pb], 0));   // receive buffer free again (hash c-2 done)
+                if (S->comm.all_to_all_on(S->comm.user, sendb, recvb, blk_elems * 32, s_comm)) return comm_fail("all_to_all(codeword column slices)");
+                HIP_TRY(c, hipEventRecord(S->ev_comm[pb], s_comm));
+            } else {
+                HIP_TRY(c, hipStreamSynchronize(s));
+                HIP_TRY(c, hipStreamSynchronize(s_hash));                               // receive buffer free again
+                if (S->comm.all_to_all(S->comm.user, sendb, recvb, blk_elems * 32)) return comm_fail("all_to_all(codeword column slices)");
+                HIP_TRY(c, hipEventRecord(S->ev_comm[pb], s));
+            }
+            HIP_TRY(c, hipStreamWaitEvent(s_hash, S->ev_comm[pb], 0));
+            for (uint32_t h = 0; h < W; h++) {               // global chunks cW .. cW+W-1 in rank order = commit order
+                const size_t rg = S->chunk_rows(cidx * W + h);
+                if (rg) lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, recvb + (size_t)h * blk_elems, ncol, rg, absorbed);
+                absorbed += rg;
+            }
+        } else {                                             // one rank: its codewords are the rows, all columns are its own
+            HIP_TRY(c, hipStreamWaitEvent(s_hash, S->ev_enc[pb], 0));
+            if (nb) lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, S->cw + lb * (size_t)n, n, nb, absorbed);
+            absorbed += nb;
+        }
+        HIP_TRY(c, hipEventRecord(S->ev_hash[pb], s_hash));
     }
-    lig::launch_sha_update_rows(s, S->sha_state, ncol, mask + (size_t)S->rank * ncol, n, 3, absorbed);
+    lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, mask + (size_t)S->rank * ncol, n, 3, absorbed);
     absorbed += 3;
     c->sha[S->sha_state].second = absorbed;
+    HIP_TRY(c, hipEventRecord(c->ev_join, s_hash));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    if (exchange && ordered) {                                // the main stream also joins the exchange stream
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s_comm));
+        HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
+    }
     TRY(lig_sha_final(c, S->sha_state, S->leaves_slice));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_gather(S->comm.user, S->leaves_slice, S->leaves, ncol * 32)) return comm_fail(rc, "all_gather(leaves)");
+    TRY(all_gather(S->leaves_slice, S->leaves, ncol * 32, s, "all_gather(leaves)"));
     TRY(lig_merkle_build(c, S->leaves, n, S->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -248,62 +338,57 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     {
         std::vector<H::Fr> rc, rq;
         const size_t NT = quad_terms(S->rows).size() / 3;
-        FieldStream code(info->stage1_seed), quad(info->stage1_seed);
-        code.next(S->code_ord[R], rc);
-        quad.next(NT, rq);
+        FieldStream code_s(info->stage1_seed), quad_s(info->stage1_seed);
+        code_s.next(S->code_ord[R], rc);
+        quad_s.next(NT, rq);
         std::vector<lig::f29s> coef(Rl + 2 * NTl + 1);
         const H::Fr R261sq = H::mul(R261, R261);
         std::memset(coef.data(), 0, coef.size() * sizeof(lig::f29s));
-        for (size_t r = 0; r < Rl; r++) if (has_code_check(S->rows[r0 + r].kind)) coef[r] = to_f29s_host(rc[S->code_ord[r0 + r]], R261);
+        for (size_t lr = 0; lr < Rl; lr++) if (has_code_check(S->rows[S->grow[lr]].kind)) coef[lr] = to_f29s_host(rc[S->code_ord[S->grow[lr]]], R261);
         for (size_t i = 0; i < NTl; i++) { coef[Rl + i] = to_f29s_host(rq[S->triple_ord[i]], R261sq); coef[Rl + NTl + i] = to_f29s_host(rq[S->triple_ord[i]], R261); }
-        HIP_TRY(c, hipMemcpyAsync(S->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
+        TRY(lig_internal_upload_small(c, S->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), s));
         lig::aes256_expand_host(info->stage1_seed, rk);
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, s));
     }
     fr* code = S->acc; fr* lin = S->acc + n; fr* quad = S->acc + 2 * (size_t)n; fr* tmp = S->acc + 3 * (size_t)n;
     fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
-    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 3 * (size_t)n * 32, s));
-    const size_t groups = (lig_tune::CHUNK + lig_tune::GROUP - 1) / lig_tune::GROUP;
-    for (size_t b = 0; b < Rl; b += lig_tune::CHUNK) {
-        const size_t nb = std::min(lig_tune::CHUNK, Rl - b);
+    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 4 * (size_t)n * 32, s));
+    const size_t groups = (CAP + lig_tune::GROUP - 1) / lig_tune::GROUP;
+    for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+        const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
+        if (!nb) continue;
         HIP_TRY(c, hipMemsetAsync(S->randb, 0, nb * (size_t)k * 32, s));
-        for (size_t r = 0; r < nb;) {          // runs of rows with equal fill are contiguous in the linear stream
+        for (size_t r = 0; r < nb;) {          // a chunk is a run of consecutive global rows: runs of equal fill are contiguous in the linear stream
             size_t run = 1;
-            const uint32_t d = S->rows[r0 + b + r].data;
-            while (r + run < nb && S->rows[r0 + b + r + run].data == d) run++;
-            lig::launch_rng_fill_rows(s, c->rk_dev, S->lin_pos[r0 + b + r], S->randb + r * k, run, d, k, 0, 1, d);
+            const size_t gr = S->grow[lb + r];
+            const uint32_t d = S->rows[gr].data;
+            while (r + run < nb && S->rows[gr + run].data == d) run++;
+            lig::launch_rng_fill_rows(s, c->rk_dev, S->lin_pos[gr], S->randb + r * k, run, d, k, 0, 1, d);
             r += run;
         }
         TRY(lig_internal_encode_rows(c, S->randb, S->rhalf, nb, true));
-        lig::launch_rlc_rows29(s, S->cw + b * n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, linC, S->parts,
+        lig::launch_rlc_rows29(s, S->cw + lb * (size_t)n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, linC, S->parts,
                                S->parts + groups * (size_t)n, lig_tune::GROUP / 4);
-        lig::launch_rlc_rows29(s, S->msgs + b * k, k, 1, S->randb, k, nb, k, S->coef_dev + b, code, linH, S->parts,
+        lig::launch_rlc_rows29(s, S->msgs + lb * (size_t)k, k, 1, S->randb, k, nb, k, S->coef_dev + lb, tmp, linH, S->parts,
                                S->parts + groups * (size_t)n, lig_tune::GROUP / 4);
     }
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
-    // partial sums [code (k) | lin (2k) | quad (2k)] -> every rank -> added mod p
-    HIP_TRY(c, hipMemcpyAsync(S->accp, code, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+    // partial sums [code (k message values) | lin (2k) | quad (2k)] -> every rank -> added mod p
+    HIP_TRY(c, hipMemcpyAsync(S->accp, tmp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->accp + k, lin, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(S->accp + 3 * (size_t)k, quad, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    H::Fr* dots = reinterpret_cast<H::Fr*>(S->h_small);
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_gather(S->comm.user, S->accp, S->accg, 5 * (size_t)k * 32)) return comm_fail(rc, "all_gather(partial accumulators)");
+    TRY(all_gather(S->accp, S->accg, 5 * (size_t)k * 32, s, "all_gather(partial accumulators)"));
     HIP_TRY(c, hipMemsetAsync(S->accp, 0, 5 * (size_t)k * 32, s));
     lig::launch_rlc_combine(s, S->accp, S->accg, W, 5 * k);
-    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 3 * (size_t)n * 32, s));
-    HIP_TRY(c, hipMemcpyAsync(code, S->accp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 4 * (size_t)n * 32, s));
+    HIP_TRY(c, hipMemcpyAsync(tmp, S->accp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(lin, S->accp + k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(quad, S->accp + 3 * (size_t)k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    {   // linear-test constant = -(sum of the message-domain half of the combined accumulator: its even points)
-        lig::launch_sum_elems(s, lin, k, 2, S->dots, nullptr);
-        HIP_TRY(c, hipMemcpyAsync(dots, S->dots, 32, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        const H::Fr sum = H::neg(dots[0]);
-        std::memcpy(info->const_sum, sum.v, 32);
-    }
-    TRY(lig_encode(c, code));
+    H::Fr* dots = reinterpret_cast<H::Fr*>(S->h_small);
+    lig::launch_sum_elems(s, lin, k, 2, S->dots, nullptr);   // linear-test constant = -(sum of the message-domain half: the even points)
+    HIP_TRY(c, hipMemcpyAsync(dots, S->dots, 32, hipMemcpyDeviceToHost, s));
+    TRY(lig_internal_encode_rows(c, tmp, code, 1, false));
     TRY(lig_internal_extend_2k(c, lin));
     TRY(lig_internal_extend_2k(c, quad));
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
@@ -312,16 +397,19 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     uint8_t* enc = S->h_enc;
     const size_t enc_bytes = 3 * (size_t)n * 32;
     HIP_TRY(c, hipMemcpyAsync(enc, S->acc, enc_bytes, hipMemcpyDeviceToHost, s));
-    H::Fr* dec = reinterpret_cast<H::Fr*>(S->h_small + ((Rl ? Rl : 1) + 2 * (size_t)l) * 32);
+    H::Fr* dec = reinterpret_cast<H::Fr*>(S->h_small + 32);
     const fr* accs[3] = {code, lin, quad};
     for (int a3 = 0; a3 < 3; a3++) {
-        HIP_TRY(c, hipMemcpyAsync(tmp, accs[a3], (size_t)n * 32, hipMemcpyDeviceToDevice, s));
-        TRY(lig_decode(c, tmp));
+        TRY(lig_internal_decode_to(c, accs[a3], tmp));
         HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
     }
     const size_t n_nodes = lig_merkle_nodes(n);
     HIP_TRY(c, hipMemcpyAsync(S->h_nodes, S->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        const H::Fr sum = H::neg(dots[0]);
+        std::memcpy(info->const_sum, sum.v, 32);
+    }
     Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     TRY(lig_sample_init(c, idx.data(), idx.size()));
@@ -342,18 +430,21 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
 
     // ---------------- stage 3
     TRY(lig_gather_rows(c, S->cw, Rl + 3, S->smp));                  // local rows, then the 3 masks
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (int rc = S->comm.all_gather(S->comm.user, S->smp, S->smpg, RM * (size_t)t * 32)) return comm_fail(rc, "all_gather(opened columns)");
+    TRY(all_gather(S->smp, S->smpg, RM * (size_t)t * 32, s, "all_gather(opened columns)"));
     char ver[17] = {0};
     std::memcpy(ver, S->job.version, 16);
     const size_t smp_bytes = (R + 3) * (size_t)t * 32;
     const EnvelopeLayout lay = write_envelope(S->h_proof, S->h_proof_cap, ver, S->job.program_hash, S->job.generated_at, k, n, t,
                                               info->root, sib, idx, enc, smp_bytes);
     if (lay.total > S->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
+    // opened columns in commit order: global chunk g = the (g / W)-th chunk of rank g mod W
+    std::vector<size_t> taken(W, 0);
     uint8_t* dst = S->h_proof + lay.samples_off;
-    for (uint32_t g = 0; g < W; g++) {
-        const size_t rg = S->bounds[g + 1] - S->bounds[g];
-        if (rg) HIP_TRY(c, hipMemcpyAsync(dst, S->smpg + (size_t)g * RM * t, rg * (size_t)t * 32, hipMemcpyDeviceToHost, s));
+    for (size_t g = 0; g < S->G; g++) {
+        const uint32_t h = (uint32_t)(g % W);
+        const size_t rg = S->chunk_rows(g);
+        if (rg) HIP_TRY(c, hipMemcpyAsync(dst, S->smpg + ((size_t)h * RM + taken[h]) * t, rg * (size_t)t * 32, hipMemcpyDeviceToHost, s));
+        taken[h] += rg;
         dst += rg * (size_t)t * 32;
     }
     HIP_TRY(c, hipMemcpyAsync(dst, S->smp + Rl * (size_t)t, 3 * (size_t)t * 32, hipMemcpyDeviceToHost, s));
@@ -365,6 +456,5 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
-
 
 }  // extern "C"

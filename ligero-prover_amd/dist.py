@@ -65,19 +65,23 @@ class Group:
     # ---- collectives for the sharded prover (include/lig_hip.h: lig_comm).  The C side hands over raw pointers after
     # synchronising its stream; the callbacks return once the received data is in place.
     def make_comm(self, pkg, ctx):
-        """pkg = the ligero_prover_amd module, ctx = its Context on this rank's GPU.  nccl: the device pointers are
-        wrapped as torch tensors (zero copy) and exchanged over RCCL/xGMI; gloo (tests): staged through host memory."""
+        """pkg = the ligero_prover_amd module, ctx = its Context on this rank's GPU.
+        nccl: the product path -- the library's own RCCL communicator (csrc/comm_rccl.hip: grouped ncclSend/ncclRecv and
+        ncclAllGather enqueued on the context's HIP streams); torch.distributed only carries the 128-byte unique id from
+        rank 0 to the others.  gloo (tests) / no process group: host-synchronous callbacks staged through host memory."""
         import ctypes as C
         import numpy as np
         import torch
         g = self
-
-        class _Dev:
-            def __init__(self, ptr, nbytes):
-                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-        def dev_tensor(ptr, nbytes):
-            return torch.as_tensor(_Dev(ptr, nbytes), device="cuda")
+        if g.backend == "nccl":
+            uid = ctx.rccl_unique_id() if g.rank == 0 else bytes(128)
+            if g.dist is not None:
+                t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+                g.dist.broadcast(t, src=0)
+                uid = bytes(t.cpu().tolist())
+            comm = ctx.rccl_comm(uid, g.rank, g.world)
+            self._rccl = (ctx, comm)
+            return comm
 
         def host_of(ptr, nbytes):        # device -> host numpy copy through the library's own stream
             return ctx.download(C.c_void_p(ptr), (nbytes,), dtype=np.uint8)
@@ -87,10 +91,6 @@ class Group:
                 total = block * g.world
                 if g.dist is None:
                     ctx.check(ctx.L.lig_copy(ctx.h, C.c_void_p(recv), C.c_void_p(send), total)); ctx.sync()
-                elif g.backend == "nccl":
-                    src, dst = dev_tensor(send, total), dev_tensor(recv, total)
-                    g.dist.all_to_all_single(dst, src)
-                    torch.cuda.synchronize()
                 else:                      # gloo has no all_to_all: gather everything, keep the blocks addressed to me
                     mine = torch.from_numpy(host_of(send, total))
                     parts = [torch.empty_like(mine) for _ in range(g.world)]
@@ -106,10 +106,6 @@ class Group:
             try:
                 if g.dist is None:
                     ctx.check(ctx.L.lig_copy(ctx.h, C.c_void_p(recv), C.c_void_p(send), nbytes)); ctx.sync()
-                elif g.backend == "nccl":
-                    src, dst = dev_tensor(send, nbytes), dev_tensor(recv, nbytes * g.world)
-                    g.dist.all_gather_into_tensor(dst, src)
-                    torch.cuda.synchronize()
                 else:
                     mine = torch.from_numpy(host_of(send, nbytes))
                     parts = [torch.empty_like(mine) for _ in range(g.world)]
@@ -128,6 +124,10 @@ class Group:
         return comm
 
     def close(self):
+        if getattr(self, "_rccl", None):
+            ctx, comm = self._rccl
+            ctx.rccl_comm_destroy(comm)
+            self._rccl = None
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()

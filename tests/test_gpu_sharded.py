@@ -1,6 +1,8 @@
 """Single trace sharded over W ranks (BASELINE.json configs[3]) -- run as W processes that share the one GPU of the
-test box, with gloo carrying the collectives (the same callbacks use RCCL when the backend is nccl).  Every rank's
-envelope must be byte-identical to the unsharded prover's (which the parity tests tie to the oracle)."""
+test box, with gloo carrying the collectives through the host-synchronous callbacks of lig_comm; the product path (the
+library's own RCCL communicator, csrc/comm_rccl.hip, stream-ordered) is exercised on a 1-rank communicator with the
+exchange forced on.  Every rank's envelope must be byte-identical to the unsharded prover's (which the parity tests tie
+to the oracle)."""
 import hashlib
 import json
 import os
@@ -68,6 +70,8 @@ def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch=False):
     (2, 320, 512, 2048, 2000, 900),       # 7 + 9 rows: linear block, quadratic triples, partial rows
     (4, 320, 512, 2048, 700, 0),          # 3 rows on 4 ranks: one rank owns no row
     (2, 8000, 8192, 32768, 5 * 8000 + 17, 8000),
+    (2, 320, 512, 2048, 320 * 1500 + 7, 330),     # 1501 + 6 rows on 2 ranks: two exchange rounds (double-buffered send / receive)
+    (4, 320, 512, 2048, 320 * 4300 + 1, 0),       # three rounds on 4 ranks, the last chunks shorter
 ])
 def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, n_quad):
     outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, 29741 + world)
@@ -95,26 +99,32 @@ NCCL_WORKER = textwrap.dedent('''
     torch.cuda.set_device(0)
     pkg = load("ligero_prover_amd", "__init__.py")
     dist = load("lig_dist", "dist.py")
-    g = dist.Group("nccl", force_init=True)          # a 1-rank RCCL communicator: exercises the device-pointer tensor path
+    g = dist.Group("nccl", force_init=True)          # torch carries the unique id; the collectives are the library's own RCCL calls
     ctx = pkg.Context(320, 512, 2048, device=0)
-    job = pkg.Context.make_job(2000, 900, generated_at=77)
-    sh = ctx.shard_prepare(job, g.rank, g.world, g.make_comm(pkg, ctx))
+    nl, nq = 320 * 1300 + 5, 900                     # 1301 + 9 rows: three exchange rounds
+    job = pkg.Context.make_job(nl, nq, generated_at=77)
+    comm = g.make_comm(pkg, ctx)
+    assert bool(comm.all_to_all_on) and bool(comm.all_gather_on)
+    sh = ctx.shard_prepare(job, g.rank, g.world, comm)
     proof, info = ctx.shard_prove(sh)
+    proof2, _ = ctx.shard_prove(sh)
     ctx.shard_destroy(sh)
-    tr = ctx.synth_prepare(2000, 900, generated_at=77)
+    tr = ctx.synth_prepare(nl, nq, generated_at=77)
     ref, _ = ctx.synth_prove(tr)
     ctx.trace_destroy(tr)
-    print(json.dumps({"equal": proof == ref, "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
-    ctx.close(); g.close()
+    print(json.dumps({"equal": proof == ref and proof2 == ref, "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
+    g.close(); ctx.close()
 ''')
 
 
-def test_rccl_device_pointer_collectives_one_rank(tmp_path):
-    """the nccl branch of the callbacks (device pointers wrapped as torch tensors, RCCL all_to_all_single /
-    all_gather_into_tensor) on a 1-rank communicator -- all that a 1-GPU box can exercise of the RCCL path"""
+def test_rccl_stream_ordered_collectives_one_rank(tmp_path):
+    """the product's RCCL communicator (grouped ncclSend/ncclRecv + ncclAllGather on the context's streams, exchange of
+    round c under the encode of round c+1) on a 1-rank communicator with the exchange forced on -- all that a 1-GPU box
+    can exercise of the RCCL path"""
     script = tmp_path / "nccl_worker.py"
     script.write_text(NCCL_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29761", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29761", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               LIG_SHARD_FORCE_EXCHANGE="1")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])     # RCCL prints its own lines
