@@ -469,6 +469,10 @@ def main():
     wl.close()
     ctx.close()
     group.close()
+    try:                            # RCCL prints its banner through C stdio, which is block-buffered when stdout is a pipe:
+        C.CDLL(None).fflush(None)   # push it out now so that the JSON line below really is the last line
+    except OSError:
+        pass
     if result is not None:          # printed last and flushed: RCCL / the runtime may print their own lines earlier
         sys.stdout.flush()
         print(result, flush=True)
