@@ -1,0 +1,144 @@
+// lig_hip_row_batcher.hpp -- the row-batching shim between the reference's per-row stage callbacks and the batched
+// caller-rows prover entry of liblig_hip.so (lig_rows_*, include/lig_hip.h).
+//
+// The reference's stage contexts push ONE row through the executor per callback and run the guest three times
+// (include/zkp/nonbatch_context.hpp: stage 1 :445-553, stage 2 :654-850, stage 3 :924-1047; src/webgpu_prover.cpp:266,305,408).
+// `ligero::hip_row_batcher` offers the same callbacks -- linear_callback / quadratic_callback / mask_callback /
+// on_batch_init / on_batch_bit / on_batch_equal / on_batch_quadratic, called by witness_manager
+// (include/zkp/backend/witness_manager.hpp:200-321) and vbn254fr_module (include/host_modules/vbn254fr.hpp) -- but only
+// RECORDS the rows; the GPU sees them in one batch per stage:
+//
+//     hip_row_batcher b(ctx, meta);                       // meta: encoding seed, program hash, timestamp, public arguments
+//     run_program(..., b)            pass 1               // callbacks record the message rows (pads included, as the
+//     root, seed1 = b.commit();                           //   witness_manager forms them) -> stage 1 on the GPU
+//     init_witness_random(seed1); run_program(..., b)     // pass 2: the same callbacks now also carry the per-witness
+//     proof = b.prove(linear_sums);                       //   randomness rows -> stages 2 + 3 on the GPU
+//
+// A third run of the guest (the reference's stage 3) is not needed: the codewords stayed resident, the opened columns
+// are gathered from them.  Rows are `k * 4` little-endian u64 limbs, exactly what mpz_vector::export_limbs produces
+// (include/util/mpz_vector.hpp:108-127; nonbatch_context.hpp:447); batch rows are device rows of the vbn254fr slab.
+// The three mask rows arrive through mask_callback upstream; the library forms the identical rows itself from the
+// encoding seed (same stream, same position: after the pads of all rows), so mask_callback only checks sizes.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lig_hip.h"
+
+namespace ligero {
+
+struct hip_proof_meta {
+    uint8_t encoding_seed[32] = {0};          // src/webgpu_prover.cpp:239-245
+    uint8_t program_hash[32] = {0};           // :222-223
+    int64_t generated_at = 0;                 // :422-427
+    std::string version = "1.5.0";
+    std::vector<std::vector<uint8_t>> public_args;   // input_args entries of the PUBLIC arguments after arg0 (:110-168)
+};
+
+class hip_row_batcher {
+public:
+    hip_row_batcher(lig_ctx* ctx, hip_proof_meta meta)
+        : ctx_(ctx), meta_(std::move(meta)), k_(lig_padding_size(ctx)) {
+        if (!ctx_) throw std::invalid_argument("hip_row_batcher: null context");
+    }
+    hip_row_batcher(const hip_row_batcher&) = delete;
+    hip_row_batcher& operator=(const hip_row_batcher&) = delete;
+    ~hip_row_batcher() { if (trace_) lig_trace_destroy(trace_); }
+
+    // ---- the callbacks of nonbatch_context_base (nonbatch_context.hpp:78-86).  `rand` rows are null in pass 1.
+    void linear_callback(const uint64_t* val, const uint64_t* rand = nullptr) { row(LIG_ROW_LINEAR, val, rand); }
+    void quadratic_callback(const uint64_t* x, const uint64_t* y, const uint64_t* z, const uint64_t* x_rand = nullptr,
+                            const uint64_t* y_rand = nullptr, const uint64_t* z_rand = nullptr) {
+        row(LIG_ROW_QX, x, x_rand); row(LIG_ROW_QY, y, y_rand); row(LIG_ROW_QZ, z, z_rand);
+    }
+    void mask_callback(size_t code_size, size_t linear_size, size_t quad_size) const {
+        if (code_size != k_ || linear_size != 2 * (size_t)k_ || quad_size != 2 * (size_t)k_) throw std::invalid_argument("mask_callback: unexpected mask sizes");
+    }
+    // vbn254fr hooks (nonbatch_context.hpp:497-553, :782-850): device rows of k elements; they carry no linear-test randomness
+    void on_batch_init(const void* dev_x) { dev_row(LIG_ROW_INIT, dev_x); }
+    void on_batch_bit(const void* dev_x) { dev_row(LIG_ROW_BIT, dev_x); }
+    void on_batch_equal(const void* dev_x, const void* dev_y) { dev_row(LIG_ROW_EQX, dev_x); dev_row(LIG_ROW_EQY, dev_y); }
+    void on_batch_quadratic(const void* dev_x, const void* dev_y, const void* dev_z) {
+        dev_row(LIG_ROW_BQX, dev_x); dev_row(LIG_ROW_BQY, dev_y); dev_row(LIG_ROW_BQZ, dev_z);
+    }
+
+    // ---- end of pass 1: stage 1 on the GPU.  Returns the Merkle root and the stage-1 seed (= the key of the code /
+    // linear / quadratic random engines of pass 2, nonbatch_context.hpp:105-112).
+    void commit(uint8_t root[32], uint8_t stage1_seed[32]) {
+        if (pass_ != 1) throw std::logic_error("hip_row_batcher::commit called twice");
+        std::vector<uint8_t> args;
+        std::vector<uint64_t> lens;
+        for (const auto& a : meta_.public_args) { args.insert(args.end(), a.begin(), a.end()); lens.push_back(a.size()); }
+        lig_rows_job job;
+        std::memset(&job, 0, sizeof job);
+        job.rows = kinds_.size();
+        job.kinds = kinds_.data();
+        job.msgs = rows_.data();
+        job.msgs_on_device = 0;
+        std::memcpy(job.encoding_seed, meta_.encoding_seed, 32);
+        std::memcpy(job.program_hash, meta_.program_hash, 32);
+        job.generated_at = meta_.generated_at;
+        std::strncpy(job.version, meta_.version.c_str(), sizeof job.version - 1);
+        job.public_args = args.empty() ? nullptr : args.data();
+        job.public_arg_lens = lens.empty() ? nullptr : lens.data();
+        job.n_public_args = lens.size();
+        check(lig_rows_begin(ctx_, &job, &trace_), "lig_rows_begin");
+        check(lig_rows_commit(trace_, root, stage1_seed), "lig_rows_commit");
+        rows_.clear(); rows_.shrink_to_fit();            // the message rows are resident on the device now
+        rands_.assign(kinds_.size() * (size_t)k_ * 4, 0);
+        pass_ = 2; next_ = 0;
+    }
+
+    // ---- end of pass 2: stages 2 + 3 on the GPU.  const_sum = the public constant of the linear test, 32 bytes little
+    // endian (linear_sums(), src/webgpu_prover.cpp:307).  The returned bytes are the serialized LigeroProofEnvelope
+    // (owned by the batcher, valid until it is destroyed); `info` (optional) receives the prover's self-check.
+    const uint8_t* prove(const uint8_t const_sum[32], size_t* proof_len, lig_proof_info* info = nullptr) {
+        if (pass_ != 2) throw std::logic_error("hip_row_batcher::prove before commit");
+        if (next_ != kinds_.size()) throw std::logic_error("hip_row_batcher::prove: pass 2 replayed " + std::to_string(next_) + " of " + std::to_string(kinds_.size()) + " rows");
+        const uint8_t* proof = nullptr;
+        lig_proof_info local;
+        check(lig_rows_prove(trace_, rands_.data(), 0, const_sum, &proof, proof_len, info ? info : &local), "lig_rows_prove");
+        pass_ = 3;
+        return proof;
+    }
+    size_t rows() const { return kinds_.size(); }
+
+private:
+    void check(int rc, const char* what) const {
+        if (rc != LIG_OK) throw std::runtime_error(std::string(what) + ": " + lig_last_error(ctx_));
+    }
+    void row(uint8_t kind, const uint64_t* val, const uint64_t* rand) {
+        const size_t words = (size_t)k_ * 4;
+        if (pass_ == 1) {
+            if (!val) throw std::invalid_argument("hip_row_batcher: null row");
+            kinds_.push_back(kind);
+            rows_.insert(rows_.end(), val, val + words);
+        } else if (pass_ == 2) {
+            // the guest is deterministic: pass 2 must replay the callbacks of pass 1 in the same order
+            if (next_ >= kinds_.size() || kinds_[next_] != kind) throw std::logic_error("hip_row_batcher: pass 2 diverges from pass 1");
+            if (rand) std::memcpy(rands_.data() + next_ * words, rand, words * 8);
+            next_++;
+        } else throw std::logic_error("hip_row_batcher: callback after prove");
+    }
+    void dev_row(uint8_t kind, const void* dev) {
+        if (pass_ == 1) {
+            std::vector<uint64_t> host((size_t)k_ * 4);
+            check(lig_read(ctx_, host.data(), dev, host.size() * 8), "lig_read(batch row)");
+            row(kind, host.data(), nullptr);
+        } else row(kind, nullptr, nullptr);
+    }
+
+    lig_ctx* ctx_;
+    hip_proof_meta meta_;
+    uint32_t k_;
+    int pass_ = 1;
+    size_t next_ = 0;
+    std::vector<uint8_t> kinds_;
+    std::vector<uint64_t> rows_, rands_;
+    lig_trace* trace_ = nullptr;
+};
+
+}  // namespace ligero

@@ -143,16 +143,16 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
             S->triple_ord.push_back(i);
         }
     }
-    const size_t chunk = S->ch_cap, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
+    const size_t chunk = S->ch_cap;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&S->msgs, (Rl ? Rl : 1) * (size_t)k * 32));
     TRY(dm((void**)&S->cw, (Rl + 3) * (size_t)n * 32));
     TRY(dm((void**)&S->send, 2 * chunk * (size_t)n * 32));          // double-buffered: W blocks of chunk x ncol each
     TRY(dm((void**)&S->recv, 2 * chunk * (size_t)n * 32));
-    TRY(dm((void**)&S->randb, chunk * (size_t)k * 32));
+    TRY(dm((void**)&S->randb, 2 * chunk * (size_t)k * 32));         // double-buffered
     TRY(dm((void**)&S->rhalf, chunk * 2 * (size_t)k * 32));
     TRY(dm((void**)&S->acc, 4 * (size_t)n * 32));
-    TRY(dm((void**)&S->parts, 2 * groups * (size_t)n * 32));
+    TRY(dm((void**)&S->parts, 3 * ((chunk + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4)) * (size_t)k * 32));
     TRY(dm((void**)&S->accp, 5 * (size_t)k * 32));
     TRY(dm((void**)&S->accg, (size_t)world * 5 * k * 32));
     TRY(dm((void**)&S->dots, 32));
@@ -353,25 +353,44 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     fr* code = S->acc; fr* lin = S->acc + n; fr* quad = S->acc + 2 * (size_t)n; fr* tmp = S->acc + 3 * (size_t)n;
     fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
     HIP_TRY(c, hipMemsetAsync(S->acc, 0, 4 * (size_t)n * 32, s));
-    const size_t groups = (CAP + lig_tune::GROUP - 1) / lig_tune::GROUP;
-    for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+    // as in lig_synth_prove: the randomness rows of chunk c+1 are sampled on the side stream (dense rows, double-buffered)
+    // while the main stream encodes / accumulates chunk c; group partials persist across chunks, one combine per accumulator
+    const uint32_t pg = (uint32_t)((CAP + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4));
+    fr* p_code = S->parts; fr* p_linH = S->parts + (size_t)pg * k; fr* p_linC = S->parts + 2 * (size_t)pg * k;
+    HIP_TRY(c, hipMemsetAsync(S->parts, 0, 3 * (size_t)pg * k * 32, s));
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key + memsets above
+    HIP_TRY(c, hipStreamWaitEvent(s_hash, c->ev_fork, 0));
+    auto form_rand_chunk = [&](size_t cidx) -> int {           // on the side stream
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
-        if (!nb) continue;
-        HIP_TRY(c, hipMemsetAsync(S->randb, 0, nb * (size_t)k * 32, s));
+        fr* rb = S->randb + (cidx & 1) * CAP * (size_t)k;
+        if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s_hash, S->ev_comm[cidx & 1], 0));        // buffer consumed (event reused: stage 1 is over)
         for (size_t r = 0; r < nb;) {          // a chunk is a run of consecutive global rows: runs of equal fill are contiguous in the linear stream
             size_t run = 1;
             const size_t gr = S->grow[lb + r];
             const uint32_t d = S->rows[gr].data;
             while (r + run < nb && S->rows[gr + run].data == d) run++;
-            lig::launch_rng_fill_rows(s, c->rk_dev, S->lin_pos[gr], S->randb + r * k, run, d, k, 0, 1, d);
+            lig::launch_rng_fill_rows_dense(s_hash, c->rk_dev, S->lin_pos[gr], rb + r * k, run, d, k);
             r += run;
         }
-        TRY(lig_internal_encode_rows(c, S->randb, S->rhalf, nb, true));
-        lig::launch_rlc_rows29(s, S->cw + lb * (size_t)n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, linC, S->parts,
-                               S->parts + groups * (size_t)n, lig_tune::GROUP / 4);
-        lig::launch_rlc_rows29(s, S->msgs + lb * (size_t)k, k, 1, S->randb, k, nb, k, S->coef_dev + lb, tmp, linH, S->parts,
-                               S->parts + groups * (size_t)n, lig_tune::GROUP / 4);
+        HIP_TRY(c, hipEventRecord(S->ev_enc[cidx & 1], s_hash));
+        return LIG_OK;
+    };
+    if (S->rounds) TRY(form_rand_chunk(0));
+    for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+        const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
+        fr* rb = S->randb + (cidx & 1) * CAP * (size_t)k;
+        if (cidx + 1 < S->rounds) TRY(form_rand_chunk(cidx + 1));
+        HIP_TRY(c, hipStreamWaitEvent(s, S->ev_enc[cidx & 1], 0));
+        if (nb) {
+            TRY(lig_internal_encode_rows(c, rb, S->rhalf, nb, true));
+            lig::launch_rlc_accumulate29(s, S->cw + lb * (size_t)n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);
+            lig::launch_rlc_accumulate29(s, S->msgs + lb * (size_t)k, k, 1, rb, k, nb, k, S->coef_dev + lb, p_code, p_linH, lig_tune::GROUP / 4);
+        }
+        HIP_TRY(c, hipEventRecord(S->ev_comm[cidx & 1], s));
     }
+    lig::launch_rlc_combine(s, tmp, p_code, pg, k);
+    lig::launch_rlc_combine(s, linH, p_linH, pg, k);
+    lig::launch_rlc_combine(s, linC, p_linC, pg, k);
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
     // partial sums [code (k message values) | lin (2k) | quad (2k)] -> every rank -> added mod p

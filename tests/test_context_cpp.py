@@ -72,3 +72,31 @@ def test_hip_context_powmod_like_reference_fixture():
         i = int(parts[0])
         got = int("".join(parts[1:]), 16)
         assert got == 2 * pow(7, i, ol.P) % ol.P
+
+
+BSRC = os.path.join(ROOT, "tests", "cpp", "row_batcher_prog.cpp")
+BEXE = os.path.join(ROOT, "tests", "cpp", "row_batcher_prog")
+
+
+def build_batcher_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    odir = os.path.join(ROOT, "oracle")
+    ol.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", BSRC, "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip", "-L" + odir, "-llig_oracle",
+                           "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-Wl,-rpath," + odir, "-o", BEXE])
+    return BEXE
+
+
+def test_row_batcher_shim_compiles_and_links():
+    assert os.path.exists(build_batcher_exe())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l,k,n,n_lin,n_quad", [(320, 512, 2048, 2000, 700), (320, 512, 2048, 320 * 530 + 1, 0), (8000, 8192, 32768, 20000, 8001)])
+def test_row_batcher_shim_gives_the_oracle_envelope(l, k, n, n_lin, n_quad):
+    """include/lig_hip_row_batcher.hpp driven like the reference's stage contexts (two passes of per-row callbacks) produces
+    the envelope of the oracle's reference-structured prover, public arguments included"""
+    out = subprocess.check_output([build_batcher_exe(), str(l), str(k), str(n), str(n_lin), str(n_quad)]).decode()
+    assert out.startswith("equal 1 "), out
