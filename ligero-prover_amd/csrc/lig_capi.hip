@@ -352,7 +352,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {
             const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->prof_on && !half) {      // only the full (3 computed cosets) launches of the dominant kernel are bracketed
+            if (c->prof_on && !half && nr > 1) {      // only the full (3 computed cosets) multi-row launches of the dominant kernel are bracketed
                 if (c->prof_used == c->prof_events.size()) {
                     hipEvent_t a, b;
                     HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
