@@ -61,7 +61,8 @@ __global__ void k_eltwise(const fr* __restrict__ x, const fr* __restrict__ y, fr
 // replaced by one), inverts the product once by Fermat (253 squarings + 109 products) and unwinds: 5M + 362 products per
 // thread instead of 363 per element.
 template <int M>
-__global__ void __launch_bounds__(256) k_div_batched(const fr* __restrict__ x, const fr* __restrict__ y, fr* __restrict__ out, size_t count) {
+// (no __restrict__: the ABI lets x, y and out alias, and the unwind loop reads y[i] again right before it stores out[i])
+__global__ void __launch_bounds__(256) k_div_batched(const fr* x, const fr* y, fr* out, size_t count) {
     const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const f29 r2 = f29_const_r2();
     f29 one_m = f29_zero();

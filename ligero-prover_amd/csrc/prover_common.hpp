@@ -234,7 +234,14 @@ bool plan_rows(const lig_synth_job& job, uint32_t l, std::vector<RowDesc>& rows,
                               (o.op == LIG_BOP_SET_SCALAR || (o.op >= LIG_BOP_ADD_CONST && o.op <= LIG_BOP_MONTMUL_CONST)) ? 32 : 0;
         if (need && (!job.batch_data || o.data_off > job.batch_data_bytes || need > job.batch_data_bytes - o.data_off)) return false;
         if (o.op == LIG_BOP_SET && o.len > l) return false;
-        if (o.op == LIG_BOP_BIT_DECOMPOSE && o.len > 256) return false;
+        if (o.op == LIG_BOP_BIT_DECOMPOSE) {
+            if (o.len > 256) return false;
+            for (uint32_t b = 0; b < o.len; b++) {           // every output slot inside the slab and different from the source
+                uint32_t slot;
+                std::memcpy(&slot, job.batch_data + o.data_off + 4ull * b, 4);
+                if (slot >= 512 || slot == o.x) return false;
+            }
+        }
         switch (o.op) {
             case LIG_BOP_SET: case LIG_BOP_SET_SCALAR: rows.push_back({RK_INIT, 0}); n_init++; break;
             case LIG_BOP_COPY: case LIG_BOP_ASSERT_EQUAL: rows.push_back({RK_EQX, 0}); rows.push_back({RK_EQY, 0}); break;

@@ -51,7 +51,10 @@ static long batch_plan(const lo_job *j, rowdesc *d) {
                               (o->op == LO_BOP_SET_SCALAR || (o->op >= LO_BOP_ADD_CONST && o->op <= LO_BOP_MONTMUL_CONST)) ? 32 : 0;
         if (need && (o->data_off > j->batch_data_bytes || need > j->batch_data_bytes - o->data_off)) return -1;
         if (o->op == LO_BOP_SET && o->len > j->l) return -1;
-        if (o->op == LO_BOP_BIT_DECOMPOSE && o->len > 256) return -1;
+        if (o->op == LO_BOP_BIT_DECOMPOSE) {
+            if (o->len > 256) return -1;
+            for (uint32_t b = 0; b < o->len; b++) { uint32_t slot; memcpy(&slot, j->batch_data + o->data_off + 4ull * b, 4); if (slot >= 512 || slot == o->x) return -1; }
+        }
         switch (o->op) {
         case LO_BOP_SET: case LO_BOP_SET_SCALAR: if (d) d[r] = (rowdesc){RK_INIT, 0}; r += 1; break;
         case LO_BOP_COPY: case LO_BOP_ASSERT_EQUAL: if (d) { d[r] = (rowdesc){RK_EQX, 0}; d[r + 1] = (rowdesc){RK_EQY, 0}; } r += 2; break;

@@ -102,6 +102,13 @@ def test_oracle_rejects_malformed_program():
     p.attach(job)
     pr = ol.Proof()
     assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) != 0
+    for outs, src in (([3, 512], 1), ([3, 1, 4], 1)):        # bit-decompose output slot outside the slab / equal to the source
+        job = ol.make_job(L_, K_, N_, 192, 10, 0)
+        p = batch_prog.Program()
+        p.set(1, [5])
+        p.bit_decompose(outs, src)
+        p.attach(job)
+        assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) != 0
 
 
 # ------------------------------------------------------------------------------------------------ HIP prover / verifier
@@ -165,6 +172,12 @@ def test_hip_false_equality_fails_quadratic_test_and_bad_program_is_rejected(amd
         bad.set(600, [1])
         with pytest.raises(Exception):
             c.synth_prepare_job(bad.attach(amd.Context.make_job(10, 0)))
+        for outs in ([3, 512], [3, 1, 4]):                   # bit-decompose output slot outside the slab / equal to the source
+            bad = batch_prog.Program()
+            bad.set(1, [5])
+            bad.bit_decompose(outs, 1)
+            with pytest.raises(Exception):
+                c.synth_prepare_job(bad.attach(amd.Context.make_job(10, 0)))
     finally:
         ol.lib().lo_proof_free(C.byref(pr))
         c.close()
