@@ -51,9 +51,10 @@ void ntt_generic_fold(hipStream_t s, fr* buf, uint32_t half, size_t rows, size_t
 bool encode_fast_supported(uint32_t k);
 // ev0/ev1 (optional): HIP events recorded on `s` immediately before/after the dominant kernel (encode_mid)
 // half: produce only the k values on the coset w_n^2 <w_n^4> (out[q] = P(w_n^(4q + 2)), rows x k) instead of the codeword;
-// msgs must not overlap out (K3 copies coset 0 of the codeword from the message row)
+// msgs must not overlap out (K3 copies coset 0 of the codeword from the message row); coset2 (optional, full encodes only):
+// rows x k compact copy of the codeword elements 4q + 2
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y,
-                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, bool half = false);
+                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, bool half = false, fr* coset2 = nullptr);
 
 // ---- eltwise.hip
 void launch_eltwise(hipStream_t s, int op, const fr* x, const fr* y, fr* out, size_t count, fr scalar, uint32_t bit);

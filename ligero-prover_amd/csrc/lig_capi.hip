@@ -340,7 +340,7 @@ int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ens
 // shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
 // codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
 // (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on) {
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on, void* coset2) {
     const size_t out_stride = half ? (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
     if (c->fast) {
@@ -362,7 +362,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                 c->prof_used++; c->prof_rows += nr;
             }
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
-                                  c->scratch_z, nr, e0, e1, half);
+                                  c->scratch_z, nr, e0, e1, half, coset2 ? (fr*)coset2 + r0 * c->k : nullptr);
         }
     } else if (!half) {
         // generic path: copy + zero-pad each row, INTT_k, then NTT_n with the radix-2 kernels
@@ -371,6 +371,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                                     rows, hipMemcpyDeviceToDevice, st));
         lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], (fr*)out, rows, out_stride);
         lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
+        if (coset2) HIP_TRY(c, hipMemcpy2DAsync(coset2, sizeof(fr), (const fr*)out + 2, 4 * sizeof(fr), sizeof(fr), rows * (size_t)c->k, hipMemcpyDeviceToDevice, st));
     } else {
         // generic path, half: NTT_2k on <w_n^2> into the Z scratch (2k per row), then keep the odd points
         const size_t k2 = 2 * (size_t)c->k, chunk = 64;

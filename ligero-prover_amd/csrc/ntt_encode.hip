@@ -120,7 +120,7 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __res
 // !FULL: out row = k elements, element q = q2 + B*q1 is P(w_n^(4q + 2)).
 template <int LOG2B, bool FULL>
 __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8,
-                                                    const fr* __restrict__ msgs, size_t rows) {
+                                                    const fr* __restrict__ msgs, size_t rows, fr* __restrict__ coset2) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     constexpr int LOGNC = FULL ? 2 : 0;
     constexpr uint32_t NC = FULL ? 3 : 1, OS = FULL ? 4 : 1;
@@ -148,13 +148,20 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
     }
 #pragma unroll
     for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, v[q1]);
+    // optional compact copy of coset 2 (the odd points of <w_n^2>): the stage-2 linear test reads it k-contiguous instead of
+    // fetching every fourth element of the codeword (4x the bytes it uses)
+    if (FULL && coset2 != nullptr && r == 2) {
+        fr* c2 = coset2 + row * (size_t)K;
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) fr_store(c2 + q2 + (size_t)B * q1, v[q1]);
+    }
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 1024 || k == 2048 || k == 4096 || k == 8192; }
 
 template <int LOG2B, bool FULL>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
-                          hipEvent_t ev0, hipEvent_t ev1) {
+                          hipEvent_t ev0, hipEvent_t ev1, fr* coset2) {
     constexpr uint32_t B = 1u << LOG2B;
     fr* Cc = Y + rows * (size_t)(8 * B);      // second half of the Y scratch (2 * rows * k elements)
     const size_t th1 = rows * B;
@@ -165,23 +172,23 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     if (kmask & 4) hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
     if (ev1) (void)hipEventRecord(ev1, s);
     const size_t th3 = rows * B * (FULL ? 4 : 1);
-    if (kmask & 8) hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    if (kmask & 8) hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
 }
 
 // half = false: codewords (rows x n).  half = true: rows x k values on the coset w_n^2 <w_n^4>, out[q] = P(w_n^(4q + 2)).
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
-                      hipEvent_t ev0, hipEvent_t ev1, bool half) {
+                      hipEvent_t ev0, hipEvent_t ev1, bool half, fr* coset2) {
     switch (ep.log2B * 2 + (half ? 1 : 0)) {
-        case 12: encode_rows_t<6, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 13: encode_rows_t<6, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 14: encode_rows_t<7, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 15: encode_rows_t<7, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 18: encode_rows_t<9, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 19: encode_rows_t<9, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 16: encode_rows_t<8, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 17: encode_rows_t<8, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 20: encode_rows_t<10, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
-        case 21: encode_rows_t<10, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1); break;
+        case 12: encode_rows_t<6, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 13: encode_rows_t<6, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 14: encode_rows_t<7, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 15: encode_rows_t<7, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 18: encode_rows_t<9, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 19: encode_rows_t<9, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 16: encode_rows_t<8, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 17: encode_rows_t<8, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 20: encode_rows_t<10, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+        case 21: encode_rows_t<10, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
         default: break;
     }
 }

@@ -38,6 +38,7 @@ struct lig_trace {
     size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
     fr* cw = nullptr;                   // (R+3) x n codewords, resident across the stages
+    fr* c2 = nullptr;                   // R x k compact copy of codeword coset 2 (elements 4q + 2): the stage-2 linear test reads it
     fr* randb = nullptr;                // chunk x k randomness rows
     fr* rcw = nullptr;                  // chunk x n their codewords
     fr* acc = nullptr;                  // code | lin | quad | tmp   (4 x n)
@@ -176,6 +177,7 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
     TRY(dm((void**)&T->cw, (R + 3) * (size_t)n * 32));
+    TRY(dm((void**)&T->c2, (R ? R : 1) * (size_t)k * 32));
     TRY(dm((void**)&T->randb, 2 * chunk * (size_t)k * 32));          // double-buffered
     TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
     TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
@@ -271,7 +273,7 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
                 lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
             }
         }
-        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc));
+        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc, T->c2 + b * (size_t)k));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
         static const int gate = [] { const char* e = std::getenv("LIG_SHA_GATE"); return e ? std::atoi(e) : 1; }();
@@ -398,7 +400,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        lig::launch_rlc_accumulate29(s, T->cw + b * n + 2, n, 4, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);
+        lig::launch_rlc_accumulate29(s, T->c2 + b * (size_t)k, k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);
         lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
@@ -564,7 +566,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream2);
     (void)hipStreamSynchronize(T->c->stream3);
     T->c->sha.erase(T->sha_state);
-    for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
+    for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->c2, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);
