@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblig_hip.so")
+LIB_PATH = os.environ.get("LIG_HIP_LIB") or os.path.join(_HERE, "liblig_hip.so")      # LIG_HIP_LIB: A/B builds of experiments
 
 OPS = dict(ADD=0, SUB=1, ADD_ASSIGN=2, ADD_CONST=3, SUB_CONST=4, CONST_SUB=5, MUL=6, MUL_CONST=7,
            MONTMUL_CONST=8, FMA=9, FMA_CONST=10, DIV=11, BIT_DECOMPOSE=12)

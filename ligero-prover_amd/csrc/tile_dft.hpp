@@ -75,6 +75,33 @@ __device__ __forceinline__ void tile_sync() {
     else __syncthreads();
 }
 
+// EXPERIMENT (-DLIG_TILE_DPP, not the default; result in profiles/r02_dpp_exchange_ab.md): the first exchange of a tile
+// transform (after spans 2 and 4: thread t holds positions 4t + q and needs 16(t/4) + (t%4) + 4q) is a 4x4 transpose inside
+// a quad of adjacent lanes, done in registers with DPP quad_perm moves instead of through LDS: two butterfly rounds
+// (lane^1, lane^2), per dword one select of what to send, one v_mov_dpp, two selects to place it.
+#ifdef LIG_TILE_DPP
+__device__ __forceinline__ void quad_transpose(f29 (&x)[4], const uint32_t lane) {
+    const bool odd = lane & 1u, hi = lane & 2u;
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+#pragma unroll
+        for (int a = 0; a < 4; a += 2) {                  // pairs (0,1), (2,3) against lane ^ 1
+            const uint32_t send = odd ? x[a].v[w] : x[a + 1].v[w];
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+            x[a].v[w] = odd ? recv : x[a].v[w];
+            x[a + 1].v[w] = odd ? x[a + 1].v[w] : recv;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++) {                      // pairs (0,2), (1,3) against lane ^ 2
+            const uint32_t send = hi ? x[a].v[w] : x[a + 2].v[w];
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+            x[a].v[w] = hi ? recv : x[a].v[w];
+            x[a + 2].v[w] = hi ? x[a + 2].v[w] : recv;
+        }
+    }
+}
+#endif
+
 // One radix-2^2 DIT step (spans M/2 and M, M = 4^(S+1)) of the size-B transform.  Thread t owns positions
 // base + q*Q (Q = M/4).  tw: the stage of span M' starts at entry M'/2 - 1 (M'/2 entries rho^(j*B/M')).
 template <int LOG2B, int S>
@@ -83,7 +110,11 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
     constexpr uint32_t M = 4u << (2 * S), Q = M >> 2;
     const uint32_t p = t & (Q - 1);
     const uint32_t base = (t / Q) * M + p;
+#ifdef LIG_TILE_DPP
+    if constexpr (S > 1) {
+#else
     if constexpr (S > 0) {
+#endif
 #pragma unroll
         for (int q = 0; q < 4; q++) x[q] = lds_get(L, base + q * Q);
     }
@@ -108,6 +139,15 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
         u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 2.5*2^30 + 8
     }
     if constexpr (S + 1 < STEPS) {
+#ifdef LIG_TILE_DPP
+        if constexpr (S == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = f29_qnorm(x[q]);
+            quad_transpose(x, t);
+            tile_step<LOG2B, S + 1>(x, tw, L, t);
+            return;
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
         tile_sync<4 * M, (1u << LOG2B) / 4>();

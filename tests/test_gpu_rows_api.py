@@ -215,11 +215,13 @@ def test_full_size_600_rows_against_oracle_on_host_cores(amd):
     assert proof == want["proof"]
 
 
-def test_configs2_full_size_proof_equals_oracle_pin(amd):
-    """the exact bench.py job (2^24 linear constraints, k = 8192, synthetic seed 1, encoding seed 0..31, generated_at 0):
-    the envelope's SHA-256, root, seeds and constant equal tests/golden/full_pin_2p24.json, which the oracle's
-    reference-structured prover produced (tests/golden/make_full_pin.py)"""
-    with open(os.path.join(GOLD, "full_pin_2p24.json")) as f:
+@pytest.mark.parametrize("lg", [24, 26])
+def test_full_size_proof_equals_oracle_pin(amd, lg):
+    """the exact bench.py jobs -- configs[2]: 2^24 linear constraints, and the configs[3] trace of 2^26 constraints on one
+    GPU (k = 8192, synthetic seed 1, encoding seed 0..31, generated_at 0): the envelope's SHA-256, root, seeds, constant and
+    sample indices equal tests/golden/full_pin_2p<lg>.json, which the oracle's reference-structured prover produced
+    (tests/golden/make_full_pin.py: 68 s / 277 s on the build container's cores)"""
+    with open(os.path.join(GOLD, "full_pin_2p%d.json" % lg)) as f:
         pin = json.load(f)
     c = amd.Context(pin["l"], pin["k"], pin["n"])
     try:
