@@ -129,3 +129,42 @@ def test_rccl_stream_ordered_collectives_one_rank(tmp_path):
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])     # RCCL prints its own lines
     assert out == {"equal": True, "valid": [1, 1, 1]}
+
+
+BIG_WORKER = textwrap.dedent('''
+    import hashlib, importlib.util, json, os, sys
+    root, lg = sys.argv[1], int(sys.argv[2])
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
+        m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+    import torch
+    torch.cuda.set_device(0)
+    pkg = load("ligero_prover_amd", "__init__.py")
+    dist = load("lig_dist", "dist.py")
+    g = dist.Group("nccl", force_init=True)
+    ctx = pkg.Context(8000, 8192, 32768, device=0)
+    job = pkg.Context.make_job(1 << lg, 0, synth_seed=1, generated_at=0)
+    sh = ctx.shard_prepare(job, g.rank, g.world, g.make_comm(pkg, ctx))
+    proof, info = ctx.shard_prove(sh)
+    ctx.shard_destroy(sh)
+    print(json.dumps({"sha": hashlib.sha256(proof).hexdigest(), "root": bytes(info.root).hex(), "rows": info.rows,
+                      "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
+    g.close(); ctx.close()
+''')
+
+
+def test_sharded_configs3_trace_full_size_equals_oracle_pin(tmp_path):
+    """configs[3]'s 2^26-constraint trace through the sharded prover with the exchange pipeline ON (1-rank RCCL
+    communicator, LIG_SHARD_FORCE_EXCHANGE: 17 rounds of pack -> grouped send/recv -> column hash, double-buffered) at
+    full size: envelope SHA-256 and root equal the oracle's pin (tests/golden/full_pin_2p26.json)"""
+    with open(os.path.join(ROOT, "tests", "golden", "full_pin_2p26.json")) as f:
+        pin = json.load(f)
+    script = tmp_path / "big_worker.py"
+    script.write_text(BIG_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29771", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               LIG_SHARD_FORCE_EXCHANGE="1")
+    p = subprocess.run([sys.executable, str(script), ROOT, "26"], env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
+    assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
