@@ -64,113 +64,121 @@ __device__ __forceinline__ uint32_t x3(uint32_t a, uint32_t b, uint32_t c) { ret
 
 // te = the four tables back to back (LDS).  Te0[x] = (2s, s, s, 3s) from the most significant byte down, so the plain
 // S-box byte sits in bits 24-31 of Te2, 16-23 of Te3, 8-15 of Te0 and 0-7 of Te1: the last round needs no S-box table.
-__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const uint32_t* te, uint64_t block_index, uint32_t out[4]) {
-    const uint32_t *t0 = te, *t1 = te + 256, *t2 = te + 512, *t3 = te + 768;
+//
+// LDS layout (LOGR): every table word is replicated R = 2^LOGR times, word (t, i, r) at index ((t*256 + i) << LOGR) + r,
+// and lane l reads replica r = l mod R.  The 16 lookups per round are random: with one copy (LOGR = 0) the 32 lanes of a
+// half-wave spread over the 32 banks with a maximum load of ~3.5, and the sampler is bound by exactly that (measured:
+// 13.8k SIMD-cycles per wave of 64 elements, 448 lookups each).  With R = 16 the bank of a lookup is 16*(i mod 2) + r: only
+// the two lanes of a half-wave that share a replica can collide (probability 1/2 when their bytes differ) -- ~1.25 cycles
+// per half-wave instead of ~3.5.  64 KiB of LDS per workgroup, so the big fills run as <= 2 persistent workgroups per CU;
+// the round keys are read through scalar loads (uniform addresses), not from LDS.
+template <int LOGR>
+__device__ __forceinline__ uint32_t te_at(const uint32_t* tl, uint32_t table, uint32_t word, int shift) {
+    // byte `shift/8` of `word` -> table index scaled by R
+    const uint32_t idx = shift == 24 ? (word >> 24) : ((word >> shift) & 255u);
+    return tl[((table << 8) + idx) << LOGR];
+}
+template <int LOGR>
+__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const uint32_t* tl, uint64_t block_index, uint32_t out[4]) {
     uint32_t s0 = rk[0], s1 = rk[1], s2 = (uint32_t)(block_index >> 32) ^ rk[2], s3 = (uint32_t)block_index ^ rk[3];
+#define T_(t, w, sh) te_at<LOGR>(tl, t, w, sh)
 #pragma unroll
     for (int r = 1; r < 14; r++) {
-        const uint32_t a0 = x3(t0[s0 >> 24], t1[(s1 >> 16) & 255], t2[(s2 >> 8) & 255]), a1 = x3(t0[s1 >> 24], t1[(s2 >> 16) & 255], t2[(s3 >> 8) & 255]);
-        const uint32_t a2 = x3(t0[s2 >> 24], t1[(s3 >> 16) & 255], t2[(s0 >> 8) & 255]), a3 = x3(t0[s3 >> 24], t1[(s0 >> 16) & 255], t2[(s1 >> 8) & 255]);
-        const uint32_t b0 = x3(a0, t3[s3 & 255], rk[4 * r]), b1 = x3(a1, t3[s0 & 255], rk[4 * r + 1]);
-        const uint32_t b2 = x3(a2, t3[s1 & 255], rk[4 * r + 2]), b3 = x3(a3, t3[s2 & 255], rk[4 * r + 3]);
+        const uint32_t a0 = x3(T_(0, s0, 24), T_(1, s1, 16), T_(2, s2, 8)), a1 = x3(T_(0, s1, 24), T_(1, s2, 16), T_(2, s3, 8));
+        const uint32_t a2 = x3(T_(0, s2, 24), T_(1, s3, 16), T_(2, s0, 8)), a3 = x3(T_(0, s3, 24), T_(1, s0, 16), T_(2, s1, 8));
+        const uint32_t b0 = x3(a0, T_(3, s3, 0), rk[4 * r]), b1 = x3(a1, T_(3, s0, 0), rk[4 * r + 1]);
+        const uint32_t b2 = x3(a2, T_(3, s1, 0), rk[4 * r + 2]), b3 = x3(a3, T_(3, s2, 0), rk[4 * r + 3]);
         s0 = b0; s1 = b1; s2 = b2; s3 = b3;
     }
-    out[0] = x3(t2[s0 >> 24] & 0xff000000u, t3[(s1 >> 16) & 255] & 0x00ff0000u, t0[(s2 >> 8) & 255] & 0x0000ff00u) ^ (t1[s3 & 255] & 0xffu) ^ rk[56];
-    out[1] = x3(t2[s1 >> 24] & 0xff000000u, t3[(s2 >> 16) & 255] & 0x00ff0000u, t0[(s3 >> 8) & 255] & 0x0000ff00u) ^ (t1[s0 & 255] & 0xffu) ^ rk[57];
-    out[2] = x3(t2[s2 >> 24] & 0xff000000u, t3[(s3 >> 16) & 255] & 0x00ff0000u, t0[(s0 >> 8) & 255] & 0x0000ff00u) ^ (t1[s1 & 255] & 0xffu) ^ rk[58];
-    out[3] = x3(t2[s3 >> 24] & 0xff000000u, t3[(s0 >> 16) & 255] & 0x00ff0000u, t0[(s1 >> 8) & 255] & 0x0000ff00u) ^ (t1[s2 & 255] & 0xffu) ^ rk[59];
+    out[0] = x3(T_(2, s0, 24) & 0xff000000u, T_(3, s1, 16) & 0x00ff0000u, T_(0, s2, 8) & 0x0000ff00u) ^ (T_(1, s3, 0) & 0xffu) ^ rk[56];
+    out[1] = x3(T_(2, s1, 24) & 0xff000000u, T_(3, s2, 16) & 0x00ff0000u, T_(0, s3, 8) & 0x0000ff00u) ^ (T_(1, s0, 0) & 0xffu) ^ rk[57];
+    out[2] = x3(T_(2, s2, 24) & 0xff000000u, T_(3, s3, 16) & 0x00ff0000u, T_(0, s0, 8) & 0x0000ff00u) ^ (T_(1, s1, 0) & 0xffu) ^ rk[58];
+    out[3] = x3(T_(2, s3, 24) & 0xff000000u, T_(3, s0, 16) & 0x00ff0000u, T_(0, s1, 8) & 0x0000ff00u) ^ (T_(1, s2, 0) & 0xffu) ^ rk[59];
+#undef T_
+}
+// stage the replicated tables; returns the calling lane's view (pointer to its replica of word (0, 0))
+template <int LOGR>
+__device__ __forceinline__ const uint32_t* te_stage(uint32_t* te) {
+    for (uint32_t i = threadIdx.x; i < (1024u << LOGR); i += blockDim.x) te[i] = g_te[i >> LOGR];
+    __syncthreads();
+    return te + (threadIdx.x & ((1u << LOGR) - 1));
+}
+// keystream element -> field element (finite_field_gmp.hpp:66-78)
+template <int LOGR>
+__device__ __forceinline__ fr aes_field_elem(const uint32_t* __restrict__ rk, const uint32_t* tl, uint64_t elem) {
+    uint32_t o[8];
+    aes256_block<LOGR>(rk, tl, 2 * elem, o);
+    aes256_block<LOGR>(rk, tl, 2 * elem + 1, o + 4);
+    fr v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.v[i] = __builtin_bswap32(o[i]);   // keystream bytes -> little-endian limbs
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.v[i] = (v.v[i] >> 2) | (i < 7 ? (v.v[i + 1] << 30) : 0u);
+    return fr_reduce_once(v);   // v < 2^254 < 2p
 }
 
-__global__ void k_rng_fill(const uint32_t* __restrict__ rk_g, uint64_t first_elem, fr* __restrict__ out, size_t count) {
-    __shared__ uint32_t te[4 * 256];
-    __shared__ uint32_t rk[60];
-    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) te[i] = g_te[i];
-    if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
-    __syncthreads();
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
-        const uint64_t blk = 2 * (first_elem + e);
-        uint32_t o[8];
-        aes256_block(rk, te, blk, o);
-        aes256_block(rk, te, blk + 1, o + 4);
-        fr v;
-#pragma unroll
-        for (int i = 0; i < 8; i++) v.v[i] = __builtin_bswap32(o[i]);   // keystream bytes -> little-endian limbs
-#pragma unroll
-        for (int i = 0; i < 8; i++) v.v[i] = (v.v[i] >> 2) | (i < 7 ? (v.v[i + 1] << 30) : 0u);
-        fr_store(out + e, fr_reduce_once(v));   // v < 2^254 < 2p
-    }
+template <int LOGR>
+__global__ void __launch_bounds__(256) k_rng_fill(const uint32_t* __restrict__ rk, uint64_t first_elem, fr* __restrict__ out, size_t count) {
+    __shared__ uint32_t te[1024 << LOGR];
+    const uint32_t* tl = te_stage<LOGR>(te);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
+        fr_store(out + e, aes_field_elem<LOGR>(rk, tl, first_elem + e));
 }
 
 // Row-structured fill: out[r*row_stride + col_off + i*elem_stride] = stream element (first + r*stream_stride + i),
 // r < rows, i < per_row.  One launch forms the k-l pad columns of a whole row batch, a dense randomness row
 // batch, or the (0, r, 0, r, ...) pattern of a mask row (elem_stride = 2).
-__global__ void k_rng_fill_rows(const uint32_t* __restrict__ rk_g, uint64_t first, fr* __restrict__ out, size_t rows,
-                                uint32_t per_row, size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
-    __shared__ uint32_t te[4 * 256];
-    __shared__ uint32_t rk[60];
-    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) te[i] = g_te[i];
-    if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
-    __syncthreads();
+template <int LOGR>
+__global__ void __launch_bounds__(256) k_rng_fill_rows(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ out, size_t rows,
+                                                       uint32_t per_row, size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
+    __shared__ uint32_t te[1024 << LOGR];
+    const uint32_t* tl = te_stage<LOGR>(te);
     const size_t total = rows * per_row;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / per_row;
         const uint32_t i = (uint32_t)(e - r * per_row);
-        const uint64_t blk = 2 * (first + r * stream_stride + i);
-        uint32_t o[8];
-        aes256_block(rk, te, blk, o);
-        aes256_block(rk, te, blk + 1, o + 4);
-        fr v;
-#pragma unroll
-        for (int w = 0; w < 8; w++) v.v[w] = __builtin_bswap32(o[w]);
-#pragma unroll
-        for (int w = 0; w < 8; w++) v.v[w] = (v.v[w] >> 2) | (w < 7 ? (v.v[w + 1] << 30) : 0u);
-        fr_store(out + r * row_stride + col_off + (size_t)i * elem_stride, fr_reduce_once(v));
+        fr_store(out + r * row_stride + col_off + (size_t)i * elem_stride, aes_field_elem<LOGR>(rk, tl, first + r * stream_stride + i));
     }
 }
 // Dense variant for whole randomness rows: row r of `out` (k elements) = per_row stream elements followed by zeros, so the
 // buffer needs no memset beforehand (the runtime's fill kernel reaches only ~1.4 TB/s).
-__global__ void k_rng_fill_rows_dense(const uint32_t* __restrict__ rk_g, uint64_t first, fr* __restrict__ out, size_t rows,
-                                      uint32_t per_row, uint32_t k) {
-    __shared__ uint32_t te[4 * 256];
-    __shared__ uint32_t rk[60];
-    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) te[i] = g_te[i];
-    if (threadIdx.x < 60) rk[threadIdx.x] = rk_g[threadIdx.x];
-    __syncthreads();
+template <int LOGR>
+__global__ void __launch_bounds__(256) k_rng_fill_rows_dense(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ out, size_t rows,
+                                                             uint32_t per_row, uint32_t k) {
+    __shared__ uint32_t te[1024 << LOGR];
+    const uint32_t* tl = te_stage<LOGR>(te);
     const size_t total = rows * k;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / k;
         const uint32_t i = (uint32_t)(e - r * k);
-        fr v = fr_zero();
-        if (i < per_row) {
-            const uint64_t blk = 2 * (first + r * (uint64_t)per_row + i);
-            uint32_t o[8];
-            aes256_block(rk, te, blk, o);
-            aes256_block(rk, te, blk + 1, o + 4);
-#pragma unroll
-            for (int w = 0; w < 8; w++) v.v[w] = __builtin_bswap32(o[w]);
-#pragma unroll
-            for (int w = 0; w < 8; w++) v.v[w] = (v.v[w] >> 2) | (w < 7 ? (v.v[w + 1] << 30) : 0u);
-            v = fr_reduce_once(v);
-        }
-        fr_store(out + e, v);
+        fr_store(out + e, i < per_row ? aes_field_elem<LOGR>(rk, tl, first + r * (uint64_t)per_row + i) : fr_zero());
     }
 }
+// launch shape: big fills = persistent workgroups (<= 2 per CU, 64 KiB of replicated tables each); small ones = one copy of
+// the tables (4 KiB), many workgroups
+static constexpr size_t BIG_FILL = (size_t)1 << 20;      // below this the 64 KiB table staging per workgroup does not pay
+#ifndef LIG_AES_REP
+#define LIG_AES_REP 4
+#endif
+static constexpr int REP = LIG_AES_REP;
+static constexpr uint32_t BIG_BLOCKS = 256u * (REP >= 4 ? 2u : REP == 3 ? 4u : 8u);     // persistent workgroups: as many as the LDS of 256 CUs holds
+static inline uint32_t small_blocks(size_t total, size_t cap) { size_t b = (total + 255) / 256; return (uint32_t)(b > cap ? cap : b); }
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k) {
     const size_t total = rows * k;
     if (!total) return;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_rng_fill_rows_dense, dim3((uint32_t)blocks), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
+    if (total >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill_rows_dense<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
+    else hipLaunchKernelGGL(k_rng_fill_rows_dense<0>, dim3(small_blocks(total, 8192)), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
 }
 
 void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,
                           size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
     const size_t total = rows * per_row;
     if (!total) return;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_rng_fill_rows, dim3((uint32_t)blocks), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride,
-                       col_off, elem_stride, stream_stride);
+    if (total >= BIG_FILL)
+        hipLaunchKernelGGL(k_rng_fill_rows<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride, col_off, elem_stride, stream_stride);
+    else
+        hipLaunchKernelGGL(k_rng_fill_rows<0>, dim3(small_blocks(total, 8192)), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride, col_off,
+                           elem_stride, stream_stride);
 }
 
 // per-device table upload, called from lig_ctx_create
@@ -184,9 +192,8 @@ void aes_upload_tables() {
 
 void launch_rng_fill(hipStream_t s, const uint32_t* rk60_dev, uint64_t first_elem, fr* out, size_t count) {
     if (!count) return;
-    size_t blocks = (count + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_rng_fill, dim3((uint32_t)blocks), dim3(256), 0, s, rk60_dev, first_elem, out, count);
+    if (count >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first_elem, out, count);
+    else hipLaunchKernelGGL(k_rng_fill<0>, dim3(small_blocks(count, 4096)), dim3(256), 0, s, rk60_dev, first_elem, out, count);
 }
 
 }  // namespace lig
