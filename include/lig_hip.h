@@ -260,6 +260,16 @@ int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, con
  * after lig_rows_commit, BEFORE lig_rows_prove of the committed trace: the new rows then go to a second message matrix
  * and arrive while the current trace is being proved (commit(i) -> restart(i+1) -> prove(i) -> commit(i+1) -> ...). */
 int lig_rows_restart(lig_trace *trace, const void *msgs, int msgs_on_device);
+/* The verifier's side of a rows job (src/webgpu_verifier.cpp:263-452 with the rows of nonbatch_verifier_context,
+ * include/zkp/nonbatch_context.hpp:1219-1287): begin parses the envelope, re-derives both seeds and the sample indices from the
+ * job's public data (kinds, public arguments; msgs is ignored) and returns the stage-1 seed; the caller's constraint generator
+ * produces the randomness rows and the linear constant from it; finish recommits the 192 opened columns, encodes the
+ * randomness rows, evaluates the seven predicates and frees the trace.  A malformed envelope is not an error: begin returns
+ * LIG_OK with out->accept = 0 (out->parsed / out->indices_match say why) and *trace = NULL. */
+typedef struct lig_vtrace lig_vtrace;
+int lig_rows_verify_begin(lig_ctx *ctx, const lig_rows_job *job, const uint8_t *proof, size_t proof_len, lig_vtrace **trace,
+                          uint8_t stage1_seed[32], lig_verify_info *out);
+int lig_rows_verify_finish(lig_vtrace *trace, const void *rands, int rands_on_device, const uint8_t const_sum[32], lig_verify_info *out);
 /* rows x k dense randomness rows on the device: row r = per_row[r] successive elements of the AES-256-CTR field stream
  * keyed by key32 (row r starts where row r-1 ended, the first at first_elem), zeros up to k -- the linear-test
  * coefficient rows of the synthetic stream, for callers that feed lig_rows_prove from the device. */

@@ -31,6 +31,7 @@ EXPORTS = [
     "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify",
     "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
     "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
+    "lig_rows_verify_begin", "lig_rows_verify_finish",
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy",
 ]
@@ -171,6 +172,8 @@ def load_library():
     L.lig_rows_begin.argtypes = [vp, C.POINTER(RowsJob), C.POINTER(vp)]
     L.lig_rows_commit.argtypes = [vp, vp, vp]
     L.lig_rows_restart.argtypes = [vp, vp, C.c_int]
+    L.lig_rows_verify_begin.argtypes = [vp, C.POINTER(RowsJob), vp, sz, C.POINTER(vp), vp, C.POINTER(VerifyInfo)]
+    L.lig_rows_verify_finish.argtypes = [vp, vp, C.c_int, vp, C.POINTER(VerifyInfo)]
     L.lig_rows_prove.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_rng_fill_rows.argtypes = [vp, vp, u64, vp, sz, vp]
     L.lig_public_arg_bytes.argtypes = [C.c_int, C.c_char_p, vp, sz, C.POINTER(sz)]
@@ -473,6 +476,29 @@ class Context:
         if not copy:
             return (C.addressof(proof.contents), ln.value), info
         return C.string_at(proof, ln.value), info
+
+    def rows_verify_begin(self, kinds, proof, public_args=None):
+        """-> (vtrace or None, stage1_seed bytes, VerifyInfo): the verifier's first half for a rows job (kinds + public data)"""
+        kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+        job = RowsJob()
+        job.rows = len(kinds)
+        job.kinds = kinds.ctypes.data if len(kinds) else None
+        job.set_public_args(public_args)
+        pb = np.frombuffer(bytes(proof), dtype=np.uint8).copy()
+        vt, seed, info = C.c_void_p(), np.zeros(32, dtype=np.uint8), VerifyInfo()
+        self.check(self.L.lig_rows_verify_begin(self.h, C.byref(job), _hptr(pb), len(pb), C.byref(vt), _hptr(seed), C.byref(info)))
+        return (vt if vt.value else None), seed.tobytes(), info
+
+    def rows_verify_finish(self, vtrace, rands, const_sum, on_device=False):
+        info = VerifyInfo()
+        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy()
+        if on_device:
+            rp = rands
+        else:
+            rands = np.ascontiguousarray(rands, dtype=np.uint32)
+            rp = C.c_void_p(rands.ctypes.data if rands.size else None)
+        self.check(self.L.lig_rows_verify_finish(vtrace, rp, int(bool(on_device)), _hptr(cs), C.byref(info)))
+        return info
 
     def rng_fill_rows(self, key, first_elem, per_row, out):
         k = np.frombuffer(bytes(key), dtype=np.uint8).copy()

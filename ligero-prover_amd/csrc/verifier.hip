@@ -44,22 +44,22 @@ bool recommit(size_t P, const std::vector<uint32_t>& idx, const uint8_t* leaf_di
 
 }  // namespace
 
-extern "C" {
+// where the verifier's randomness rows (and, for the synthetic stream, the public targets) come from
+struct VSource {
+    const uint8_t* witness_key = nullptr;      // synthetic stream: dense rows generated from rows[].data; the public targets for the derived constant
+    const fr* rand_dev = nullptr;              // caller's rows (R x k) on the device, used in place
+    const uint8_t* rand_host = nullptr;        // caller's rows in host memory, uploaded chunk by chunk
+};
 
-int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_sum, const uint8_t* proof, size_t proof_len,
-                     lig_verify_info* out) {
-    CHECK_CTX(c);
-    if (!job || !proof || !out) return LIG_E_ARG;
-    if (job->n_public_args && (!job->public_args || !job->public_arg_lens)) return LIG_E_ARG;
+// The verifier proper.  seeds_only: stop after the envelope is parsed and both seeds / the sample indices are re-derived
+// (lig_rows_verify_begin: the caller needs the stage-1 seed to produce its randomness rows).
+static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8_t ih[32], const VSource& src, const uint8_t* const_sum,
+                       const uint8_t* proof, size_t proof_len, lig_verify_info* out, uint8_t* seed1_out, bool seeds_only) {
     std::memset(out, 0, sizeof *out);
     const auto t_begin = clk::now();
     struct Stamp { lig_verify_info* o; decltype(t_begin) t0; ~Stamp() { o->ms_total = ms_since(t0); } } stamp{out, t_begin};
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     hipStream_t s = c->stream;
-    // ---- row plan of the public constraint stream
-    std::vector<RowDesc> rows;
-    size_t n_init = 0;
-    if (!plan_rows(*job, l, rows, n_init)) return LIG_E_ARG;
     const size_t R = rows.size();
     // ---- parse the envelope (proto/ligero_proof.proto; deserialize_proof, proof_serializer.hpp:193-226)
     PbReader top{proof, proof + proof_len}, meta{nullptr, nullptr}, body{nullptr, nullptr};
@@ -113,24 +113,15 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_
     if (!canonical_all(pcode, n) || !canonical_all(plin, n) || !canonical_all(pquad, n) || !canonical_all(psmp, (R + 3) * (size_t)t)) return LIG_OK;
     out->parsed = 1;
     // ---- seeds and sample indices (src/webgpu_verifier.cpp:268-293)
-    uint8_t ih[32], seed1[32], seed2[32];
+    uint8_t seed1[32], seed2[32];
     {
-        // instance_hash over arg0 = "Ligero\0" and the job's public arguments (src/webgpu_verifier.cpp mirrors webgpu_prover.cpp:110-168)
-        std::memset(ih, 0, 32);
-        Sha256().add(ih, 32).add("Ligero", 7).finish(ih);
-        const uint8_t* a = job->public_args;
-        for (uint64_t i = 0; i < job->n_public_args; i++) {
-            uint8_t prev[32];
-            std::memcpy(prev, ih, 32);
-            Sha256().add(prev, 32).add(a, job->public_arg_lens[i]).finish(ih);
-            a += job->public_arg_lens[i];
-        }
         Sha256().add("LigetronStage1", 15).add(root, 32).add(ih, 32).finish(seed1);
         Sha256().add("LigetronStage2", 15).add(root, 32).add(pcode, vec).add(plin, vec).add(pquad, vec).finish(seed2);
     }
     const std::vector<uint32_t> idx = sample_columns(seed2, n, t);
     out->indices_match = idx == pidx;
-    if (!out->indices_match) return LIG_OK;
+    if (seed1_out) std::memcpy(seed1_out, seed1, 32);
+    if (!out->indices_match || seeds_only) return LIG_OK;
     // ---- device buffers
     const size_t CH = 512;
     fr *dS = nullptr, *drand = nullptr, *drcw = nullptr, *drg = nullptr, *dacc = nullptr, *dparts = nullptr, *dpoly = nullptr;
@@ -157,7 +148,8 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_
     TRY(dm((void**)&dcoef, (R + 2 * NT + 1) * sizeof(lig::f29s)));
     // The constant of the linear test is derived from public data (lig_hip.h): the public targets b of the synthetic
     // statement (= the witness_key stream, regenerated here like lig_synth_prepare does) against the same coefficient rows.
-    const bool derive = const_sum == nullptr;
+    const bool derive = const_sum == nullptr && src.witness_key != nullptr;
+    if (!derive && !const_sum) return LIG_E_ARG;
     size_t RBv = 0;
     while (RBv < R && rows[RBv].kind >= RK_INIT) RBv++;
     fr *dW = nullptr, *dpl = nullptr, *dsum = nullptr;
@@ -167,7 +159,7 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_
         TRY(dm((void**)&dpl, (pgroups + 1) * (size_t)k * 32));
         TRY(dm((void**)&dsum, 32));
     }
-    if (derive) TRY(lig_internal_synth_witness(c, job->witness_key, rows, RBv, dW));    // before the stage-1 key is installed below
+    if (derive) TRY(lig_internal_synth_witness(c, src.witness_key, rows, RBv, dW));    // before the stage-1 key is installed below
     HIP_TRY(c, hipMemcpyAsync(dS, psmp, smp_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(dpoly, pcode, vec, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(dpoly + n, plin, vec, hipMemcpyHostToDevice, s));
@@ -209,10 +201,17 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key upload done
     HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
     const size_t n_chunks = (R + CH - 1) / CH;
+    auto rand_buf = [&](size_t ci) -> fr* { return src.rand_dev ? const_cast<fr*>(src.rand_dev) + ci * CH * (size_t)k : drand + (ci & 1) * CH * (size_t)k; };
     auto sample_chunk = [&](size_t ci) -> int {
         const size_t b = ci * CH, nb = std::min(CH, R - b);
-        fr* rb = drand + (ci & 1) * CH * (size_t)k;
+        fr* rb = rand_buf(ci);
+        if (src.rand_dev) { HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2)); return LIG_OK; }
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, ev_used[ci & 1], 0));
+        if (src.rand_host) {
+            HIP_TRY(c, hipMemcpyAsync(rb, src.rand_host + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, s2));
+            HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2));
+            return LIG_OK;
+        }
         for (size_t r = 0; r < nb;) {
             size_t run = 1;
             const uint32_t d = rows[b + r].data;
@@ -226,7 +225,7 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_
     if (n_chunks) TRY(sample_chunk(0));
     for (size_t ci = 0; ci < n_chunks; ci++) {
         const size_t b = ci * CH, nb = std::min(CH, R - b);
-        fr* rb = drand + (ci & 1) * CH * (size_t)k;
+        fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(sample_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, drcw, nb, false));
@@ -280,6 +279,82 @@ int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_
     out->accept = out->valid_merkle && out->valid_code && out->valid_linear && out->valid_quad && out->code_equal && out->linear_equal && out->quad_equal;
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
+}
+
+static bool instance_hash_v(const uint8_t* args, const uint64_t* lens, uint64_t n_args, uint8_t ih[32]) {
+    if (n_args && (!args || !lens)) return false;
+    std::memset(ih, 0, 32);
+    Sha256().add(ih, 32).add("Ligero", 7).finish(ih);
+    for (uint64_t i = 0; i < n_args; i++) {
+        uint8_t prev[32];
+        std::memcpy(prev, ih, 32);
+        Sha256().add(prev, 32).add(args, lens[i]).finish(ih);
+        args += lens[i];
+    }
+    return true;
+}
+
+// the verifier's side of a rows job (lig_rows_verify_*): kinds + public data, the proof, and between the two calls the
+// caller's randomness rows
+struct lig_vtrace {
+    lig_ctx* c = nullptr;
+    std::vector<RowDesc> rows;
+    uint8_t ih[32] = {0};
+    std::vector<uint8_t> proof;
+};
+
+extern "C" {
+
+int lig_synth_verify(lig_ctx* c, const lig_synth_job* job, const uint8_t* const_sum, const uint8_t* proof, size_t proof_len,
+                     lig_verify_info* out) {
+    CHECK_CTX(c);
+    if (!job || !proof || !out) return LIG_E_ARG;
+    // ---- row plan of the public constraint stream
+    std::vector<RowDesc> rows;
+    size_t n_init = 0;
+    uint8_t ih[32];
+    if (!plan_rows(*job, c->l, rows, n_init)) return LIG_E_ARG;
+    if (!instance_hash_v(job->public_args, job->public_arg_lens, job->n_public_args, ih)) return LIG_E_ARG;   // src/webgpu_verifier.cpp mirrors webgpu_prover.cpp:110-168
+    VSource src;
+    src.witness_key = job->witness_key;
+    return verify_core(c, rows, ih, src, const_sum, proof, proof_len, out, nullptr, false);
+}
+
+int lig_rows_verify_begin(lig_ctx* c, const lig_rows_job* job, const uint8_t* proof, size_t proof_len, lig_vtrace** vt, uint8_t stage1_seed[32],
+                          lig_verify_info* out) {
+    CHECK_CTX(c);
+    if (!job || !proof || !vt || !out || (job->rows && !job->kinds)) return LIG_E_ARG;
+    *vt = nullptr;
+    lig_vtrace* V = new lig_vtrace();
+    V->c = c;
+    V->rows.resize(job->rows);
+    for (size_t r = 0; r < job->rows; r++) {
+        const uint8_t kd = job->kinds[r] & 0x7f;
+        if (kd > RK_BQZ) { delete V; FAIL(c, LIG_E_ARG, "rows job: unknown row kind"); }
+        const bool first_of_3 = kd == 1 || kd == RK_BQX, first_of_2 = kd == RK_EQX, follower = kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ;
+        const bool ok = (!first_of_3 || (r + 2 < job->rows && (job->kinds[r + 1] & 0x7f) == kd + 1 && (job->kinds[r + 2] & 0x7f) == kd + 2)) &&
+                        (!first_of_2 || (r + 1 < job->rows && (job->kinds[r + 1] & 0x7f) == RK_EQY)) && (!follower || (r > 0 && (job->kinds[r - 1] & 0x7f) == kd - 1));
+        if (!ok) { delete V; FAIL(c, LIG_E_ARG, "rows job: incomplete row group"); }
+        V->rows[r] = RowDesc{kd, 0};
+    }
+    if (!instance_hash_v(job->public_args, job->public_arg_lens, job->n_public_args, V->ih)) { delete V; return LIG_E_ARG; }
+    V->proof.assign(proof, proof + proof_len);
+    const int rc = verify_core(c, V->rows, V->ih, VSource{}, nullptr, V->proof.data(), V->proof.size(), out, stage1_seed, true);
+    if (rc != LIG_OK || !out->parsed || !out->indices_match) { delete V; return rc; }      // malformed envelope: accept = 0, no trace
+    *vt = V;
+    return LIG_OK;
+}
+
+int lig_rows_verify_finish(lig_vtrace* V, const void* rands, int rands_on_device, const uint8_t const_sum[32], lig_verify_info* out) {
+    if (!V || !out || !const_sum) return LIG_E_ARG;
+    lig_ctx* c = V->c;
+    CHECK_CTX(c);
+    if (!V->rows.empty() && !rands) { delete V; FAIL(c, LIG_E_ARG, "lig_rows_verify_finish: null randomness rows"); }
+    VSource src;
+    if (rands_on_device) src.rand_dev = (const fr*)rands; else src.rand_host = (const uint8_t*)rands;
+    const int rc = verify_core(c, V->rows, V->ih, src, const_sum, V->proof.data(), V->proof.size(), out, nullptr, false);
+    delete V;
+    return rc;
 }
 
 }  // extern "C"

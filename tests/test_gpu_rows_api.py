@@ -92,6 +92,26 @@ def test_rows_entry_equals_oracle(amd, l, k, n, n_linear, n_quad, prog, pub, mod
         proof2, info2 = c.rows_prove(tr, rands if mode == "host_rows_library_pads" else d_r, None, on_device=mode != "host_rows_library_pads")
         assert proof2 == proof and bytes(info2.const_sum) == want["const_sum"]
         c.trace_destroy(tr)
+        # the verifier's side of the rows job: kinds + public data + the proof -> stage-1 seed -> the driver's randomness rows
+        vt, vseed, vinfo = c.rows_verify_begin(ol.row_kinds(job), proof, public_args=pub)
+        assert vt is not None and vseed == seed1 and vinfo.parsed == 1 and vinfo.indices_match == 1
+        v = c.rows_verify_finish(vt, rands, const_sum)
+        assert [v.valid_merkle, v.valid_code, v.valid_linear, v.valid_quad, v.code_equal, v.linear_equal, v.quad_equal, v.accept] == [1] * 8
+        if R:
+            vt, _, _ = c.rows_verify_begin(ol.row_kinds(job), proof, public_args=pub)
+            wrong = ((int.from_bytes(const_sum, "little") + 1) % ol.P).to_bytes(32, "little")
+            v = c.rows_verify_finish(vt, d_r if mode != "host_rows_library_pads" else rands, wrong, on_device=mode != "host_rows_library_pads")
+            assert (v.accept, v.valid_linear, v.valid_merkle, v.code_equal, v.linear_equal) == (0, 0, 1, 1, 1)
+            bad = bytearray(proof)
+            bad[len(bad) - 40] ^= 1                              # an opened mask element
+            vt, _, _ = c.rows_verify_begin(ol.row_kinds(job), bytes(bad), public_args=pub)
+            assert c.rows_verify_finish(vt, rands, const_sum).valid_merkle == 0
+            vt, _, vi = c.rows_verify_begin(ol.row_kinds(job), proof[:len(proof) // 2], public_args=pub)
+            assert vt is None and vi.accept == 0
+            other_rands = rands.copy()
+            other_rands[0, 0, 0] ^= 1                            # another public constraint stream
+            vt, _, _ = c.rows_verify_begin(ol.row_kinds(job), proof, public_args=pub)
+            assert c.rows_verify_finish(vt, other_rands, const_sum).accept == 0
         # both verifiers accept it, deriving the constant from the public statement themselves
         hjob = amd.Context.make_job(n_linear, n_quad, generated_at=77, public_args=pub)
         if prog:
