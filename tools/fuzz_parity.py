@@ -52,8 +52,9 @@ def main(cases, seed):
         n_quad = rng.choice([0, rng.randint(0, 1000 * SCALE), rng.randint(0, 120000 * SCALE // (SCALE * SCALE) * SCALE)])
         ts = rng.randint(0, 1 << 40)
         prog = random_program(rng) if rng.random() < 0.5 else None
-        oj = ol.make_job(L_, K_, N_, 192, n_lin, n_quad, generated_at=ts, threads=8)
-        hj = amd.Context.make_job(n_lin, n_quad, generated_at=ts)
+        pub = [bytes(rng.randrange(256) for _ in range(rng.randint(0, 12))) for _ in range(rng.randint(0, 3))] if rng.random() < 0.5 else None
+        oj = ol.make_job(L_, K_, N_, 192, n_lin, n_quad, generated_at=ts, threads=8, public_args=pub)
+        hj = amd.Context.make_job(n_lin, n_quad, generated_at=ts, public_args=pub)
         if prog is not None:
             prog.attach(oj); prog.attach(hj)
         pr = ol.Proof()
@@ -66,6 +67,24 @@ def main(cases, seed):
         v = c.synth_verify(hj, bytes(info.const_sum), proof)
         valid = bool(info.valid_code and info.valid_linear and info.valid_quad)
         ok = ok and bool(v.accept) == valid
+        ok = ok and bool(c.synth_verify(hj, None, proof).accept) == valid       # constant derived from the public statement
+        if ok and info.rows <= 1500:                                             # the caller-rows entry on the same rows
+            import numpy as np
+            rows = ol.form_rows(oj)[0]
+            kinds = ol.row_kinds(oj).copy()
+            lib_pads = rng.random() < 0.5
+            if lib_pads:
+                draws = (kinds <= 3) | (kinds == 4)
+                rows = rows.copy(); rows[draws, L_:] = 0
+                kinds[draws] |= amd.ROW_DRAW_PAD
+            tr, keep = c.rows_begin(kinds, rows, generated_at=ts, public_args=pub)
+            _, seed1 = c.rows_commit(tr)
+            rands, cs = ol.rand_rows(oj, seed1)
+            proof_r, info_r = c.rows_prove(tr, rands, cs)
+            c.trace_destroy(tr)
+            ok = ok and proof_r == want
+            vt, vseed, vi = c.rows_verify_begin(ol.row_kinds(oj), proof_r, public_args=pub)
+            ok = ok and vt is not None and bool(c.rows_verify_finish(vt, rands, cs).accept) == valid
         print("case %3d lin %7d quad %7d batch %-5s rows %5d valid %s -> %s" % (i, n_lin, n_quad, prog is not None, info.rows, valid, "ok" if ok else "MISMATCH"), flush=True)
         ol.lib().lo_proof_free(C.byref(pr))
         if not ok:
