@@ -132,7 +132,17 @@ public:
     template <typename T> void write_buffer_clear(buffer_type buf, const T* data, size_t len) {
         hip::check(ctx_, lig_write_clear(ctx_, buf.data(), buf.size(), data, len * sizeof(T)), "write_buffer_clear");
     }
-    void write_limbs(buffer_type buf, const uint32_t* limbs, size_t n_limbs) { write_buffer(buf, limbs, n_limbs); }
+    // write_limbs (include/wgpu.hpp:171-183): `size` copies of one element / a vector of elements, as device_bignum limbs
+    void write_limbs(buffer_type buf, const hip::scalar& val, size_t size) {
+        std::vector<hip::device_bignum> host_buf(size, hip::device_bignum(val));
+        write_buffer(buf, host_buf.data(), host_buf.size());
+    }
+    void write_limbs(buffer_type buf, const std::vector<hip::scalar>& vals) {
+        std::vector<hip::device_bignum> host_buf;
+        host_buf.reserve(vals.size());
+        for (const auto& v : vals) host_buf.emplace_back(v);
+        write_buffer(buf, host_buf.data(), host_buf.size());
+    }
     void clear_buffer(buffer_type buf) { hip::check(ctx_, lig_clear(ctx_, buf.data(), buf.size()), "clear_buffer"); }
     void copy_buffer_to_buffer(buffer_type from, buffer_type to) {
         hip::check(ctx_, lig_copy(ctx_, to.data(), from.data(), from.size() < to.size() ? from.size() : to.size()), "copy_buffer_to_buffer");
@@ -198,6 +208,12 @@ public:
     }
 #ifdef LIG_HAVE_GMP
     static hip::scalar to_scalar(const mpz_class& v) { return hip::device_bignum(v).to_scalar(); }
+    void write_limbs(buffer_type buf, const mpz_class& val, size_t size) { write_limbs(buf, to_scalar(val), size); }
+    void write_limbs(buffer_type buf, const std::vector<mpz_class>& vals) {
+        std::vector<hip::scalar> s;
+        for (const auto& v : vals) s.push_back(to_scalar(v));
+        write_limbs(buf, s);
+    }
     void powmod_set_base(const mpz_class& base, const mpz_class& /*p: fixed BN254 modulus*/) { powmod_set_base(to_scalar(base)); }
     void EltwiseAddMod(const hip::buffer_binding& b, const mpz_class& c, hip::eltwise_offset o = {}) { EltwiseAddMod(b, to_scalar(c), o); }
     void EltwiseSubConstMod(const hip::buffer_binding& b, const mpz_class& c, hip::eltwise_offset o = {}) { EltwiseSubConstMod(b, to_scalar(c), o); }
