@@ -43,10 +43,10 @@ struct lig_trace {
     fr* rcw = nullptr;                  // chunk x n their codewords
     fr* acc = nullptr;                  // code | lin | quad | tmp   (4 x n)
     fr* parts = nullptr;                // 2 x groups x n partial accumulators
-    fr* dots = nullptr;                 // R inner products
+    fr* dots = nullptr;                 // one element: a device-side sum (mask closing slot, linear-test constant)
     fr* samples = nullptr;              // (R+3) x t
     uint32_t* sha_state = nullptr; uint32_t* leaves = nullptr; uint32_t* nodes = nullptr;
-    uint32_t* data_dev = nullptr; uint32_t* tri_dev = nullptr;
+    uint32_t* tri_dev = nullptr;
     lig::f29s* coef_dev = nullptr;      // rc (R) | rq2 (T) | rq1 (T)
     std::vector<uint32_t> triples;
     uint8_t* h_proof = nullptr; size_t h_proof_cap = 0;   // pinned: the envelope is assembled here (owned by the trace)
@@ -54,7 +54,7 @@ struct lig_trace {
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
     hipEvent_t ev_gate = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
-    uint8_t* h_small = nullptr;                            // pinned: dots (R x 32) | mask odd slots (2l x 32) | decode buffer (n x 32)
+    uint8_t* h_small = nullptr;                            // pinned: the device-side sum (32 B) | 3 decoded accumulators (3 x n x 32)
 };
 
 // The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
@@ -170,7 +170,7 @@ int lig_internal_synth_witness(lig_ctx* c, const uint8_t witness_key[32], const 
 // ---------------------------------------------------------------------------------------------------------------------
 // shared by lig_synth_* and lig_rows_*: buffers of a trace whose row plan (T->rows) is known
 static int trace_alloc(lig_ctx* c, lig_trace* T) {
-    const uint32_t k = c->k, n = c->n, t = 192, l = c->l;
+    const uint32_t k = c->k, n = c->n, t = 192;
     const size_t R = T->R = T->rows.size();
     T->triples = quad_terms(T->rows);
     const size_t chunk = lig_tune::CHUNK, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
@@ -182,12 +182,11 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
     TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
     TRY(dm((void**)&T->parts, 3 * groups * (size_t)n * 32));
-    TRY(dm((void**)&T->dots, (R ? R : 1) * 32));
+    TRY(dm((void**)&T->dots, 32));
     TRY(dm((void**)&T->samples, (R + 3) * (size_t)t * 32));
     TRY(dm((void**)&T->sha_state, lig_sha_state_bytes(n)));
     TRY(dm((void**)&T->leaves, (size_t)n * 32));
     TRY(dm((void**)&T->nodes, lig_merkle_nodes(n) * 32));
-    TRY(dm((void**)&T->data_dev, (R ? R : 1) * sizeof(uint32_t)));
     TRY(dm((void**)&T->tri_dev, (T->triples.size() ? T->triples.size() : 1) * sizeof(uint32_t)));
     TRY(dm((void**)&T->coef_dev, (R + 2 * T->triples.size() / 3 + 1) * sizeof(lig::f29s)));
     T->h_proof_cap = (size_t)1 << 19;
@@ -195,7 +194,7 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     HIP_TRY(c, hipHostMalloc((void**)&T->h_proof, T->h_proof_cap, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&T->h_enc, 3 * (size_t)n * 32, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&T->h_nodes, lig_merkle_nodes(n) * 32, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void**)&T->h_small, ((R ? R : 1) + 2 * (size_t)l + 3 * (size_t)n) * 32, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&T->h_small, (1 + 3 * (size_t)n) * 32, hipHostMallocDefault));
     for (int i = 0; i < 2; i++) {
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_ready[i], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_used[i], hipEventDisableTiming));
@@ -319,7 +318,6 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     const size_t R = T->R;
     hipStream_t s = c->stream, s2 = c->stream2;
-    const bool synth = !T->from_rows;
     auto t0 = clk::now();
     uint32_t rk[60];
     // ================= stage 2: code / linear / quadratic accumulators over the resident codewords
@@ -436,7 +434,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     HIP_TRY(c, hipMemcpyAsync(enc + 2 * vec_bytes, quad, vec_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(T->ev_acc[2], s));
     // prover self-check (src/webgpu_prover.cpp:355-386,465-469): the three decodes run on the GPU while the host hashes
-    H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + ((R ? R : 1) + 2 * (size_t)l) * 32);    // 3 x n
+    H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + 32);    // 3 x n
     const fr* accs[3] = {code, lin, quad};
     for (int a3 = 0; a3 < 3; a3++) {
         TRY(lig_internal_decode_to(c, accs[a3], tmp));
@@ -459,7 +457,6 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         const H::Fr sum = H::neg(dots[0]);
         std::memcpy(info->const_sum, sum.v, 32);
     }
-    (void)synth;
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     mark("accumulators to host, seed hash, sampling, decodes");
     info->ms_stage2 = ms_since(t0);
@@ -545,12 +542,6 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
     // pads: init rows of the batch program drew theirs while the program ran (prepare); every stream row draws at commit time
     if (R > T->RB) T->pad_runs.push_back({T->RB, R - T->RB, (uint64_t)T->n_init * (k - l)});
     T->mask_pos = (uint64_t)(T->n_init + (R - T->RB)) * (k - l);
-    {
-        std::vector<uint32_t> d(R);
-        for (size_t r = 0; r < R; r++) d[r] = T->rows[r].data;
-        if (R) HIP_TRY(c, hipMemcpyAsync(T->data_dev, d.data(), R * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
     // witness values: one draw per data slot of every linear / x / y row, in commit order; z = x*y
     if (T->RB) TRY(lig_run_batch_program(c, *job, T->msgs));
     TRY(lig_internal_synth_witness(c, job->witness_key, T->rows, T->RB, T->msgs));
@@ -567,7 +558,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream3);
     T->c->sha.erase(T->sha_state);
     for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->c2, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
-                    (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->data_dev, (void*)T->tri_dev,
+                    (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);
     for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
