@@ -141,4 +141,70 @@ private:
     lig_trace* trace_ = nullptr;
 };
 
+// The verifier's counterpart (src/webgpu_verifier.cpp:263-452 with nonbatch_verifier_context, nonbatch_context.hpp:1081-1388):
+// the verifier runs the guest as well, its callbacks deliver the public randomness rows (the "value" rows it sees are the
+// 192 opened elements it pops from the proof, which the library reads from the envelope itself).  One pass suffices when the
+// caller derives stage1_seed first: begin(proof) -> seed -> run_program with the callbacks below -> finish(linear_sums).
+class hip_row_verifier {
+public:
+    hip_row_verifier(lig_ctx* ctx, hip_proof_meta meta) : ctx_(ctx), meta_(std::move(meta)), k_(lig_padding_size(ctx)) {
+        if (!ctx_) throw std::invalid_argument("hip_row_verifier: null context");
+    }
+    hip_row_verifier(const hip_row_verifier&) = delete;
+    hip_row_verifier& operator=(const hip_row_verifier&) = delete;
+
+    // the row kinds of the public constraint stream, in commit order (a dry run of the guest, or the prover's kinds)
+    void expect_rows(const std::vector<uint8_t>& kinds) { kinds_ = kinds; }
+    // parse the envelope, re-derive both seeds and the sample indices; false: malformed envelope / wrong indices (reject)
+    bool begin(const uint8_t* proof, size_t len, uint8_t stage1_seed[32], lig_verify_info* info = nullptr) {
+        std::vector<uint8_t> args;
+        std::vector<uint64_t> lens;
+        for (const auto& a : meta_.public_args) { args.insert(args.end(), a.begin(), a.end()); lens.push_back(a.size()); }
+        lig_rows_job job;
+        std::memset(&job, 0, sizeof job);
+        job.rows = kinds_.size();
+        job.kinds = kinds_.data();
+        job.public_args = args.empty() ? nullptr : args.data();
+        job.public_arg_lens = lens.empty() ? nullptr : lens.data();
+        job.n_public_args = lens.size();
+        lig_verify_info local;
+        const int rc = lig_rows_verify_begin(ctx_, &job, proof, len, &vt_, stage1_seed, info ? info : &local);
+        if (rc != LIG_OK) throw std::runtime_error(std::string("lig_rows_verify_begin: ") + lig_last_error(ctx_));
+        rands_.assign(kinds_.size() * (size_t)k_ * 4, 0);
+        next_ = 0;
+        return vt_ != nullptr;
+    }
+    void linear_callback(const uint64_t* rand) { row(LIG_ROW_LINEAR, rand); }
+    void quadratic_callback(const uint64_t* x_rand, const uint64_t* y_rand, const uint64_t* z_rand) { row(LIG_ROW_QX, x_rand); row(LIG_ROW_QY, y_rand); row(LIG_ROW_QZ, z_rand); }
+    void on_batch_init() { row(LIG_ROW_INIT, nullptr); }
+    void on_batch_bit() { row(LIG_ROW_BIT, nullptr); }
+    void on_batch_equal() { row(LIG_ROW_EQX, nullptr); row(LIG_ROW_EQY, nullptr); }
+    void on_batch_quadratic() { row(LIG_ROW_BQX, nullptr); row(LIG_ROW_BQY, nullptr); row(LIG_ROW_BQZ, nullptr); }
+    // the seven predicates of webgpu_verifier.cpp:412-442; returns accept
+    bool finish(const uint8_t const_sum[32], lig_verify_info* info = nullptr) {
+        if (!vt_) throw std::logic_error("hip_row_verifier::finish without a successful begin");
+        if (next_ != kinds_.size()) throw std::logic_error("hip_row_verifier::finish: fewer rows replayed than expected");
+        lig_verify_info local;
+        lig_verify_info* o = info ? info : &local;
+        lig_vtrace* vt = vt_;
+        vt_ = nullptr;                                        // finish frees the trace
+        if (lig_rows_verify_finish(vt, rands_.data(), 0, const_sum, o) != LIG_OK) throw std::runtime_error(std::string("lig_rows_verify_finish: ") + lig_last_error(ctx_));
+        return o->accept != 0;
+    }
+
+private:
+    void row(uint8_t kind, const uint64_t* rand) {
+        if (next_ >= kinds_.size() || (kinds_[next_] & 0x7f) != kind) throw std::logic_error("hip_row_verifier: the guest diverges from the expected row kinds");
+        if (rand) std::memcpy(rands_.data() + next_ * (size_t)k_ * 4, rand, (size_t)k_ * 32);
+        next_++;
+    }
+    lig_ctx* ctx_;
+    hip_proof_meta meta_;
+    uint32_t k_;
+    size_t next_ = 0;
+    std::vector<uint8_t> kinds_;
+    std::vector<uint64_t> rands_;
+    lig_vtrace* vt_ = nullptr;
+};
+
 }  // namespace ligero

@@ -72,7 +72,26 @@ int main(int argc, char** argv) {
         if (lo_prove(&j, &P) != 0) throw std::runtime_error("oracle prover failed");
         ok = len == P.proof_len && !std::memcmp(proof, P.proof, len) && !std::memcmp(root, P.root, 32) && !std::memcmp(seed1, P.stage1_seed, 32) &&
              info.valid_code && info.valid_linear && info.valid_quad;
-        std::printf("equal %d rows %zu proof_len %zu\n", ok, b.rows() + 3, len);
+        // the verifier's shim on the same public stream: accepts the proof, rejects it for another linear constant
+        int vok = 0;
+        {
+            ligero::hip_row_verifier v(ctx, meta);
+            v.expect_rows(std::vector<uint8_t>(kinds.begin(), kinds.begin() + R));
+            auto vreplay = [&]() {
+                for (size_t r = 0; r < R;) {
+                    if (kinds[r] == 0) { v.linear_callback(at(rands, r)); r += 1; }
+                    else { v.quadratic_callback(at(rands, r), at(rands, r + 1), at(rands, r + 2)); r += 3; }
+                }
+            };
+            uint8_t vseed[32];
+            lo_fr wrong = cs;
+            wrong.v[0] ^= 1;
+            const bool began = v.begin(proof, len, vseed) && !std::memcmp(vseed, seed1, 32);
+            if (began) { vreplay(); vok = v.finish(reinterpret_cast<const uint8_t*>(cs.v)) ? 1 : 0; }
+            if (vok && R) { vok = v.begin(proof, len, vseed) ? 1 : 0; if (vok) { vreplay(); vok = v.finish(reinterpret_cast<const uint8_t*>(wrong.v)) ? 0 : 1; } }
+        }
+        ok = ok && vok;
+        std::printf("equal %d rows %zu proof_len %zu verifier_shim %d\n", ok, b.rows() + 3, len, vok);
         lo_proof_free(&P);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
