@@ -37,8 +37,11 @@
 namespace lig {
 
 // ---------------------------------------------------------------------------------------------------- K1
+#ifndef LIG_K1_WAVES
+#define LIG_K1_WAVES 2
+#endif
 template <int LOG2B>
-__global__ void __launch_bounds__(256, 2) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29s* __restrict__ seam_inv,
+__global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29s* __restrict__ seam_inv,
                                                    const f29s* __restrict__ w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
