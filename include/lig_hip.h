@@ -314,6 +314,9 @@ enum { LIG_RCCL_ID_BYTES = 128 };
 int  lig_rccl_unique_id(uint8_t out[LIG_RCCL_ID_BYTES]);
 int  lig_rccl_comm_create(lig_ctx *ctx, const uint8_t id[LIG_RCCL_ID_BYTES], uint32_t rank, uint32_t world, lig_comm *out);
 void lig_rccl_comm_destroy(lig_comm *comm);
+/* host only: the block-cyclic deal of a job's committed rows (masks excluded) for packing size l: *rounds exchange rounds,
+ * world * rounds + 1 chunk boundaries (chunk g = rows [b[g], b[g+1]) belongs to rank g mod world).  LIG_E_NOMEM: cap too small. */
+int  lig_shard_plan(const lig_synth_job *job, uint32_t l, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
 int  lig_shard_prepare(lig_ctx *ctx, const lig_synth_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
 int  lig_shard_prove(lig_shard *shard, const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
 void lig_shard_destroy(lig_shard *shard);

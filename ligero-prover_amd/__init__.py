@@ -33,7 +33,7 @@ EXPORTS = [
     "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
     "lig_rows_verify_begin", "lig_rows_verify_finish",
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
-    "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy",
+    "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_shard_plan",
 ]
 
 ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
@@ -215,6 +215,18 @@ def instance_hash(args):
     if L.lig_instance_hash(_hptr(blob), _hptr(lens), len(args), _hptr(out)) != 0:
         raise LigError("lig_instance_hash failed")
     return out.tobytes()
+
+
+def shard_plan(job, l, world):
+    """-> (rounds, boundaries): the block-cyclic deal of the job's rows over `world` ranks (host only)"""
+    L = load_library()
+    L.lig_shard_plan.argtypes = [C.POINTER(SynthJob), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
+    rounds = C.c_uint64()
+    cap = 1 << 16
+    b = np.zeros(cap, dtype=np.uint64)
+    if L.lig_shard_plan(C.byref(job), l, world, C.byref(rounds), _hptr(b), cap) != 0:
+        raise LigError("lig_shard_plan failed")
+    return int(rounds.value), [int(x) for x in b[:rounds.value * world + 1]]
 
 
 def sample_columns(seed, n, t=192):

@@ -57,7 +57,39 @@ __global__ void __launch_bounds__(256) k_pack_slices(const fr* __restrict__ cw, 
 }
 }  // namespace lig
 
+// The block-cyclic deal: rounds = ceil(R / (W * CHUNK)), G = W * rounds global chunks of (nearly) equal size whose boundaries
+// never fall inside an x,y,z triple or an equality pair; chunk g belongs to rank g mod W.  gb: G + 1 boundaries.
+static void shard_chunks(const std::vector<RowDesc>& rows, uint32_t W, size_t& rounds, std::vector<size_t>& gb) {
+    const size_t R = rows.size();
+    rounds = std::max<size_t>(1, (R + W * lig_tune::CHUNK - 1) / (W * lig_tune::CHUNK));
+    const size_t G = rounds * W;
+    const size_t target = std::max<size_t>(1, (R + G - 1) / G);
+    gb.assign(G + 1, R);
+    gb[0] = 0;
+    auto inside_group = [&](uint8_t kd) { return kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ; };
+    for (size_t g = 1; g < G; g++) {
+        size_t b = std::min(R, gb[g - 1] + target);
+        while (b < R && inside_group(rows[b].kind)) b++;                       // never split a triple / an equality pair
+        gb[g] = b;
+    }
+}
+
 extern "C" {
+
+// host only (no GPU work): the deal of a job's committed rows over `world` ranks, for drivers and tests
+int lig_shard_plan(const lig_synth_job* job, uint32_t l, uint32_t world, uint64_t* rounds_out, uint64_t* boundaries, size_t cap) {
+    if (!job || !world || !rounds_out) return LIG_E_ARG;
+    std::vector<RowDesc> rows;
+    size_t n_init = 0;
+    if (!plan_rows(*job, l, rows, n_init)) return LIG_E_ARG;
+    size_t rounds = 0;
+    std::vector<size_t> gb;
+    shard_chunks(rows, world, rounds, gb);
+    *rounds_out = rounds;
+    if (gb.size() > cap || !boundaries) return gb.size() > cap ? LIG_E_NOMEM : LIG_E_ARG;
+    for (size_t i = 0; i < gb.size(); i++) boundaries[i] = gb[i];
+    return LIG_OK;
+}
 
 static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S);
 int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, const lig_comm* comm, lig_shard** out) {
@@ -102,18 +134,8 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
         S->code_ord[r + 1] = S->code_ord[r] + has_code_check(kd);                                    // position in the code-test stream
         S->pad_ord[r + 1] = S->pad_ord[r] + ((kd <= 3 || kd == RK_INIT) ? 1 : 0);                   // rows that draw k-l pads upstream
     }
-    // global chunks: rounds = ceil(R / (W * CHUNK)), G = W * rounds chunks of (nearly) equal size
-    S->rounds = std::max<size_t>(1, (R + W * lig_tune::CHUNK - 1) / (W * lig_tune::CHUNK));
+    shard_chunks(S->rows, W, S->rounds, S->gb);
     S->G = S->rounds * W;
-    const size_t target = std::max<size_t>(1, (R + S->G - 1) / S->G);
-    S->gb.assign(S->G + 1, R);
-    S->gb[0] = 0;
-    auto inside_group = [&](uint8_t kd) { return kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ; };
-    for (size_t g = 1; g < S->G; g++) {
-        size_t b = std::min(R, S->gb[g - 1] + target);
-        while (b < R && inside_group(S->rows[b].kind)) b++;                       // never split a triple / an equality pair
-        S->gb[g] = b;
-    }
     for (size_t g = 0; g < S->G; g++) S->ch_cap = std::max(S->ch_cap, S->chunk_rows(g));
     if (!S->ch_cap) S->ch_cap = 1;
     S->lrow0.assign(S->rounds + 1, 0);

@@ -61,3 +61,33 @@ def test_single_process_group_is_a_noop():
         g.barrier(); g.close()
     finally:
         os.environ.update(env)
+
+
+def test_shard_plan_block_cyclic_deal():
+    """host-only view of the sharded prover's row deal (lig_shard_plan): boundaries cover the rows in order, chunks hold at
+    most 512 (+2) rows, never split an x,y,z triple or an equality pair, are balanced, and chunk g goes to rank g mod W"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hip_lib
+    import oracle_lib as ol
+    import test_batch_rows as tb
+    amd = hip_lib.load()
+    l, k, n = 320, 512, 2048
+    for (nl, nq, prog) in ((700, 0, False), (320 * 1500 + 7, 330, False), (0, 0, False), (100, 320 * 40 + 3, True), (320 * 4300 + 1, 0, False)):
+        oj = ol.make_job(l, k, n, 192, nl, nq)
+        hj = amd.Context.make_job(nl, nq)
+        if prog:
+            tb.demo_program().attach(oj); tb.demo_program().attach(hj)
+        kinds = list(ol.row_kinds(oj))
+        R = len(kinds)
+        for W in (1, 2, 4, 8):
+            rounds, b = amd.shard_plan(hj, l, W)
+            assert rounds == max(1, -(-R // (W * 512))) and len(b) == rounds * W + 1
+            assert b[0] == 0 and b[-1] == R and all(x <= y for x, y in zip(b, b[1:]))
+            sizes = [y - x for x, y in zip(b, b[1:])]
+            assert max(sizes, default=0) <= 512 + 2
+            for x in b[1:-1]:
+                if x < R:
+                    assert kinds[x] not in (2, 3, 7, 9, 10), "a chunk boundary inside a row group"
+            per_rank = [sum(sizes[g] for g in range(r, len(sizes), W)) for r in range(W)]
+            assert sum(per_rank) == R and max(per_rank) - min(per_rank) <= max(3 * rounds + (R % (W * rounds) != 0) * (-(-R // (W * rounds))), 3)
