@@ -61,6 +61,15 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     hipStream_t s = c->stream;
     const size_t R = rows.size();
+    // LIG_TRACE=1: synchronised phase marks on stderr (debug aid)
+    const bool trace_on = std::getenv("LIG_TRACE") != nullptr;
+    auto t_mark = clk::now();
+    auto mark = [&](const char* what) {
+        if (!trace_on) return;
+        (void)hipStreamSynchronize(s);
+        std::fprintf(stderr, "[lig_verify] %-34s %8.3f ms\n", what, ms_since(t_mark));
+        t_mark = clk::now();
+    };
     // ---- parse the envelope (proto/ligero_proof.proto; deserialize_proof, proof_serializer.hpp:193-226)
     PbReader top{proof, proof + proof_len}, meta{nullptr, nullptr}, body{nullptr, nullptr};
     while (top.p < top.end) {
@@ -119,6 +128,7 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
         Sha256().add("LigetronStage2", 15).add(root, 32).add(pcode, vec).add(plin, vec).add(pquad, vec).finish(seed2);
     }
     const std::vector<uint32_t> idx = sample_columns(seed2, n, t);
+    mark("parse, canonical checks, seeds, indices");
     out->indices_match = idx == pidx;
     if (seed1_out) std::memcpy(seed1_out, seed1, 32);
     if (!out->indices_match || seeds_only) return LIG_OK;
@@ -130,9 +140,8 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     std::vector<void*> owned;
     auto dm0 = [&](void** p, size_t bytes, bool zero) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
     auto dm = [&](void** p, size_t bytes) -> int { return dm0(p, bytes, true); };
-    struct Cleanup { std::vector<void*>& v; lig_ctx* c; uint32_t*& sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
+    struct Cleanup { std::vector<void*>& v; lig_ctx* c; uint32_t*& sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
     Cleanup cleanup{owned, c, dsha};            // constructed before the first allocation: a failing TRY below frees what exists
-    const size_t groups = (CH + lig_tune::GROUP - 1) / lig_tune::GROUP;
     const std::vector<uint32_t> triples = quad_terms(rows);
     const size_t NT = triples.size() / 3;
     TRY(dm((void**)&dS, smp_bytes));
@@ -140,7 +149,9 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     TRY(dm0((void**)&drcw, CH * (size_t)n * 32, false));
     TRY(dm((void**)&drg, (R ? R : 1) * (size_t)t * 32));
     TRY(dm((void**)&dacc, 3 * (size_t)t * 32));
-    TRY(dm((void**)&dparts, 2 * groups * (size_t)t * 32));
+    const uint32_t vgroup = 64;                                  // rows per lazily summed partial of the 192-wide accumulators
+    const size_t vspan = 64 * (size_t)vgroup, vgroups = 64;      // rows per accumulate pass: 64 partials of < 2p each stay far below 2^261
+    TRY(dm((void**)&dparts, 2 * vgroups * (size_t)t * 32));
     TRY(dm((void**)&dpoly, 3 * vec));
     TRY(dm((void**)&dsha, lig_sha_state_bytes(t)));
     TRY(dm((void**)&dleaves, (size_t)t * 32));
@@ -164,7 +175,7 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     HIP_TRY(c, hipMemcpyAsync(dpoly, pcode, vec, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(dpoly + n, plin, vec, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(dpoly + 2 * (size_t)n, pquad, vec, hipMemcpyHostToDevice, s));
-    if (!triples.empty()) HIP_TRY(c, hipMemcpyAsync(dtri, triples.data(), triples.size() * 4, hipMemcpyHostToDevice, s));
+    if (!triples.empty()) TRY(lig_internal_upload_small(c, dtri, triples.data(), triples.size() * 4, s));
     {
         std::vector<H::Fr> rc, rq;
         FieldStream code(seed1), quad(seed1);
@@ -177,18 +188,19 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
         const H::Fr R261sq = H::mul(R261, R261);
         for (size_t r = 0, ci = 0; r < R; r++) if (has_code_check(rows[r].kind)) coef[r] = to_f29s_host(rc[ci++], R261);
         for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
-        HIP_TRY(c, hipMemcpyAsync(dcoef, coef.data(), coef.size() * sizeof(lig::f29s), hipMemcpyHostToDevice, s));
+        TRY(lig_internal_upload_small(c, dcoef, coef.data(), coef.size() * sizeof(lig::f29s), s));
         uint32_t rk[60];
         lig::aes256_expand_host(seed1, rk);
-        HIP_TRY(c, hipMemcpyAsync(c->rk_dev, rk, sizeof rk, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
+        TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, s));
     }
     // ---- column hash of the opened columns -> 192 leaves -> recommit (webgpu_verifier.cpp:309-310)
-    TRY(lig_sha_init(c, dsha, t));
-    TRY(lig_sha_update_rows(c, dsha, dS, R + 3));
-    TRY(lig_sha_final(c, dsha, dleaves));
+    mark("buffers, uploads, coefficients");
+    // (a chain of (R+3)/2 compressions on only 192 lanes: latency-bound, 2.7 ms for 2^24 constraints.  It is cut into the same
+    // row chunks as the randomness rows and rides on the side stream behind each sampler launch: 0.27 ms of sampling + 0.67 ms
+    // of hashing per chunk stay under the 1.1 ms the main stream needs to encode a chunk.  A third stream was measured to
+    // share a hardware queue with the main one -- the hash then simply serialised with the encodes.)
     std::vector<uint8_t> leaves((size_t)t * 32);
-    HIP_TRY(c, hipMemcpyAsync(leaves.data(), dleaves, leaves.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->ev_join, s));                  // dS uploaded
     // ---- randomness rows of the public stream, encoded, read at the sampled positions; accumulators on 192-vectors
     TRY(lig_sample_init(c, idx.data(), idx.size()));
     fr* vc = dacc; fr* vl = dacc + t; fr* vq = dacc + 2 * (size_t)t;
@@ -200,16 +212,20 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     for (int i = 0; i < 2; i++) { HIP_TRY(c, hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming)); HIP_TRY(c, hipEventCreateWithFlags(&ev_used[i], hipEventDisableTiming)); }
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key upload done
     HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_join, 0));
+    lig::launch_sha_init(s2, dsha, t);
     const size_t n_chunks = (R + CH - 1) / CH;
     auto rand_buf = [&](size_t ci) -> fr* { return src.rand_dev ? const_cast<fr*>(src.rand_dev) + ci * CH * (size_t)k : drand + (ci & 1) * CH * (size_t)k; };
     auto sample_chunk = [&](size_t ci) -> int {
         const size_t b = ci * CH, nb = std::min(CH, R - b);
         fr* rb = rand_buf(ci);
-        if (src.rand_dev) { HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2)); return LIG_OK; }
+        auto hash_chunk = [&]() { lig::launch_sha_update_rows(s2, dsha, t, dS + b * t, t, nb, b); };      // opened rows b .. b+nb of every sampled column
+        if (src.rand_dev) { HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2)); hash_chunk(); return LIG_OK; }
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, ev_used[ci & 1], 0));
         if (src.rand_host) {
             HIP_TRY(c, hipMemcpyAsync(rb, src.rand_host + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, s2));
             HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2));
+            hash_chunk();
             return LIG_OK;
         }
         for (size_t r = 0; r < nb;) {
@@ -220,6 +236,7 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
             lpos += (uint64_t)run * d; r += run;
         }
         HIP_TRY(c, hipEventRecord(ev_ready[ci & 1], s2));
+        hash_chunk();
         return LIG_OK;
     };
     if (n_chunks) TRY(sample_chunk(0));
@@ -232,8 +249,12 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
         if (derive) lig::launch_rlc_accumulate29(s, dW + b * k, k, 1, rb, k, nb, k, nullptr, nullptr, dpl + k, lig_tune::GROUP / 4);   // sum_r b_r o rho_r
         HIP_TRY(c, hipEventRecord(ev_used[ci & 1], s));
         TRY(lig_gather_rows(c, drcw, nb, drg + b * t));
-        lig::launch_rlc_rows29(s, dS + b * t, t, 1, drg + b * t, t, nb, t, dcoef + b, vc, vl, dparts, dparts + groups * (size_t)t, lig_tune::GROUP);
     }
+    // code / linear accumulators on the 192 opened positions: one pass per 4096 rows after the encodes (only 192 columns wide:
+    // inside the loop it was a latency-bound 8-workgroup launch per chunk that the next encode had to wait for)
+    for (size_t b = 0; b < R; b += vspan)
+        lig::launch_rlc_rows29(s, dS + b * t, t, 1, drg + b * t, t, std::min(vspan, R - b), t, dcoef + b, vc, vl, dparts, dparts + vgroups * (size_t)t, vgroup);
+    mark("randomness rows: sample, encode, gather, accumulate");
     lig::launch_quad_rows29(s, dS, t, 1, t, dtri, dcoef + R, dcoef + R + NT, NT, vq);
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, dS + R * (size_t)t, nullptr, vc, t, fr{}, 0);          // opened mask columns
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, dS + (R + 1) * (size_t)t, nullptr, vl, t, fr{}, 0);
@@ -253,6 +274,12 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
         HIP_TRY(c, hipMemcpyAsync(dec.data() + (size_t)a * n, dpoly + (size_t)a * n, vec, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
+    mark("quad, masks, decodes");
+    lig::launch_sha_update_rows(s2, dsha, t, dS + R * (size_t)t, t, 3, R);      // the three opened mask rows
+    lig::launch_sha_final(s2, dsha, t, R + 3, dleaves);
+    HIP_TRY(c, hipMemcpyAsync(leaves.data(), dleaves, leaves.size(), hipMemcpyDeviceToHost, s2));
+    HIP_TRY(c, hipStreamSynchronize(s2));                       // the leaves of the opened columns
+    mark("column hash join");
     // ---- the seven predicates (webgpu_verifier.cpp:412-442)
     uint8_t vroot[32];
     size_t P = 1;
