@@ -225,6 +225,9 @@ int lig_sample_columns(const uint8_t seed[32], uint32_t n, uint32_t t, uint32_t 
  *                    derives its linear-test randomness from stage1_seed (the reference re-runs the guest for that).
  *   lig_rows_prove   stage 2 + 3 with the caller's randomness rows (rows x k; the row of a batch-kind row must be zero) and
  *                    the public constant of the linear test (linear_sums, src/webgpu_prover.cpp:307).
+ * Encoding-stream positions follow the reference whoever draws: every LINEAR / QX / QY / QZ / INIT row owns the next k-l
+ * elements of the stream keyed by encoding_seed (witness_manager pads each of them when it is formed), the three mask rows
+ * take what follows; a row flagged LIG_ROW_DRAW_PAD gets exactly its own k-l elements, an unflagged one must carry them.
  * Row kinds: LINEAR rows stand alone; QX,QY,QZ / BQX,BQY,BQZ are consecutive triples (z = x*y); EQX,EQY a consecutive
  * pair; INIT and BIT stand alone.  Code-test coefficients are drawn per row (not for EQ rows), quadratic-test
  * coefficients per triple / pair / bit row, from the streams keyed by stage1_seed, exactly as lig_synth_prove does. ==== */
