@@ -172,7 +172,9 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     if (kmask & 2) hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
     if (ev0) (void)hipEventRecord(ev0, s);
-    if (kmask & 4) hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), 0, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
+    // LIG_K2B_DYN_LDS (experiments only): extra dynamic LDS bytes per workgroup = fewer workgroups per CU (profiles/r02_occupancy_ab.md)
+    static const uint32_t dyn_lds = [] { const char* e = std::getenv("LIG_K2B_DYN_LDS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    if (kmask & 4) hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), dyn_lds, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
     if (ev1) (void)hipEventRecord(ev1, s);
     const size_t th3 = rows * B * (FULL ? 4 : 1);
     if (kmask & 8) hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
