@@ -89,8 +89,22 @@ __device__ __forceinline__ f29 f29_montmul(const f29& a, const f29& b) {
     uint32_t m[9];
     f29 t;
     uint64_t acc = 0;
+#ifdef LIG_MONTMUL_PLAIN             // experiment: the same 17 columns left to hipcc (profiles/r02_montmul_plain_ab.md)
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const int j = k - i; if (j >= 0 && j < 9) acc = mad64(a.v[i], b.v[j], acc); }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const int j = k - i; if (j >= 1 && j < 9) acc = mad64(m[i], F29_P(j), acc); }
+        if (k < 9) { m[k] = ((uint32_t)acc * F29_N0) & F29_MASK; acc = mad64(m[k], f29_p0_opaque(), acc); }
+        if (k >= 9) t.v[k - 9] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    t.v[8] = (uint32_t)acc;
+#else
     const uint32_t p0 = f29_p0_opaque();
 #include "fr29_montmul_gen.hpp"      // the 17 columns, one chained v_mad_u64_u32 block each (tools/gen_fr29_montmul.py)
+#endif
     return t;
 }
 
