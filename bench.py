@@ -143,9 +143,14 @@ class FullWorkload:
             job = pkg.Context.make_job(self.constraints_per_trace, 0, synth_seed=1, generated_at=0)
             info = self.last_info
             self.ctx.synth_verify(job, None, proof)            # first call: its buffers are allocated right after the workloads freed theirs
-            t0 = time.perf_counter()
-            v = self.ctx.synth_verify(job, None, proof)        # the verifier derives the linear constant from the public statement
-            d.update(verifier_accepts=bool(v.accept), verify_ms=v.ms_total, verify_ms_with_python_copies=1e3 * (time.perf_counter() - t0))
+            best = None
+            for _ in range(3):                                 # the verifier derives the linear constant from the public statement
+                t0 = time.perf_counter()
+                v = self.ctx.synth_verify(job, None, proof)
+                wall = 1e3 * (time.perf_counter() - t0)
+                if best is None or v.ms_total < best[0]:
+                    best = (v.ms_total, wall, bool(v.accept))
+            d.update(verifier_accepts=best[2], verify_ms=best[0], verify_ms_with_python_copies=best[1])
             pin_path = os.path.join(ROOT, "tests", "golden", "full_pin_2p%d.json" % lg)
             if os.path.exists(pin_path):                      # the oracle's reference-structured prover on this exact job
                 with open(pin_path) as f:
