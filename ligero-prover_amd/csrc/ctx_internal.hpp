@@ -30,6 +30,7 @@ struct lig_ctx {
     fr* scratch_y = nullptr; fr* scratch_z = nullptr; size_t scratch_rows = 0;
     std::unordered_map<void*, std::pair<size_t, uint64_t>> sha;   // state ptr -> (n_inst, rows absorbed)
     uint32_t* sample_idx = nullptr; size_t sample_count = 0, sample_cap = 0;
+    std::vector<std::pair<void*, size_t>> vws; // verifier workspace: the device buffers of the last verification, reused slot by slot
     uint32_t* rk_dev = nullptr;               // 60 AES round-key words
     // small host -> device transfers on the proving path (round keys, coefficients, sample indices) go through a pinned
     // staging ring read by a copy KERNEL: a hipMemcpy H2D would queue behind the multi-hundred-MB row uploads of

@@ -260,6 +260,7 @@ void lig_ctx_destroy(lig_ctx* c) {
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z); (void)hipFree(c->sample_idx);
     (void)hipFree(c->rk_dev); (void)hipFree(c->small_dev); (void)hipFree(c->tri_dev);
     if (c->stage_host) (void)hipHostFree(c->stage_host);
+    for (auto& w : c->vws) (void)hipFree(w.first);
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

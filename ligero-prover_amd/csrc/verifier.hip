@@ -137,8 +137,24 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     fr *dS = nullptr, *drand = nullptr, *drcw = nullptr, *drg = nullptr, *dacc = nullptr, *dparts = nullptr, *dpoly = nullptr;
     uint32_t *dsha = nullptr, *dleaves = nullptr, *dtri = nullptr;
     lig::f29s* dcoef = nullptr;
-    std::vector<void*> owned;
-    auto dm0 = [&](void** p, size_t bytes, bool zero) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); owned.push_back(*p); if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s)); return LIG_OK; };
+    // device buffers come from the context's verifier workspace: slot i of this call reuses slot i of the previous one when it is
+    // large enough (a verification allocates ~2.5 GB for 2^24 constraints; hipMalloc / hipFree of that per call cost milliseconds
+    // and, right after another workload freed its memory, two orders of magnitude more)
+    std::vector<void*> owned;                                   // (kept for the guard below: nothing is freed per call any more)
+    size_t ws_slot = 0;
+    auto dm0 = [&](void** p, size_t bytes, bool zero) -> int {
+        const size_t need = bytes ? bytes : 16;
+        if (ws_slot == c->vws.size()) c->vws.push_back({nullptr, 0});
+        auto& w = c->vws[ws_slot++];
+        if (w.second < need) {
+            if (w.first) { HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(w.first)); w = {nullptr, 0}; }
+            HIP_TRY(c, hipMalloc(&w.first, need));
+            w.second = need;
+        }
+        *p = w.first;
+        if (zero) HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, s));
+        return LIG_OK;
+    };
     auto dm = [&](void** p, size_t bytes) -> int { return dm0(p, bytes, true); };
     struct Cleanup { std::vector<void*>& v; lig_ctx* c; uint32_t*& sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
     Cleanup cleanup{owned, c, dsha};            // constructed before the first allocation: a failing TRY below frees what exists
