@@ -271,7 +271,7 @@ class ShardedWorkload:
         (addr, length), info = self.ctx.shard_prove(self.shard, copy=False)
         if not (info.valid_code and info.valid_linear and info.valid_quad):
             raise SystemExit("prover self-check failed")
-        self.last = (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3)
+        self.last = (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3, info.ms_total)
 
     def describe(self):
         d = {"workload": "configs[3]-style: ONE 2^%d-constraint trace row-sharded over the GPUs, full proof"
@@ -280,7 +280,7 @@ class ShardedWorkload:
         if self.last:
             proof = C.string_at(self.last[0], self.last[1])
             d.update(proof_bytes=len(proof), proof_sha256=hashlib.sha256(proof).hexdigest(),
-                     stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]})
+                     stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]}, proof_latency_ms=self.last[5])
         return d
 
     def close(self):

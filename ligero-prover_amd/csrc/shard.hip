@@ -415,45 +415,67 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_rlc_combine(s, linC, p_linC, pg, k);
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
-    // partial sums [code (k message values) | lin (2k) | quad (2k)] -> every rank -> added mod p
-    HIP_TRY(c, hipMemcpyAsync(S->accp, tmp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(S->accp + k, lin, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(S->accp + 3 * (size_t)k, quad, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    TRY(all_gather(S->accp, S->accg, 5 * (size_t)k * 32, s, "all_gather(partial accumulators)"));
-    HIP_TRY(c, hipMemsetAsync(S->accp, 0, 5 * (size_t)k * 32, s));
-    lig::launch_rlc_combine(s, S->accp, S->accg, W, 5 * k);
-    HIP_TRY(c, hipMemsetAsync(S->acc, 0, 4 * (size_t)n * 32, s));
-    HIP_TRY(c, hipMemcpyAsync(tmp, S->accp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(lin, S->accp + k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(quad, S->accp + 3 * (size_t)k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+    // partial sums [code (k message values) | lin (2k) | quad (2k)] -> every rank -> added mod p (one rank: they are the sums)
+    if (W > 1 || S->exchange_even_alone) {
+        HIP_TRY(c, hipMemcpyAsync(S->accp, tmp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(S->accp + k, lin, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(S->accp + 3 * (size_t)k, quad, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+        TRY(all_gather(S->accp, S->accg, 5 * (size_t)k * 32, s, "all_gather(partial accumulators)"));
+        HIP_TRY(c, hipMemsetAsync(S->accp, 0, 5 * (size_t)k * 32, s));
+        lig::launch_rlc_combine(s, S->accp, S->accg, W, 5 * k);
+        HIP_TRY(c, hipMemsetAsync(S->acc, 0, 4 * (size_t)n * 32, s));
+        HIP_TRY(c, hipMemcpyAsync(tmp, S->accp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(lin, S->accp + k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(quad, S->accp + 3 * (size_t)k, 2 * (size_t)k * 32, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));      // linH / linC scratch behind the 2k values
+    }
     H::Fr* dots = reinterpret_cast<H::Fr*>(S->h_small);
     lig::launch_sum_elems(s, lin, k, 2, S->dots, nullptr);   // linear-test constant = -(sum of the message-domain half: the even points)
     HIP_TRY(c, hipMemcpyAsync(dots, S->dots, 32, hipMemcpyDeviceToHost, s));
-    TRY(lig_internal_encode_rows(c, tmp, code, 1, false));
-    TRY(lig_internal_extend_2k(c, lin));
-    TRY(lig_internal_extend_2k(c, quad));
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
+    // as in lig_synth_prove: each accumulator is extended, masked and sent to the host as soon as it is final; the host absorbs
+    // it into the stage-2 seed hash (sequential SHA-256 over 3 MiB) while the GPU extends the next one and runs the decodes
     uint8_t* enc = S->h_enc;
-    const size_t enc_bytes = 3 * (size_t)n * 32;
-    HIP_TRY(c, hipMemcpyAsync(enc, S->acc, enc_bytes, hipMemcpyDeviceToHost, s));
+    const size_t vec_bytes = (size_t)n * 32, enc_bytes = 3 * vec_bytes;
+    hipEvent_t ev_acc[3] = {S->ev_enc[0], S->ev_enc[1], S->ev_hash[0]};      // stage 1 is over: its events are free
+    TRY(lig_internal_encode_rows(c, tmp, code, 1, false));
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
+    HIP_TRY(c, hipMemcpyAsync(enc, code, vec_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(ev_acc[0], s));
+    TRY(lig_internal_extend_2k(c, lin));
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
+    HIP_TRY(c, hipMemcpyAsync(enc + vec_bytes, lin, vec_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(ev_acc[1], s));
+    TRY(lig_internal_extend_2k(c, quad));
+    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
+    HIP_TRY(c, hipMemcpyAsync(enc + 2 * vec_bytes, quad, vec_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(ev_acc[2], s));
     H::Fr* dec = reinterpret_cast<H::Fr*>(S->h_small + 32);
     const fr* accs[3] = {code, lin, quad};
     for (int a3 = 0; a3 < 3; a3++) {
         TRY(lig_internal_decode_to(c, accs[a3], tmp));
-        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, vec_bytes, hipMemcpyDeviceToHost, s));
     }
     const size_t n_nodes = lig_merkle_nodes(n);
     HIP_TRY(c, hipMemcpyAsync(S->h_nodes, S->nodes, n_nodes * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventRecord(c->ev_join, s));
     {
-        const H::Fr sum = H::neg(dots[0]);
+        Sha256 h2;
+        h2.add("LigetronStage2", 15).add(info->root, 32);
+        for (int a3 = 0; a3 < 3; a3++) {
+            HIP_TRY(c, hipEventSynchronize(ev_acc[a3]));
+            h2.add(enc + (size_t)a3 * vec_bytes, vec_bytes);
+        }
+        h2.finish(info->stage2_seed);
+    }
+    (void)enc_bytes;
+    {
+        const H::Fr sum = H::neg(dots[0]);                    // (copied before ev_acc[0])
         std::memcpy(info->const_sum, sum.v, 32);
     }
-    Sha256().add("LigetronStage2", 15).add(info->root, 32).add(enc, enc_bytes).finish(info->stage2_seed);
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     TRY(lig_sample_init(c, idx.data(), idx.size()));
+    HIP_TRY(c, hipEventSynchronize(c->ev_join));          // decoded accumulators and Merkle nodes are on the host
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
     info->valid_code = 1;
     for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
