@@ -416,10 +416,10 @@ def main():
     if rank == 0:
         sharded = a.workload == "sharded"
         total_constraints = wl.constraints * a.steps * (1 if sharded else world)
-        # dominant kernel = k_encode_mid (K2b): per encoded row it reads the k coefficients and writes the three computed
-        # cosets: (k + 3k) * 32 B = 1,048,576 B.  (SURVEY.md 8(d) quotes 1,310,720 B for a whole row encode, read k*32 +
-        # write n*32; the fourth coset is the reversed message and is written by k_encode_out, so the conservative figure
-        # for THIS kernel is its own compulsory traffic.)
+        # dominant kernel = k_encode_tiles (K2: all tile transforms of a row, 90 % of the encode's multiplies): per encoded row
+        # it reads k elements and writes the three computed cosets: (k + 3k) * 32 B = 1,048,576 B.  (SURVEY.md 8(d) quotes
+        # 1,310,720 B for a whole row encode, read k*32 + write n*32; the fourth coset is the message row itself, so the
+        # conservative figure for THIS kernel is its own compulsory traffic.)
         alg_bytes_per_row = (K_ + 3 * K_) * 32
         avg_launch_s = (kms / max(launches, 1)) * 1e-3
         rows_per_launch = prows / max(launches, 1)
@@ -429,7 +429,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)["k_encode_mid<10, true>"]
+                pmc = json.load(f)["k_encode_tiles<10, true>"]
             traffic = pmc["hbm_bytes_per_row"] * rows_per_launch
             traffic_src = "profiles/pmc_traffic.json (%.0f B/row measured on %d-row launches)" % (pmc["hbm_bytes_per_row"], pmc["rows_in_launch"])
         except (OSError, KeyError, ValueError):
@@ -443,7 +443,7 @@ def main():
             "config": dict(wl.describe(), parallelism=("1 trace sharded over %d GPUs: all-to-all of codeword column slices + all-gathers" % world)
                            if sharded else "1 trace per GPU (independent traces, no collective)"),
             "proof_wall_ms": (single_ms if single_ms is not None else 1e3 * dt / a.steps) if a.workload != "encode" else None,
-            "roofline": {"bound": "hbm", "kernel": "k_encode_mid", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_encode_tiles", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": rows_per_launch * alg_bytes_per_row,
                          "avg_launch_ms": 1e3 * avg_launch_s, "rows_per_launch": rows_per_launch, "launches": launches,
@@ -453,8 +453,9 @@ def main():
                              "avg_launch_ms": single_prof[2] / single_prof[0], "rows_per_launch": single_prof[1] / single_prof[0],
                              "achieved": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9,
                              "frac": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9 / 8000.0},
-                         "note": "integer-VALU-bound kernel (~150k 256-bit Montgomery products per row in this kernel, "
-                                 "v_mad_u64_u32 issues at a quarter of the simple-ALU rate); the HBM fraction is small by "
+                         "note": "integer-VALU-bound kernel (~185k 256-bit Montgomery products per row in this kernel: since round 2 it "
+                                 "also carries the inverse tile transforms that used to be a kernel of their own, same bytes, more "
+                                 "arithmetic; v_mad_u64_u32 issues at half the simple-ALU rate); the HBM fraction is small by "
                                  "construction, see DESIGN.md"},
         }
         if a.workload != "encode":

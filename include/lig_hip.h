@@ -325,7 +325,7 @@ int  lig_shard_prove(lig_shard *shard, const uint8_t **proof, size_t *proof_len,
 void lig_shard_destroy(lig_shard *shard);
 
 /* Measurement hook (no reference counterpart): while enabled, every lig_encode_rows launch group records HIP
- * events on the context stream immediately around the dominant kernel (encode_mid).  lig_profile_read syncs
+ * events on the context stream immediately around the dominant kernel (k_encode_tiles).  lig_profile_read syncs
  * and returns the number of bracketed launches, the rows they covered and the summed kernel time. */
 int lig_profile_enable(lig_ctx *ctx, int on);
 int lig_profile_read(lig_ctx *ctx, uint64_t *launches, uint64_t *rows, double *total_ms);

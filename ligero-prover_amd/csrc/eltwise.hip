@@ -153,6 +153,16 @@ __global__ void k_gather_rows(const fr* __restrict__ cw, size_t row_stride, size
         fr_store(out + t, fr_load(cw + r * row_stride + idx[i]));
     }
 }
+__global__ void k_gather_rows_planar(CwView cw, size_t rows, const uint32_t* __restrict__ idx, uint32_t count, fr* __restrict__ out) {
+    const size_t total = rows * count;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = t / count;
+        fr_store(out + t, fr_load(cw.at(r, idx[(uint32_t)(t - r * count)])));
+    }
+}
+void launch_gather_rows_planar(hipStream_t s, CwView cw, size_t rows, const uint32_t* idx, uint32_t count, fr* out) {
+    if (rows) hipLaunchKernelGGL(k_gather_rows_planar, dim3(blocks_for(rows * count)), dim3(256), 0, s, cw, rows, idx, count, out);
+}
 void launch_gather_rows(hipStream_t s, const fr* cw, size_t row_stride, size_t rows, const uint32_t* idx, uint32_t count, fr* out) {
     hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(rows * count)), dim3(256), 0, s, cw, row_stride, rows, idx, count, out);
 }

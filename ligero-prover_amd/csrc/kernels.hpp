@@ -49,17 +49,33 @@ void ntt_generic_fold(hipStream_t s, fr* buf, uint32_t half, size_t rows, size_t
 
 // ---- ntt_encode.hip
 bool encode_fast_supported(uint32_t k);
-// ev0/ev1 (optional): HIP events recorded on `s` immediately before/after the dominant kernel (encode_mid)
-// half: produce only the k values on the coset w_n^2 <w_n^4> (out[q] = P(w_n^(4q + 2)), rows x k) instead of the codeword;
-// msgs must not overlap out (K3 copies coset 0 of the codeword from the message row); coset2 (optional, full encodes only):
-// rows x k compact copy of the codeword elements 4q + 2
+// ev0/ev1 (optional): HIP events recorded on `s` immediately before/after the dominant kernel (k_encode_tiles)
+// mode ENC_FULL: out = rows x n codewords in the reference layout; msgs must not overlap out (K3 copies coset 0 of the
+//   codeword from the message row); coset2 (optional): rows x k compact copy of the codeword elements 4q + 2.
+// mode ENC_HALF: out = rows x k, only the values on the coset w_n^2 <w_n^4> (out[q] = P(w_n^(4q + 2))).
+// mode ENC_PLANAR: out = rows x 3k, out[(r-1)*k + q] = P(w_n^(4q + r)) for r = 1, 2, 3; coset 0 of a codeword is its message
+//   row reversed (codeword[4q] = msg[(k - q) mod k]) and is not stored.  CwView below addresses such a matrix by column.
+enum { ENC_FULL = 0, ENC_HALF = 1, ENC_PLANAR = 2 };
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y,
-                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, bool half = false, fr* coset2 = nullptr);
+                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, int mode = ENC_FULL, fr* coset2 = nullptr);
+
+// The batched prover's resident codeword matrix: message rows (coset 0, reversed) + the three computed cosets as planes.
+struct CwView {
+    const fr* msgs;       // rows x k
+    const fr* planes;     // rows x 3k
+    uint32_t k;
+    // codeword element `col` (0 <= col < 4k) of row `row`
+    __host__ __device__ const fr* at(size_t row, uint32_t col) const {
+        const uint32_t r = col & 3u, q = col >> 2;
+        return r == 0 ? msgs + row * k + ((k - q) & (k - 1)) : planes + row * 3 * (size_t)k + (size_t)(r - 1) * k + q;
+    }
+};
 
 // ---- eltwise.hip
 void launch_eltwise(hipStream_t s, int op, const fr* x, const fr* y, fr* out, size_t count, fr scalar, uint32_t bit);
 void launch_powmod(hipStream_t s, const fr* table32, const uint32_t* exp, const fr* coeff, fr* out, size_t count, int add);
 void launch_gather_rows(hipStream_t s, const fr* cw, size_t row_stride, size_t rows, const uint32_t* idx, uint32_t count, fr* out);
+void launch_gather_rows_planar(hipStream_t s, CwView cw, size_t rows, const uint32_t* idx, uint32_t count, fr* out);
 void launch_rlc_rows(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const fr* rc_dev,
                      fr* code, fr* lin, const uint32_t* triples_dev, const fr* rq_dev, size_t n_triples, fr* quad);
 
@@ -69,9 +85,11 @@ struct ShaState {          // layout of the caller-owned device state buffer
     uint32_t* pend;        // [8][n_inst]  buffered element when an odd number of rows has been absorbed
 };
 void launch_sha_init(hipStream_t s, uint32_t* state, size_t n_inst);
+// plane_k = 0: instance j = column j of `rows`.  plane_k = k: plane-major instances (j = r*k + q is column 4q + r), reading
+// interleaved rows (msgs == nullptr) or a CwView {msgs, planes = rows} (sha.hip); launch_sha_final then needs the same plane_k
 void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const fr* rows, size_t row_stride,
-                            size_t nrows, uint64_t rows_before);
-void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests);
+                            size_t nrows, uint64_t rows_before, uint32_t plane_k = 0, const fr* msgs = nullptr);
+void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests, uint32_t plane_k = 0);
 void launch_merkle_build(hipStream_t s, const uint32_t* leaves, size_t n_leaves, uint32_t* nodes);
 
 // ---- aes.hip

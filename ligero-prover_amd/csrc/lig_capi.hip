@@ -328,7 +328,7 @@ static int ensure_scratch(lig_ctx* c, size_t rows) {
     if (c->stream3) HIP_TRY(c, hipStreamSynchronize(c->stream3));
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z);
     c->scratch_y = c->scratch_z = nullptr; c->scratch_rows = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->scratch_y, 2 * rows * (size_t)c->k * sizeof(fr)));   // Y and C
+    HIP_TRY(c, hipMalloc((void**)&c->scratch_y, rows * (size_t)c->k * sizeof(fr)));       // Y
     HIP_TRY(c, hipMalloc((void**)&c->scratch_z, rows * (size_t)c->n * sizeof(fr)));
     c->scratch_rows = rows;
     return LIG_OK;
@@ -341,11 +341,12 @@ int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ens
 // shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
 // codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
 // (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, bool half, hipStream_t on, void* coset2) {
-    const size_t out_stride = half ? (size_t)c->k : (size_t)c->n;
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on, void* coset2) {
+    const bool half = mode == lig::ENC_HALF;
+    const size_t out_stride = half ? (size_t)c->k : mode == lig::ENC_PLANAR ? 3 * (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
     if (c->fast) {
-        // rows per launch group: the Y/C/Z scratch (1.5 MiB/row) should stay inside the 256 MiB L3 so that K3's
+        // rows per launch group: the Y/Z scratch (1 MiB/row) should stay inside the 256 MiB L3 so that K3's
         // re-read of Z does not go to HBM.  LIG_ENCODE_CHUNK overrides for experiments.
         static const size_t chunk = [] { const char* e = std::getenv("LIG_ENCODE_CHUNK"); size_t v = e ? (size_t)std::atoi(e) : 0; return v ? v : (size_t)512; }();
         int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
@@ -363,7 +364,24 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                 c->prof_used++; c->prof_rows += nr;
             }
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
-                                  c->scratch_z, nr, e0, e1, half, coset2 ? (fr*)coset2 + r0 * c->k : nullptr);
+                                  c->scratch_z, nr, e0, e1, mode, coset2 ? (fr*)coset2 + r0 * c->k : nullptr);
+        }
+    } else if (mode == lig::ENC_PLANAR) {
+        // generic path (k > 8192), planar: codewords of a few rows at a time in the Z scratch, then one strided copy per plane
+        const size_t n = c->n, k = c->k, chunk = 64;
+        int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
+        if (rc != LIG_OK) return rc;
+        for (size_t r0 = 0; r0 < rows; r0 += chunk) {
+            const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
+            fr* z = c->scratch_z;
+            HIP_TRY(c, hipMemsetAsync(z, 0, nr * n * sizeof(fr), st));
+            HIP_TRY(c, hipMemcpy2DAsync(z, n * sizeof(fr), (const fr*)msgs + r0 * k, k * sizeof(fr), k * sizeof(fr), nr, hipMemcpyDeviceToDevice, st));
+            lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], z, nr, n);
+            lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], z, nr, n);
+            for (size_t r = 0; r < nr; r++)
+                for (uint32_t cs = 1; cs < 4; cs++)
+                    HIP_TRY(c, hipMemcpy2DAsync((fr*)out + (r0 + r) * 3 * k + (cs - 1) * k, sizeof(fr), z + r * n + cs, 4 * sizeof(fr), sizeof(fr), k,
+                                                hipMemcpyDeviceToDevice, st));
         }
     } else if (!half) {
         // generic path: copy + zero-pad each row, INTT_k, then NTT_n with the radix-2 kernels

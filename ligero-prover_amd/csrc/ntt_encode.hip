@@ -1,7 +1,7 @@
 // ntt_encode.hip -- the hot loop: Reed-Solomon encode of a BATCH of rows on gfx950.
 //
 // Replaces encode_ntt_device (src/webgpu/engine.cpp:755-770: 15 dispatches of <=64 workgroups per row,
-// radix-2 stages through global memory, bit-reversal passes) with four launches per row batch.
+// radix-2 stages through global memory, bit-reversal passes) with three launches per row batch.
 //
 // Math.  codeword[j] = P(w_n^j), j < n = 4k, P = the degree-<k interpolant of the message on
 // the w_k domain.  With c = INTT_k(msg), psi = w_n^4 (order k) and j = 4q + r:
@@ -12,17 +12,16 @@
 //
 //   K1  encode_in  : thread = (row, i2).  Radix-8 butterfly across the strided elements msg[B*i1 + i2], seam
 //                    twiddle w_k^(-i2*j1) -> Y[j1][i2].
-//   K2a encode_coef: workgroup = (row, j1).  Size-B inverse transform of Y[j1][.] in LDS (the 1/k factor rides on the K2b twist)
-//                    -> C[j1][j2] = coefficient c[j1 + 8*j2].
-//   K2b encode_mid : workgroup = (row, j1, coset r).  C[j1][.] * w_n^(r*i) -> size-B forward transform in LDS
-//                    -> times seam twiddle psi^(j1*q2) -> Z[r][j1][q2].                 (72% of all multiplies)
+//   K2  encode_tiles: workgroup = (row, j1).  Size-B inverse transform of Y[j1][.] in LDS -> the coefficients c[j1 + 8*j2] (the
+//                    1/k factor rides on the twist tables), kept in registers; then per coset r: times w_n^(r*i) -> size-B
+//                    forward transform in LDS -> times seam twiddle psi^(j1*q2) -> Z[r][j1][q2].   (90% of all multiplies)
 //   K3  encode_out : thread = (row, q2, r).  Radix-8 butterfly across Z[r][0..8)[q2], exact canonical
 //                    reduction, codeword[4*(q2 + B*q1) + r]: 4 adjacent lanes = 4 cosets = 128 contiguous bytes,
 //                    a wave writes 2 KiB runs in natural order (no bit-reversal pass anywhere).
 //
 // All butterflies are decimation-in-time on 29-bit-limb lazy values (fr29.hpp): x' = x + w*y, y' = x - w*y + 2p,
 // so magnitudes grow additively (<= 4p per radix-4 step) and no modular reduction is needed inside a transform;
-// limbs are renormalised once per radix-4 step.  Y, C, Z hold values < 2^256 in the canonical 8 x u32 layout
+// limbs are renormalised once per radix-4 step.  Y, Z hold values < 2^256 in the canonical 8 x u32 layout
 // (not necessarily < p); only K3 produces canonical residues, which is all the reference guarantees as well.
 //
 // Limb/value bounds are stated next to each operation; the invariants are
@@ -61,139 +60,150 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
 #undef LIG_SEAM
 }
 
-// ---------------------------------------------------------------------------------------------------- K2a
-template <int LOG2B>
-__global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_coef(const fr* __restrict__ Y, fr* __restrict__ Cc,
-                                                                  const f29s* __restrict__ tw_inv, const f29s* __restrict__ kinv) {
-    constexpr uint32_t B = 1u << LOG2B, T = B / 4;
-    __shared__ TileLds<LOG2B> L;
-    const uint32_t t = threadIdx.x;
-    const fr* y = Y + (size_t)blockIdx.x * B;          // tile (row, j1) = blockIdx.x
-    f29 x[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + (__brev(4 * t + q) >> (32 - LOG2B))));
-    tile_dft<LOG2B>(x, tw_inv, L, t);
-    (void)kinv;                                    // the 1/k factor is folded into the twist tables of K2b (lig_capi.hip)
-    fr* c = Cc + (size_t)blockIdx.x * B;
-#pragma unroll
-    for (int q = 0; q < 4; q++) fr_store(c + t + q * T, pack29(f29_reduce_2p(x[q])));
-}
-
-// ---------------------------------------------------------------------------------------------------- K2b
-// Coset 0 of the codeword needs no arithmetic: w_4k comes from root2 = root1^(2^61 - 1) (src/bn254.cpp:36-43), so
-// w_4k^4 = w_k^(2^61 - 1) = w_k^(-1) and codeword[4q] = P(w_k^(-q)) = msg[(k - q) mod k] -- a reversed copy of the message.
-// FULL = true : cosets r = 1, 2, 3 are computed here (3 workgroups per tile), K3 copies coset 0 from the message row.
-// FULL = false: only coset r = 2 (the odd points of the order-2k subgroup <w_n^2>) -- all a stage-2 randomness row
-//               needs: its values on the even points are the row itself (prover.hip).
+// ---------------------------------------------------------------------------------------------------- K2 (fused K2a + K2b)
+// workgroup = (row, j1): the coefficient tile C[j1][.] is produced (inverse tile transform of Y[j1][.]) and consumed (one
+// forward tile transform per coset) without leaving the CU.  Between the two, the tile changes ownership once through
+// LDS: the inverse transform leaves thread t with coefficients t + q*T, the forward transforms start from the bit-reversed
+// positions brev(4t + q).  The C scratch matrix (k*32 bytes written + read per row) and one launch are gone; the price is
+// 36 more live registers (the coefficients stay in VGPRs across the NC transforms).
+#ifndef LIG_K2_WAVES
+#define LIG_K2_WAVES 3
+#endif
 template <int LOG2B, bool FULL>
-__global__ void __launch_bounds__((1 << LOG2B) / 4) k_encode_mid(const fr* __restrict__ Cc, fr* __restrict__ Z,
-                                                                 const f29s* __restrict__ tw_fwd, const f29s* __restrict__ twist,
-                                                                 const f29s* __restrict__ seam_fwd) {
+__global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_encode_tiles(const fr* __restrict__ Y, fr* __restrict__ Z,
+                                                                   const f29s* __restrict__ tw_inv, const f29s* __restrict__ tw_fwd,
+                                                                   const f29s* __restrict__ twist, const f29s* __restrict__ seam_fwd) {
     constexpr uint32_t B = 1u << LOG2B, T = B / 4, NC = FULL ? 3 : 1;
     __shared__ TileLds<LOG2B> L;
     const uint32_t t = threadIdx.x;
-    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with a private L2.  The NC
-    // coset workgroups of one tile read the same 32 KiB of coefficients, so they get block ids 8 apart (same XCD)
-    // and the tile index is the fastest-varying part: per group of 8*NC blocks, b = j1 + 8*ci.
-    const uint32_t j1 = blockIdx.x & 7u, ci = (blockIdx.x >> 3) % NC;      // tile, coset slot
-    const uint32_t r = FULL ? ci + 1 : 2;                                  // coset number
-    const size_t row = blockIdx.x / (8 * NC);
-    const fr* c = Cc + (row * 8 + j1) * (size_t)B;
-    f29 x[4];
+    const uint32_t j1 = blockIdx.x & 7u;
+    const size_t row = blockIdx.x >> 3;
+    const fr* y = Y + (size_t)blockIdx.x * B;
+    f29 x[4], cb[4];
+    uint32_t pos[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t pos = __brev(4 * t + q) >> (32 - LOG2B);
-        x[q] = f29_montmul(unpack29(fr_load(c + pos)), f29_load_tab(twist + ((size_t)(r - 1) * 8 + j1) * B + pos));   // w_n^(r*(j1 + 8*pos))
-    }
-    tile_dft<LOG2B>(x, tw_fwd, L, t);
-    fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
-    if (j1 != 0) {
-        const f29s* sf = seam_fwd + (size_t)j1 * B;
+    for (int q = 0; q < 4; q++) pos[q] = __brev(4 * t + q) >> (32 - LOG2B);
 #pragma unroll
-        for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_montmul(x[q], f29_load_tab(sf + t + q * T))));
-    } else {
+    for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + pos[q]));
+    tile_dft<LOG2B>(x, tw_inv, L, t);
+    __syncthreads();                                   // every wave is done reading the last exchange of the transform
 #pragma unroll
-        for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_reduce_2p(x[q])));
+    for (int q = 0; q < 4; q++) lds_put(L, t + q * T, f29_reduce_2p(x[q]));      // < 2p, normalised
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) cb[q] = lds_get(L, pos[q]);
+#pragma unroll 1
+    for (uint32_t ci = 0; ci < NC; ci++) {
+        const uint32_t r = FULL ? ci + 1 : 2;
+        const f29s* tws = twist + ((size_t)(r - 1) * 8 + j1) * B;
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] = f29_montmul(cb[q], f29_load_tab(tws + pos[q]));       // w_n^(r*(j1 + 8*pos))
+        __syncthreads();                               // the exchange buffer is free again (ownership change / previous coset)
+        tile_dft<LOG2B>(x, tw_fwd, L, t);
+        fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
+        if (j1 != 0) {
+            const f29s* sf = seam_fwd + (size_t)j1 * B;
+#pragma unroll
+            for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_montmul(x[q], f29_load_tab(sf + t + q * T))));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_reduce_2p(x[q])));
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- K3
-// FULL : out row = the codeword, element 4*(q2 + B*q1) + r; the lanes with r = 0 copy the reversed message instead of
-//        running the radix-8 step, so every 128-byte line of the codeword is still written by four adjacent lanes.
-// !FULL: out row = k elements, element q = q2 + B*q1 is P(w_n^(4q + 2)).
-template <int LOG2B, bool FULL>
+// MODE 0 (interleaved): out row = the codeword as the reference lays it out, element 4*(q2 + B*q1) + r; the lanes with r = 0
+//        copy the reversed message instead of running the radix-8 step, so every 128-byte line is written by four
+//        adjacent lanes.  Optional compact copy of coset 2.
+// MODE 1 (half): out row = k elements, element q = q2 + B*q1 is P(w_n^(4q + 2)).
+// MODE 2 (planar): out row = 3k elements, the computed cosets as planes: element (r-1)*k + q is P(w_n^(4q + r)), r = 1, 2, 3.
+//        Coset 0 is not stored at all (it IS the message row, reversed); the batched prover reads its columns from there.
+//        Per row this writes 3k*32 bytes instead of 4k*32 (+ k*32 for the compact coset-2 copy) and does not read the message.
+template <int LOG2B, int MODE>
 __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8,
                                                     const fr* __restrict__ msgs, size_t rows, fr* __restrict__ coset2) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
-    constexpr int LOGNC = FULL ? 2 : 0;
-    constexpr uint32_t NC = FULL ? 3 : 1, OS = FULL ? 4 : 1;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t row = gid >> (LOG2B + LOGNC);
-    if (row >= rows) return;
-    const uint32_t r = FULL ? (uint32_t)gid & 3u : 0u;
-    const uint32_t q2 = ((uint32_t)gid >> LOGNC) & (B - 1);
-    fr* out = cw + row * (OS * (size_t)K);
-    fr v[8];
-    if (FULL && r == 0) {
-        // loads only: the stores below are shared with the other three lanes of the 128-byte line (one full-line write)
-        const fr* m = msgs + row * (size_t)K;
-#pragma unroll
-        for (int q1 = 0; q1 < 8; q1++) v[q1] = fr_load(m + ((K - (q2 + B * q1)) & (K - 1)));
-    } else {
-        const uint32_t ci = FULL ? r - 1 : 0;
-        const fr* z = Z + ((row * NC + ci) * 8) * (size_t)B + q2;
+    if constexpr (MODE == 2) {
+        const uint32_t q2 = (uint32_t)gid & (B - 1);
+        const size_t rc = gid >> LOG2B;                 // row * 3 + coset slot
+        if (rc >= rows * 3) return;
+        const fr* z = Z + (rc * 8) * (size_t)B + q2;
         f29 a[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
         radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
+        fr* out = cw + rc * (size_t)K + q2;
 #pragma unroll
-        for (int q1 = 0; q1 < 8; q1++) v[q1] = pack29(f29_canon(a[q1]));
-    }
+        for (int q1 = 0; q1 < 8; q1++) fr_store(out + (size_t)B * q1, pack29(f29_canon(a[q1])));
+    } else {
+        constexpr bool FULL = MODE == 0;
+        constexpr int LOGNC = FULL ? 2 : 0;
+        constexpr uint32_t NC = FULL ? 3 : 1, OS = FULL ? 4 : 1;
+        const size_t row = gid >> (LOG2B + LOGNC);
+        if (row >= rows) return;
+        const uint32_t r = FULL ? (uint32_t)gid & 3u : 0u;
+        const uint32_t q2 = ((uint32_t)gid >> LOGNC) & (B - 1);
+        fr* out = cw + row * (OS * (size_t)K);
+        fr v[8];
+        if (FULL && r == 0) {
+            // loads only: the stores below are shared with the other three lanes of the 128-byte line (one full-line write)
+            const fr* m = msgs + row * (size_t)K;
 #pragma unroll
-    for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, v[q1]);
-    // optional compact copy of coset 2 (the odd points of <w_n^2>): the stage-2 linear test reads it k-contiguous instead of
-    // fetching every fourth element of the codeword (4x the bytes it uses)
-    if (FULL && coset2 != nullptr && r == 2) {
-        fr* c2 = coset2 + row * (size_t)K;
+            for (int q1 = 0; q1 < 8; q1++) v[q1] = fr_load(m + ((K - (q2 + B * q1)) & (K - 1)));
+        } else {
+            const uint32_t ci = FULL ? r - 1 : 0;
+            const fr* z = Z + ((row * NC + ci) * 8) * (size_t)B + q2;
+            f29 a[8];
 #pragma unroll
-        for (int q1 = 0; q1 < 8; q1++) fr_store(c2 + q2 + (size_t)B * q1, v[q1]);
+            for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
+            radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
+#pragma unroll
+            for (int q1 = 0; q1 < 8; q1++) v[q1] = pack29(f29_canon(a[q1]));
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, v[q1]);
+        if (FULL && coset2 != nullptr && r == 2) {
+            fr* c2 = coset2 + row * (size_t)K;
+#pragma unroll
+            for (int q1 = 0; q1 < 8; q1++) fr_store(c2 + q2 + (size_t)B * q1, v[q1]);
+        }
     }
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 1024 || k == 2048 || k == 4096 || k == 8192; }
 
-template <int LOG2B, bool FULL>
+// mode: 0 = codewords rows x n (reference layout), 1 = rows x k (coset 2 only), 2 = rows x 3k (cosets 1..3 as planes)
+template <int LOG2B>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
-                          hipEvent_t ev0, hipEvent_t ev1, fr* coset2) {
+                          hipEvent_t ev0, hipEvent_t ev1, int mode, fr* coset2) {
     constexpr uint32_t B = 1u << LOG2B;
-    fr* Cc = Y + rows * (size_t)(8 * B);      // second half of the Y scratch (2 * rows * k elements)
     const size_t th1 = rows * B;
-    static const int kmask = [] { const char* e = std::getenv("LIG_ENCODE_KMASK"); return e ? std::atoi(e) : 15; }();   // experiments only
+    static const int kmask = [] { const char* e = std::getenv("LIG_ENCODE_KMASK"); return e ? std::atoi(e) : 15; }();   // experiments only: 1 = K1, 6 = K2, 8 = K3
     if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
-    if (kmask & 2) hipLaunchKernelGGL(k_encode_coef<LOG2B>, dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Cc, ep.tw_b_inv, ep.kinv);
     if (ev0) (void)hipEventRecord(ev0, s);
-    // LIG_K2B_DYN_LDS (experiments only): extra dynamic LDS bytes per workgroup = fewer workgroups per CU (profiles/r02_occupancy_ab.md)
-    static const uint32_t dyn_lds = [] { const char* e = std::getenv("LIG_K2B_DYN_LDS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-    if (kmask & 4) hipLaunchKernelGGL((k_encode_mid<LOG2B, FULL>), dim3((uint32_t)(rows * 8 * (FULL ? 3 : 1))), dim3(B / 4), dyn_lds, s, Cc, Z, ep.tw_b, ep.twist, ep.seam_fwd);
+    if (kmask & 6) {
+        if (mode == 1) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+        else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+    }
     if (ev1) (void)hipEventRecord(ev1, s);
-    const size_t th3 = rows * B * (FULL ? 4 : 1);
-    if (kmask & 8) hipLaunchKernelGGL((k_encode_out<LOG2B, FULL>), dim3((uint32_t)((th3 + 255) / 256)), dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
+    if (!(kmask & 8)) return;
+    const size_t th3 = rows * B * (mode == 0 ? 4 : mode == 1 ? 1 : 3);
+    const dim3 g3((uint32_t)((th3 + 255) / 256));
+    if (mode == 0) hipLaunchKernelGGL((k_encode_out<LOG2B, 0>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
+    else if (mode == 1) hipLaunchKernelGGL((k_encode_out<LOG2B, 1>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
+    else hipLaunchKernelGGL((k_encode_out<LOG2B, 2>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
 }
 
-// half = false: codewords (rows x n).  half = true: rows x k values on the coset w_n^2 <w_n^4>, out[q] = P(w_n^(4q + 2)).
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
-                      hipEvent_t ev0, hipEvent_t ev1, bool half, fr* coset2) {
-    switch (ep.log2B * 2 + (half ? 1 : 0)) {
-        case 12: encode_rows_t<6, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 13: encode_rows_t<6, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 14: encode_rows_t<7, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 15: encode_rows_t<7, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 18: encode_rows_t<9, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 19: encode_rows_t<9, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 16: encode_rows_t<8, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 17: encode_rows_t<8, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 20: encode_rows_t<10, true>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
-        case 21: encode_rows_t<10, false>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, coset2); break;
+                      hipEvent_t ev0, hipEvent_t ev1, int mode, fr* coset2) {
+    switch (ep.log2B) {
+        case 6: encode_rows_t<6>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
+        case 7: encode_rows_t<7>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
+        case 8: encode_rows_t<8>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
+        case 9: encode_rows_t<9>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
+        case 10: encode_rows_t<10>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
         default: break;
     }
 }

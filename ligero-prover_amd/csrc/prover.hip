@@ -37,8 +37,9 @@ struct lig_trace {
     lig_proof_info info1;               // stage-1 results kept between lig_rows_commit and lig_rows_prove
     size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
-    fr* cw = nullptr;                   // (R+3) x n codewords, resident across the stages
-    fr* c2 = nullptr;                   // R x k compact copy of codeword coset 2 (elements 4q + 2): the stage-2 linear test reads it
+    fr* cw = nullptr;                   // R x 3k: cosets 1..3 of every codeword as planes (lig::ENC_PLANAR), resident across the stages;
+                                        // coset 0 of a codeword is its message row reversed and is read from `msgs` (lig::CwView)
+    fr* maskcw = nullptr;               // 3 x n: the mask rows' codewords, reference layout
     fr* randb = nullptr;                // chunk x k randomness rows
     fr* rcw = nullptr;                  // chunk x n their codewords
     fr* acc = nullptr;                  // code | lin | quad | tmp   (4 x n)
@@ -176,8 +177,8 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     const size_t chunk = lig_tune::CHUNK, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
-    TRY(dm((void**)&T->cw, (R + 3) * (size_t)n * 32));
-    TRY(dm((void**)&T->c2, (R ? R : 1) * (size_t)k * 32));
+    TRY(dm((void**)&T->cw, (R ? R : 1) * 3 * (size_t)k * 32));
+    TRY(dm((void**)&T->maskcw, 3 * (size_t)n * 32));
     TRY(dm((void**)&T->randb, 2 * chunk * (size_t)k * 32));          // double-buffered
     TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
     TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
@@ -226,7 +227,7 @@ static bool instance_hash_of(const uint8_t* args, const uint64_t* lens, uint64_t
 static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<void(const char*)>& mark) {
     lig_ctx* c = T->c;
     const uint32_t l = c->l, k = c->k, n = c->n, pad = k - l;
-    const size_t R = T->R;
+    const size_t k3 = 3 * (size_t)k;
     hipStream_t s = c->stream;
     uint32_t rk[60];
     lig::aes256_expand_host(T->encoding_seed, rk);
@@ -237,7 +238,7 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
             lig::launch_rng_fill_rows(s, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
     mark("  pads");
     uint64_t epos = T->mask_pos;
-    fr* mask = T->cw + R * (size_t)n;                                                               // the 3 mask rows are formed in place
+    fr* mask = T->maskcw;                                                                           // the 3 mask rows are formed in place
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;               // code mask: l randoms, zeros to k
     fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
@@ -272,32 +273,32 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
                 lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
             }
         }
-        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * n, nb, false, s_enc, T->c2 + b * (size_t)k));
+        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, lig::ENC_PLANAR, s_enc));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
         static const int gate = [] { const char* e = std::getenv("LIG_SHA_GATE"); return e ? std::atoi(e) : 1; }();
         if (gate && nb > 4) {
             // the hash waves must be placed while the chip is idle (one per SIMD, evenly): hash the first two rows, let the
             // encode stream wait for that, and queue the rest of the chunk right behind it on the hash stream
-            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, 2, absorbed);
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, 2, absorbed, k, T->msgs + b * k);
             HIP_TRY(c, hipEventRecord(T->ev_gate, s_sha));
-            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + (b + 2) * n, n, nb - 2, absorbed + 2);
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + (b + 2) * k3, 0, nb - 2, absorbed + 2, k, T->msgs + (b + 2) * k);
             HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_gate, 0));
         } else {
-            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * n, n, nb, absorbed);
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, nb, absorbed, k, T->msgs + b * k);
         }
         absorbed += nb;
     }
     mark("encode message rows");
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
-    lig::launch_sha_update_rows(s_sha, T->sha_state, n, mask, n, 3, absorbed);
+    lig::launch_sha_update_rows(s_sha, T->sha_state, n, mask, n, 3, absorbed, k, nullptr);     // same plane-major instances, interleaved rows
     absorbed += 3;
     c->sha[T->sha_state].second = absorbed;
     HIP_TRY(c, hipEventRecord(c->ev_join, s_sha));
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     mark("encode mask rows + column sha tail");
-    TRY(lig_sha_final(c, T->sha_state, T->leaves));
+    lig::launch_sha_final(s, T->sha_state, n, absorbed, T->leaves, k);       // plane-major instances -> leaves in column order
     TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -398,7 +399,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        lig::launch_rlc_accumulate29(s, T->c2 + b * (size_t)k, k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);
+        lig::launch_rlc_accumulate29(s, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);   // plane of coset 2
         lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
@@ -412,11 +413,12 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     lig::launch_sum_elems(s, linH, k, 1, T->dots, nullptr);       // sum of all <witness row, randomness row> (prover_kernels.hip)
     lig::launch_lin_interleave(s, lin, linH, linC, k);
     HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));
-    lig::launch_quad_rows29(s, T->cw, n, 2, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
+    const lig::CwView view{T->msgs, T->cw, k};
+    lig::launch_quad_rows29_view(s, view, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
     // Each accumulator is extended to the n evaluation points, masked (nonbatch_context.hpp:739-753) and sent to the host
     // as soon as it is final; the host absorbs it into the stage-2 seed hash (a sequential SHA-256 over 3 MiB, the longest
     // host step of the proof) while the GPU extends the next one.
-    fr* mask = T->cw + R * (size_t)n; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
+    fr* mask = T->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
     uint8_t* enc = T->h_enc;
     const size_t vec_bytes = (size_t)n * 32;
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
@@ -466,7 +468,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // runs while the host derives the decommitment (the Merkle nodes were downloaded in stage 1) and lays out the envelope;
     // the opened columns then land in place while the host evaluates the self-check predicates.
     TRY(lig_sample_init(c, idx.data(), idx.size()));
-    TRY(lig_gather_rows(c, T->cw, R + 3, T->samples));
+    lig::launch_gather_rows_planar(s, view, R, c->sample_idx, t, T->samples);
+    lig::launch_gather_rows(s, T->maskcw, n, 3, c->sample_idx, t, T->samples + R * (size_t)t);
     const size_t n_nodes = lig_merkle_nodes(n);
     const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
     const size_t smp_bytes = (R + 3) * (size_t)t * 32;
@@ -557,7 +560,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream2);
     (void)hipStreamSynchronize(T->c->stream3);
     T->c->sha.erase(T->sha_state);
-    for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->c2, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
+    for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);

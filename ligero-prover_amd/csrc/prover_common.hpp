@@ -26,6 +26,8 @@ void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, con
                        const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
+void launch_quad_rows29_view(hipStream_t s, CwView cw, uint32_t count, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
+                             size_t n_triples, fr* quad);
 void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out, fr* neg_out);
 void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
                              const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows);

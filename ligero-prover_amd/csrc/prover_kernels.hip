@@ -52,7 +52,12 @@ __global__ void __launch_bounds__(256) k_rlc_combine(fr* __restrict__ acc, const
 }
 
 // quad[j] += sum_t rq[t] * (U[x_t][j*ues] * U[y_t][j*ues] - U[z_t][j*ues]);  rq2 = rq*R'^2, rq1 = rq*R' (per triple)
-__global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, size_t urs, uint32_t ues, uint32_t count,
+// Src: where element j of a row lives.  StridedRows = rows of any stride / element stride; EvenOfView = the order-2k subgroup
+// <w_n^2> (codeword elements 2j) of a CwView: even j from the message row, odd j from the coset-2 plane.
+struct StridedRows { const fr* U; size_t urs; uint32_t ues; __device__ const fr* at(size_t row, uint32_t j) const { return U + row * urs + (size_t)j * ues; } };
+struct EvenOfView { CwView v; __device__ const fr* at(size_t row, uint32_t j) const { return v.at(row, 2 * j); } };
+template <class Src>
+__global__ void __launch_bounds__(256) k_quad_rows(Src src, uint32_t count,
                                                    const uint32_t* __restrict__ triples, const f29s* __restrict__ rq2,
                                                    const f29s* __restrict__ rq1, size_t n_triples, fr* __restrict__ quad) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,11 +65,11 @@ __global__ void __launch_bounds__(256) k_quad_rows(const fr* __restrict__ U, siz
     f29 a = unpack29(fr_load(quad + j));
     for (size_t t = 0; t < n_triples; t++) {
         const uint32_t yi = triples[3 * t + 1];
-        const f29 x = unpack29(fr_load(U + (size_t)triples[3 * t] * urs + (size_t)j * ues));
-        const f29 z = unpack29(fr_load(U + (size_t)triples[3 * t + 2] * urs + (size_t)j * ues));
+        const f29 x = unpack29(fr_load(src.at(triples[3 * t], j)));
+        const f29 z = unpack29(fr_load(src.at(triples[3 * t + 2], j)));
         // y index 0xFFFFFFFF: the equality term rq * (x - z) of on_batch_equal (nonbatch_context.hpp:811-825), i.e. y = 1
         const f29 xy = yi == 0xFFFFFFFFu ? f29_montmul(x, f29_load_tab(rq1 + t))
-                                         : f29_montmul(f29_montmul(x, unpack29(fr_load(U + (size_t)yi * urs + (size_t)j * ues))), f29_load_tab(rq2 + t));      // x*y*rq  (< 1.2p)
+                                         : f29_montmul(f29_montmul(x, unpack29(fr_load(src.at(yi, j)))), f29_load_tab(rq2 + t));      // x*y*rq  (< 1.2p)
         const f29 zq = f29_montmul(z, f29_load_tab(rq1 + t));                       // z*rq    (< 1.2p)
         a = f29_add(a, f29_add(xy, f29_sub_k2(f29_zero(), zq)));                    // + xy + (2p - zq)
         a = f29_reduce_2p(a);
@@ -97,7 +102,13 @@ void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups,
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
                         const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad) {
     if (!n_triples) return;
-    hipLaunchKernelGGL(k_quad_rows, dim3((count + 255) / 256), dim3(256), 0, s, U, urs, ues, count, triples_dev, rq2, rq1, n_triples, quad);
+    hipLaunchKernelGGL(k_quad_rows<StridedRows>, dim3((count + 255) / 256), dim3(256), 0, s, StridedRows{U, urs, ues}, count, triples_dev, rq2, rq1, n_triples, quad);
+}
+// the same sum over the 2k even codeword positions of a planar codeword matrix
+void launch_quad_rows29_view(hipStream_t s, CwView cw, uint32_t count, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
+                             size_t n_triples, fr* quad) {
+    if (!n_triples) return;
+    hipLaunchKernelGGL(k_quad_rows<EvenOfView>, dim3((count + 255) / 256), dim3(256), 0, s, EvenOfView{cw}, count, triples_dev, rq2, rq1, n_triples, quad);
 }
 
 // ---------------------------------------------------------------------------------------------- linear-test constant

@@ -64,9 +64,13 @@ __global__ void k_sha_init(uint32_t* __restrict__ st, size_t n_inst) {
     }
 }
 
-// absorb nrows rows (row r at rows + r*row_stride, element j = column j); rows_before = rows absorbed so far
+// absorb nrows rows; rows_before = rows absorbed so far.  Instance j hashes one codeword column:
+//   pk == 0                : column j of `rows` (row r at rows + r*row_stride)                      -- the ABI form
+//   pk == k, msgs == null  : PLANE-MAJOR instances: j = r*k + q is column 4q + r of `rows` (interleaved rows, e.g. the masks)
+//   pk == k, msgs != null  : plane-major instances over a CwView: coset 0 from the message rows (reversed), cosets 1..3 from
+//                            the planes in `rows` (rows x 3k); a wave reads 2 KiB contiguous per row
 __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, const fr* __restrict__ rows, size_t row_stride,
-                                  size_t nrows, uint64_t rows_before) {
+                                  size_t nrows, uint64_t rows_before, uint32_t pk, const fr* __restrict__ msgs) {
     // The column chain is sequential in rows: this kernel is latency-bound with only n_inst/64 waves and usually runs
     // next to an encode kernel on the side stream.  Highest wave priority lets it issue whenever it is ready, so its
     // critical path stays close to the stand-alone one while the encode waves fill the remaining issue slots.
@@ -83,6 +87,14 @@ __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, cons
     // (about a quarter of a compression for a lone wave) is covered by the ~1470 instructions of the rounds.
     const size_t pend = (size_t)(rows_before & 1);
     const size_t total = nrows + pend;
+    const fr* p0 = rows + j;                               // this column's element of row 0, and its row stride
+    size_t rs = row_stride;
+    if (pk) {
+        const uint32_t r = (uint32_t)j / pk, q = (uint32_t)j - r * pk;
+        if (msgs == nullptr) p0 = rows + 4 * (size_t)q + r;
+        else if (r == 0) { p0 = msgs + ((pk - q) & (pk - 1)); rs = pk; }
+        else { p0 = rows + (size_t)(r - 1) * pk + q; rs = 3 * (size_t)pk; }
+    }
     auto elem = [&](size_t v) -> fr {                      // virtual element v
         if (v == 0 && pend) {
             fr e;
@@ -90,7 +102,7 @@ __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, cons
             for (int i = 0; i < 8; i++) e.v[i] = st[(size_t)(8 + i) * n_inst + j];
             return e;
         }
-        return fr_load(rows + (v - pend) * row_stride + j);
+        return fr_load(p0 + (v - pend) * rs);
     };
     fr n0 = fr_zero(), n1 = fr_zero();
     if (total >= 2) { n0 = elem(0); n1 = elem(1); }
@@ -104,7 +116,7 @@ __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, cons
         if (total == 1 && pend) {
             // nothing new absorbed (nrows == 0 is filtered by the launcher); unreachable, kept for clarity
         } else {
-            const fr e = fr_load(rows + (total - 1 - pend) * row_stride + j);
+            const fr e = fr_load(p0 + (total - 1 - pend) * rs);
 #pragma unroll
             for (int i = 0; i < 8; i++) st[(size_t)(8 + i) * n_inst + j] = e.v[i];
         }
@@ -114,7 +126,8 @@ __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, cons
 }
 
 // padding + length (shader/sha256.wgsl:180-224); does not modify the state
-__global__ void k_sha_final(const uint32_t* __restrict__ st, size_t n_inst, uint64_t rows_total, uint32_t* __restrict__ digests) {
+// pk != 0: plane-major instances (see k_sha_update_rows): instance j = r*pk + q is leaf 4q + r
+__global__ void k_sha_final(const uint32_t* __restrict__ st, size_t n_inst, uint64_t rows_total, uint32_t* __restrict__ digests, uint32_t pk) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_inst) return;
     uint32_t h[8], w[16];
@@ -133,7 +146,8 @@ __global__ void k_sha_final(const uint32_t* __restrict__ st, size_t n_inst, uint
     w[14] = (uint32_t)(bits >> 32);
     w[15] = (uint32_t)bits;
     sha256_compress(h, w);
-    uint4* out = reinterpret_cast<uint4*>(digests + 8 * j);
+    const size_t leaf = pk ? 4 * (j % pk) + j / pk : j;
+    uint4* out = reinterpret_cast<uint4*>(digests + 8 * leaf);
     out[0] = make_uint4(h[0], h[1], h[2], h[3]);
     out[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
@@ -142,7 +156,7 @@ void launch_sha_init(hipStream_t s, uint32_t* state, size_t n_inst) {
     hipLaunchKernelGGL(k_sha_init, dim3((uint32_t)((n_inst + 255) / 256)), dim3(256), 0, s, state, n_inst);
 }
 void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const fr* rows, size_t row_stride, size_t nrows,
-                            uint64_t rows_before) {
+                            uint64_t rows_before, uint32_t plane_k, const fr* msgs) {
     if (!nrows) return;
     // 256-thread workgroups = one hash wave on each of the 4 SIMDs of a CU: a hash wave keeps ~65% of its SIMD's VALU busy,
     // and the encode workgroups that share the chip finish with their slowest wave, so the hash load has to be the same
@@ -150,10 +164,10 @@ void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const
     // 256-thread ones; tools/corun_bench.py).  LIG_SHA_BLOCK overrides for experiments.
     static const uint32_t bs = [] { const char* e = std::getenv("LIG_SHA_BLOCK"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t)v : 256u; }();
     hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + bs - 1) / bs)), dim3(bs), 0, s, state, n_inst, rows, row_stride,
-                       nrows, rows_before);
+                       nrows, rows_before, plane_k, msgs);
 }
-void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests) {
-    hipLaunchKernelGGL(k_sha_final, dim3((uint32_t)((n_inst + 63) / 64)), dim3(64), 0, s, state, n_inst, rows_total, digests);
+void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests, uint32_t plane_k) {
+    hipLaunchKernelGGL(k_sha_final, dim3((uint32_t)((n_inst + 63) / 64)), dim3(64), 0, s, state, n_inst, rows_total, digests, plane_k);
 }
 
 // ---- Merkle tree: node[i] = SHA256(node[2i+1] || node[2i+2]) over canonical digest BYTES

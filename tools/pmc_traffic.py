@@ -15,11 +15,11 @@ K, N, B = 8192, 32768, 1024
 # kernel -> work-items per row (grid size / this = rows in the launch)
 ITEMS = {
     "k_encode_in<10>": B,
-    "k_encode_coef<10>": 8 * (B // 4),
-    "k_encode_mid<10, true>": 3 * 8 * (B // 4),
-    "k_encode_mid<10, false>": 8 * (B // 4),
-    "k_encode_out<10, true>": 4 * B,
-    "k_encode_out<10, false>": B,
+    "k_encode_tiles<10, true>": 8 * (B // 4),
+    "k_encode_tiles<10, false>": 8 * (B // 4),
+    "k_encode_out<10, 0>": 4 * B,
+    "k_encode_out<10, 1>": B,
+    "k_encode_out<10, 2>": 3 * B,
 }
 
 
