@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
 // forward tile transform per coset) without leaving the CU.  Between the two, the tile changes ownership once through
 // LDS: the inverse transform leaves thread t with coefficients t + q*T, the forward transforms start from the bit-reversed
 // positions brev(4t + q).  The C scratch matrix (k*32 bytes written + read per row) and one launch are gone; the price is
-// 36 more live registers (the coefficients stay in VGPRs across the NC transforms).
+// 36 more live registers (the coefficients stay in VGPRs across the NC transforms): 134 VGPRs = 3 waves per SIMD instead of
+// 4 (measured: forcing 128 registers, with 3 spilled dwords, is not faster; profiles/r02_fused_tiles_ab.md).
 #ifndef LIG_K2_WAVES
 #define LIG_K2_WAVES 3
 #endif
@@ -80,34 +81,36 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
     const size_t row = blockIdx.x >> 3;
     const fr* y = Y + (size_t)blockIdx.x * B;
     f29 x[4], cb[4];
-    uint32_t pos[4];
+    auto pos = [t](int q) { return __brev(4 * t + q) >> (32 - LOG2B); };
 #pragma unroll
-    for (int q = 0; q < 4; q++) pos[q] = __brev(4 * t + q) >> (32 - LOG2B);
-#pragma unroll
-    for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + pos[q]));
+    for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + pos(q)));
     tile_dft<LOG2B>(x, tw_inv, L, t);
     __syncthreads();                                   // every wave is done reading the last exchange of the transform
 #pragma unroll
     for (int q = 0; q < 4; q++) lds_put(L, t + q * T, f29_reduce_2p(x[q]));      // < 2p, normalised
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; q++) cb[q] = lds_get(L, pos[q]);
+    for (int q = 0; q < 4; q++) cb[q] = lds_get(L, pos(q));
 #pragma unroll 1
     for (uint32_t ci = 0; ci < NC; ci++) {
         const uint32_t r = FULL ? ci + 1 : 2;
         const f29s* tws = twist + ((size_t)(r - 1) * 8 + j1) * B;
+        // the thread index is made opaque once per coset: otherwise every t-dependent table / store address of the loop body is
+        // hoisted into 64-bit register pairs that do not fit next to the coefficients and end up in scratch memory
+        uint32_t tt = t;
+        asm volatile("" : "+v"(tt));
 #pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = f29_montmul(cb[q], f29_load_tab(tws + pos[q]));       // w_n^(r*(j1 + 8*pos))
+        for (int q = 0; q < 4; q++) x[q] = f29_montmul(cb[q], f29_load_tab(tws + (__brev(4 * tt + q) >> (32 - LOG2B))));   // w_n^(r*(j1 + 8*pos))
         __syncthreads();                               // the exchange buffer is free again (ownership change / previous coset)
-        tile_dft<LOG2B>(x, tw_fwd, L, t);
+        tile_dft<LOG2B>(x, tw_fwd, L, tt);
         fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
         if (j1 != 0) {
             const f29s* sf = seam_fwd + (size_t)j1 * B;
 #pragma unroll
-            for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_montmul(x[q], f29_load_tab(sf + t + q * T))));
+            for (int q = 0; q < 4; q++) fr_store(z + tt + q * T, pack29(f29_montmul(x[q], f29_load_tab(sf + tt + q * T))));
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) fr_store(z + t + q * T, pack29(f29_reduce_2p(x[q])));
+            for (int q = 0; q < 4; q++) fr_store(z + tt + q * T, pack29(f29_reduce_2p(x[q])));
         }
     }
 }
