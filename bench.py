@@ -28,6 +28,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 L_, K_, N_, T_ = 8000, 8192, 32768, 192
+NO_VERIFY = False
 
 
 def load_pkg():
@@ -138,19 +139,21 @@ class FullWorkload:
             d.update(proof_bytes=len(proof), proof_sha256=hashlib.sha256(proof).hexdigest(),
                      stage_ms={"stage1": self.last[2], "stage2": self.last[3], "stage3": self.last[4]},
                      proof_latency_ms=self.last[5])
-            # outside the timed region: the HIP verifier on that proof (informational)
+            # outside the timed region: the HIP verifier on that proof (informational; --no-verify skips it so that a
+            # profiler run of this command sees the prover's kernel launches only)
             pkg = sys.modules["ligero_prover_amd"]
             job = pkg.Context.make_job(self.constraints_per_trace, 0, synth_seed=1, generated_at=0)
             info = self.last_info
-            self.ctx.synth_verify(job, None, proof)            # first call: its buffers are allocated right after the workloads freed theirs
-            best = None
-            for _ in range(3):                                 # the verifier derives the linear constant from the public statement
-                t0 = time.perf_counter()
-                v = self.ctx.synth_verify(job, None, proof)
-                wall = 1e3 * (time.perf_counter() - t0)
-                if best is None or v.ms_total < best[0]:
-                    best = (v.ms_total, wall, bool(v.accept))
-            d.update(verifier_accepts=best[2], verify_ms=best[0], verify_ms_with_python_copies=best[1])
+            if not NO_VERIFY:
+                self.ctx.synth_verify(job, None, proof)            # first call: its buffers are allocated right after the workloads freed theirs
+                best = None
+                for _ in range(3):                                 # the verifier derives the linear constant from the public statement
+                    t0 = time.perf_counter()
+                    v = self.ctx.synth_verify(job, None, proof)
+                    wall = 1e3 * (time.perf_counter() - t0)
+                    if best is None or v.ms_total < best[0]:
+                        best = (v.ms_total, wall, bool(v.accept))
+                d.update(verifier_accepts=best[2], verify_ms=best[0], verify_ms_with_python_copies=best[1])
             pin_path = os.path.join(ROOT, "tests", "golden", "full_pin_2p%d.json" % lg)
             if os.path.exists(pin_path):                      # the oracle's reference-structured prover on this exact job
                 with open(pin_path) as f:
@@ -337,11 +340,14 @@ def main():
     ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded"])
     ap.add_argument("--log2-constraints", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the (untimed, informational) HIP verifier run on the last proof")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive second measurement (value_incl_h2d)")
     ap.add_argument("--h2d-inflight", type=int, default=1, help="traces in flight for the PCIe-inclusive measurement (one context "
                     "already pipelines upload i+1 under proof i; two contexts share the PCIe link and were measured slower)")
     ap.add_argument("--inflight", type=int, default=2, help="full workload: proofs (traces) proved concurrently per GPU in one step")
     a = ap.parse_args()
+    global NO_VERIFY
+    NO_VERIFY = a.no_verify
     log2c = a.log2_constraints if a.log2_constraints is not None else (20 if a.workload == "encode" else 24)
 
     import torch
