@@ -6,8 +6,10 @@
 //
 // The committed rows are cut into G = W * rounds global chunks (<= 512 rows, equal sizes, never splitting an x,y,z
 // triple or an equality pair) and dealt block-cyclically: chunk g belongs to rank g mod W, so the local rows of a rank are
-// its chunks r, r+W, r+2W, ...; every rank forms, encodes and keeps only those.  leaf_j hashes ALL rows in commit order, so
-// the hash is column-partitioned (rank h owns columns [h*n/W, (h+1)*n/W)): in round c every rank sends the column slices
+// its chunks r, r+W, r+2W, ...; every rank forms, encodes and keeps only those (codewords as three coset planes + the message
+// rows, like the single-GPU prover: lig::CwView).  leaf_j hashes ALL rows in commit order, so
+// the hash is column-partitioned (rank h owns columns [h*n/W, (h+1)*n/W), i.e. positions q in [h*k/W, (h+1)*k/W) of all four
+// cosets): in round c every rank sends the column slices
 // of its c-th chunk to their owners -- ONE all-to-all per round -- and receives the W consecutive global chunks
 // cW .. cW+W-1 restricted to its columns, in rank order = commit order.  The column hash therefore runs in commit order
 // from the first round on, on the side stream, while the main stream encodes round c+1 and the copy stream exchanges it:
@@ -32,7 +34,7 @@ struct lig_shard {
     std::vector<uint64_t> code_ord, pad_ord;   // code-test draws / pad draws before every global row (+1 entry)
     size_t RB = 0, n_init = 0;                 // leading rows committed by the batch program, of those: init rows
     size_t R = 0, Rl = 0, rows_max = 0, ncol = 0, rounds = 0, G = 0, ch_cap = 0;
-    fr *msgs = nullptr, *cw = nullptr, *send = nullptr, *recv = nullptr, *randb = nullptr, *rhalf = nullptr, *acc = nullptr,
+    fr *msgs = nullptr, *cw = nullptr, *maskcw = nullptr, *send = nullptr, *recv = nullptr, *randb = nullptr, *rhalf = nullptr, *acc = nullptr,
        *parts = nullptr, *accp = nullptr, *accg = nullptr, *dots = nullptr, *smp = nullptr, *smpg = nullptr;
     uint32_t *sha_state = nullptr, *leaves_slice = nullptr, *leaves = nullptr, *nodes = nullptr, *tri_dev = nullptr;
     lig::f29s* coef_dev = nullptr;
@@ -47,12 +49,16 @@ struct lig_shard {
 };
 
 namespace lig {
-// out[h][r][j] = cw[r][h*ncol + j]: the column slices of `rows` codewords, one block of cap_rows x ncol per destination rank
-__global__ void __launch_bounds__(256) k_pack_slices(const fr* __restrict__ cw, size_t n, fr* __restrict__ out, size_t rows, size_t ncol, size_t cap_rows) {
-    const size_t total = rows * n;
+// The column slices of `rows` codewords, one block of cap_rows x ncol per destination rank h.  Inside a row of a block the
+// ncol = 4*kq columns of rank h are PLANE-MAJOR: element c*kq + ql = codeword column 4*(h*kq + ql) + c, so that both sides
+// move contiguous runs (reads: runs of kq elements of one plane / of the message row; the receiver's column hash then reads
+// 32-byte neighbours) and instance j of the receiver's hash state is simply element j of every received row.
+__global__ void __launch_bounds__(256) k_pack_slices(CwView cw, fr* __restrict__ out, size_t rows, size_t kq, size_t cap_rows) {
+    const size_t n = 4 * (size_t)cw.k, ncol = 4 * kq, total = rows * n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / n, j = i - r * n, h = j / ncol;
-        fr_store(out + (h * cap_rows + r) * ncol + (j - h * ncol), fr_load(cw + i));
+        const size_t r = i / n, j = i - r * n;                  // j: position in the row of blocks = h*ncol + c*kq + ql
+        const size_t h = j / ncol, e = j - h * ncol, c = e / kq, ql = e - c * kq;
+        fr_store(out + (h * cap_rows + r) * ncol + e, fr_load(cw.at(r, (uint32_t)(4 * (h * kq + ql) + c))));
     }
 }
 }  // namespace lig
@@ -120,7 +126,7 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
 }
 static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S) {
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192, W = world;
-    if (l >= k || l < 2 || t > n || k - l < t || n % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | n");
+    if (l >= k || l < 2 || t > n || k - l < t || k % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | k");
     S->ncol = n / world;
     S->exchange_even_alone = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
     if (!plan_rows(*job, l, S->rows, S->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
@@ -168,7 +174,8 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
     const size_t chunk = S->ch_cap;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&S->msgs, (Rl ? Rl : 1) * (size_t)k * 32));
-    TRY(dm((void**)&S->cw, (Rl + 3) * (size_t)n * 32));
+    TRY(dm((void**)&S->cw, (Rl ? Rl : 1) * 3 * (size_t)k * 32));      // cosets 1..3 of the local codewords as planes
+    TRY(dm((void**)&S->maskcw, 3 * (size_t)n * 32));                  // the mask rows' codewords, reference layout
     TRY(dm((void**)&S->send, 2 * chunk * (size_t)n * 32));          // double-buffered: W blocks of chunk x ncol each
     TRY(dm((void**)&S->recv, 2 * chunk * (size_t)n * 32));
     TRY(dm((void**)&S->randb, 2 * chunk * (size_t)k * 32));         // double-buffered
@@ -238,7 +245,7 @@ void lig_shard_destroy(lig_shard* S) {
     (void)hipStreamSynchronize(S->c->stream2);
     (void)hipStreamSynchronize(S->c->stream3);
     S->c->sha.erase(S->sha_state);
-    for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
+    for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->maskcw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
                     (void*)S->parts, (void*)S->accp, (void*)S->accg, (void*)S->dots, (void*)S->smp, (void*)S->smpg, (void*)S->sha_state,
                     (void*)S->leaves_slice, (void*)S->leaves, (void*)S->nodes, (void*)S->tri_dev, (void*)S->coef_dev})
         (void)hipFree(p);
@@ -284,7 +291,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         lr += run;
     }
     uint64_t epos = S->pad_ord[R] * pad;
-    fr* mask = S->cw + Rl * (size_t)n; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;           // masks: formed by every rank
+    fr* mask = S->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;                        // masks: formed by every rank
+    const size_t k3 = 3 * (size_t)k, kq = ncol / 4;                                                      // kq = positions per coset of a rank's columns
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mask, 1, l, 0, 0, 1, 0); epos += l;
     lig::launch_rng_fill_rows(s, c->rk_dev, epos, mlin, 1, l - 1, 0, 1, 2, 0); epos += l - 1;
@@ -306,10 +314,10 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         const int pb = (int)(cidx & 1);
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
         fr* sendb = S->send + (size_t)pb * CAP * n; fr* recvb = S->recv + (size_t)pb * CAP * n;
-        if (nb) TRY(lig_internal_encode_rows(c, S->msgs + lb * (size_t)k, S->cw + lb * (size_t)n, nb, false, s));
+        if (nb) TRY(lig_internal_encode_rows(c, S->msgs + lb * (size_t)k, S->cw + lb * k3, nb, lig::ENC_PLANAR, s));
         if (exchange) {
             if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s, S->ev_comm[pb], 0));          // send buffer free again (exchange c-2 done)
-            if (nb) hipLaunchKernelGGL(lig::k_pack_slices, dim3(2048), dim3(256), 0, s, S->cw + lb * (size_t)n, (size_t)n, sendb, nb, ncol, CAP);
+            if (nb) hipLaunchKernelGGL(lig::k_pack_slices, dim3(2048), dim3(256), 0, s, lig::CwView{S->msgs + lb * (size_t)k, S->cw + lb * k3, k}, sendb, nb, kq, CAP);
         }
         HIP_TRY(c, hipEventRecord(S->ev_enc[pb], s));
         if (exchange) {
@@ -332,12 +340,12 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
             }
         } else {                                             // one rank: its codewords are the rows, all columns are its own
             HIP_TRY(c, hipStreamWaitEvent(s_hash, S->ev_enc[pb], 0));
-            if (nb) lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, S->cw + lb * (size_t)n, n, nb, absorbed);
+            if (nb) lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, S->cw + lb * k3, 0, nb, absorbed, k, S->msgs + lb * (size_t)k);
             absorbed += nb;
         }
         HIP_TRY(c, hipEventRecord(S->ev_hash[pb], s_hash));
     }
-    lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, mask + (size_t)S->rank * ncol, n, 3, absorbed);
+    lig::launch_sha_update_rows(s_hash, S->sha_state, ncol, mask + (size_t)S->rank * ncol, n, 3, absorbed, (uint32_t)kq, nullptr);   // plane-major instances over interleaved rows
     absorbed += 3;
     c->sha[S->sha_state].second = absorbed;
     HIP_TRY(c, hipEventRecord(c->ev_join, s_hash));
@@ -346,7 +354,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_comm));
         HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     }
-    TRY(lig_sha_final(c, S->sha_state, S->leaves_slice));
+    lig::launch_sha_final(s, S->sha_state, ncol, absorbed, S->leaves_slice, (uint32_t)kq);      // plane-major instances -> the rank's leaves in column order
     TRY(all_gather(S->leaves_slice, S->leaves, ncol * 32, s, "all_gather(leaves)"));
     TRY(lig_merkle_build(c, S->leaves, n, S->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
@@ -405,7 +413,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         HIP_TRY(c, hipStreamWaitEvent(s, S->ev_enc[cidx & 1], 0));
         if (nb) {
             TRY(lig_internal_encode_rows(c, rb, S->rhalf, nb, true));
-            lig::launch_rlc_accumulate29(s, S->cw + lb * (size_t)n + 2, n, 4, S->rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);
+            lig::launch_rlc_accumulate29(s, S->cw + lb * 3 * (size_t)k + k, 3 * (size_t)k, 1, S->rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);   // plane of coset 2
             lig::launch_rlc_accumulate29(s, S->msgs + lb * (size_t)k, k, 1, rb, k, nb, k, S->coef_dev + lb, p_code, p_linH, lig_tune::GROUP / 4);
         }
         HIP_TRY(c, hipEventRecord(S->ev_comm[cidx & 1], s));
@@ -414,7 +422,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_rlc_combine(s, linH, p_linH, pg, k);
     lig::launch_rlc_combine(s, linC, p_linC, pg, k);
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
-    lig::launch_quad_rows29(s, S->cw, n, 2, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
+    const lig::CwView view{S->msgs, S->cw, k};
+    lig::launch_quad_rows29_view(s, view, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
     // partial sums [code (k message values) | lin (2k) | quad (2k)] -> every rank -> added mod p (one rank: they are the sums)
     if (W > 1 || S->exchange_even_alone) {
         HIP_TRY(c, hipMemcpyAsync(S->accp, tmp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
@@ -492,7 +501,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     t0 = clk::now();
 
     // ---------------- stage 3
-    TRY(lig_gather_rows(c, S->cw, Rl + 3, S->smp));                  // local rows, then the 3 masks
+    lig::launch_gather_rows_planar(s, view, Rl, c->sample_idx, t, S->smp);                      // local rows, then the 3 masks
+    lig::launch_gather_rows(s, S->maskcw, n, 3, c->sample_idx, t, S->smp + Rl * (size_t)t);
     TRY(all_gather(S->smp, S->smpg, RM * (size_t)t * 32, s, "all_gather(opened columns)"));
     char ver[17] = {0};
     std::memcpy(ver, S->job.version, 16);

@@ -261,10 +261,10 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
         fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(sample_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, ev_ready[ci & 1], 0));
-        TRY(lig_internal_encode_rows(c, rb, drcw, nb, false));
+        TRY(lig_internal_encode_rows(c, rb, drcw, nb, lig::ENC_PLANAR));      // cosets 1..3 as planes; coset 0 is the row itself
         if (derive) lig::launch_rlc_accumulate29(s, dW + b * k, k, 1, rb, k, nb, k, nullptr, nullptr, dpl + k, lig_tune::GROUP / 4);   // sum_r b_r o rho_r
-        HIP_TRY(c, hipEventRecord(ev_used[ci & 1], s));
-        TRY(lig_gather_rows(c, drcw, nb, drg + b * t));
+        lig::launch_gather_rows_planar(s, lig::CwView{rb, drcw, k}, nb, c->sample_idx, t, drg + b * t);
+        HIP_TRY(c, hipEventRecord(ev_used[ci & 1], s));      // the gather still reads the rows themselves (coset 0)
     }
     // code / linear accumulators on the 192 opened positions: one pass per 4096 rows after the encodes (only 192 columns wide:
     // inside the loop it was a latency-bound 8-workgroup launch per chunk that the next encode had to wait for)
