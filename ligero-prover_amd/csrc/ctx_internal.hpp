@@ -47,7 +47,8 @@ struct lig_ctx {
 };
 
 // mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes)
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr, void* coset2 = nullptr);
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr);
+int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on = nullptr);
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
 // decode_ntt_device of `src` (n elements, left intact) into `dst` (n elements, != src), on the context stream
 int lig_internal_decode_to(lig_ctx* c, const void* src, void* dst);

@@ -51,13 +51,17 @@ void ntt_generic_fold(hipStream_t s, fr* buf, uint32_t half, size_t rows, size_t
 bool encode_fast_supported(uint32_t k);
 // ev0/ev1 (optional): HIP events recorded on `s` immediately before/after the dominant kernel (k_encode_tiles)
 // mode ENC_FULL: out = rows x n codewords in the reference layout; msgs must not overlap out (K3 copies coset 0 of the
-//   codeword from the message row); coset2 (optional): rows x k compact copy of the codeword elements 4q + 2.
+//   codeword from the message row).
 // mode ENC_HALF: out = rows x k, only the values on the coset w_n^2 <w_n^4> (out[q] = P(w_n^(4q + 2))).
 // mode ENC_PLANAR: out = rows x 3k, out[(r-1)*k + q] = P(w_n^(4q + r)) for r = 1, 2, 3; coset 0 of a codeword is its message
 //   row reversed (codeword[4q] = msg[(k - q) mod k]) and is not stored.  CwView below addresses such a matrix by column.
-enum { ENC_FULL = 0, ENC_HALF = 1, ENC_PLANAR = 2 };
+// mode ENC_DOT: like ENC_HALF, but the k coset values of row r are not stored: their products with cw2[r] (rows of another
+//   matrix on the same coset, cw2_stride elements apart) are added, per group of group_rows rows, to part[group][k]
+//   (group partials in the format of k_rlc_partial's lin_part: plain values < 2p; `out` is unused).
+enum { ENC_FULL = 0, ENC_HALF = 1, ENC_PLANAR = 2, ENC_DOT = 3 };
+struct EncodeDot { const fr* cw2; size_t cw2_stride; uint32_t group_rows; fr* part; };
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y,
-                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, int mode = ENC_FULL, fr* coset2 = nullptr);
+                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, int mode = ENC_FULL, const EncodeDot* dot = nullptr);
 
 // The batched prover's resident codeword matrix: message rows (coset 0, reversed) + the three computed cosets as planes.
 struct CwView {

@@ -341,7 +341,7 @@ int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ens
 // shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
 // codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
 // (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on, void* coset2) {
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on) {
     const bool half = mode == lig::ENC_HALF;
     const size_t out_stride = half ? (size_t)c->k : mode == lig::ENC_PLANAR ? 3 * (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
@@ -364,7 +364,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                 c->prof_used++; c->prof_rows += nr;
             }
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
-                                  c->scratch_z, nr, e0, e1, mode, coset2 ? (fr*)coset2 + r0 * c->k : nullptr);
+                                  c->scratch_z, nr, e0, e1, mode);
         }
     } else if (mode == lig::ENC_PLANAR) {
         // generic path (k > 8192), planar: codewords of a few rows at a time in the Z scratch, then one strided copy per plane
@@ -390,7 +390,6 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                                     rows, hipMemcpyDeviceToDevice, st));
         lig::ntt_generic_inverse(st, c->plan[LIG_SIZE_K], (fr*)out, rows, out_stride);
         lig::ntt_generic_forward(st, c->plan[LIG_SIZE_N], (fr*)out, rows, out_stride);
-        if (coset2) HIP_TRY(c, hipMemcpy2DAsync(coset2, sizeof(fr), (const fr*)out + 2, 4 * sizeof(fr), sizeof(fr), rows * (size_t)c->k, hipMemcpyDeviceToDevice, st));
     } else {
         // generic path, half: NTT_2k on <w_n^2> into the Z scratch (2k per row), then keep the odd points
         const size_t k2 = 2 * (size_t)c->k, chunk = 64;
@@ -408,6 +407,19 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                                         hipMemcpyDeviceToDevice, st));
         }
     }
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+// stage-2 linear test on the coset w_n^2 <w_n^4>: for every row r the coset values of rands[r] (k values, never stored) times
+// cw2[r] (k values of another matrix on the same coset, rows cw2_stride elements apart), summed per group of group_rows rows
+// into part[group][k] (added to what is there).  Fast encoder only; rows <= the reserved scratch.
+int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on) {
+    if (!c->fast) return LIG_E_STATE;
+    hipStream_t st = on ? on : c->stream;
+    int rc = ensure_scratch(c, rows);
+    if (rc != LIG_OK) return rc;
+    const lig::EncodeDot dot{(const fr*)cw2, cw2_stride, group_rows, (fr*)part};
+    lig::encode_rows_fast(st, c->ep, (const fr*)rands, nullptr, c->scratch_y, c->scratch_z, rows, nullptr, nullptr, lig::ENC_DOT, &dot);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }

@@ -118,14 +118,14 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
 // ---------------------------------------------------------------------------------------------------- K3
 // MODE 0 (interleaved): out row = the codeword as the reference lays it out, element 4*(q2 + B*q1) + r; the lanes with r = 0
 //        copy the reversed message instead of running the radix-8 step, so every 128-byte line is written by four
-//        adjacent lanes.  Optional compact copy of coset 2.
+//        adjacent lanes.
 // MODE 1 (half): out row = k elements, element q = q2 + B*q1 is P(w_n^(4q + 2)).
 // MODE 2 (planar): out row = 3k elements, the computed cosets as planes: element (r-1)*k + q is P(w_n^(4q + r)), r = 1, 2, 3.
 //        Coset 0 is not stored at all (it IS the message row, reversed); the batched prover reads its columns from there.
 //        Per row this writes 3k*32 bytes instead of 4k*32 (+ k*32 for the compact coset-2 copy) and does not read the message.
 template <int LOG2B, int MODE>
 __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8,
-                                                    const fr* __restrict__ msgs, size_t rows, fr* __restrict__ coset2) {
+                                                    const fr* __restrict__ msgs, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (MODE == 2) {
@@ -167,46 +167,92 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
         }
 #pragma unroll
         for (int q1 = 0; q1 < 8; q1++) fr_store(out + OS * ((size_t)q2 + (size_t)B * q1) + r, v[q1]);
-        if (FULL && coset2 != nullptr && r == 2) {
-            fr* c2 = coset2 + row * (size_t)K;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- K3 . codeword
+// The stage-2 linear test needs, per randomness row R_r, its values on the coset w_n^2 <w_n^4> only to multiply them with the
+// same coset of the codeword U_r and add the products over the rows.  This output kernel does that in place of writing the
+// k values: thread = (q2, group of rows); per row the radix-8 butterfly across Z[0..8)[q2] (no canonical reduction: the
+// lazy values go straight into the products), eight products with U_r's coset-2 plane, lazy accumulation; one partial sum
+// per group and position, ADDED to part[g][.] (the partials persist across chunks, prover_kernels.hip: k_rlc_partial has
+// the same contract).  Saves the k*32-byte write and re-read of the coset values per row and one launch.
+template <int LOG2B>
+__global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict__ Z, const f29s* __restrict__ w8, const fr* __restrict__ cw2,
+                                                           size_t cws, size_t rows, uint32_t group_rows, fr* __restrict__ part) {
+    constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
+    const uint32_t q2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q2 >= B) return;
+    const size_t r0 = (size_t)blockIdx.y * group_rows;
+    const size_t r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
+    const f29 w1 = f29_load_tab(w8 + 1), w2 = f29_load_tab(w8 + 2), w3 = f29_load_tab(w8 + 3);
+    f29 acc[8];
 #pragma unroll
-            for (int q1 = 0; q1 < 8; q1++) fr_store(c2 + q2 + (size_t)B * q1, v[q1]);
+    for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_zero();
+    int since = 0;
+    for (size_t r = r0; r < r1; r++) {
+        const fr* z = Z + (r * 8) * (size_t)B + q2;
+        const fr* u = cw2 + r * cws + q2;
+        f29 a[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
+        radix8_dit(a, w1, w2, w3);                                         // limbs < 2^31 + 8, value < 28p
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_add(acc[q1], f29_montmul(a[q1], unpack29(fr_load(u + (size_t)B * q1))));   // each term < 1.2p
+        if (++since == 6) {
+#pragma unroll
+            for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_qnorm(acc[q1]);
+            since = 0;
         }
+    }
+    fr* out = part + (size_t)blockIdx.y * K + q2;
+#pragma unroll
+    for (int q1 = 0; q1 < 8; q1++) {
+        f29 v = f29_montmul(f29_qnorm(acc[q1]), f29_const_r2());          // plain value, < 1.2p
+        v = f29_reduce_2p(f29_add(v, unpack29(fr_load(out + (size_t)B * q1))));
+        fr_store(out + (size_t)B * q1, pack29(v));
     }
 }
 
 bool encode_fast_supported(uint32_t k) { return k == 512 || k == 1024 || k == 2048 || k == 4096 || k == 8192; }
 
-// mode: 0 = codewords rows x n (reference layout), 1 = rows x k (coset 2 only), 2 = rows x 3k (cosets 1..3 as planes)
+// mode: 0 = codewords rows x n (reference layout), 1 = rows x k (coset 2 only), 2 = rows x 3k (cosets 1..3 as planes),
+// 3 = coset 2 only, not stored: its products with the rows of dot.cw2 are added to the group partials dot.part
 template <int LOG2B>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
-                          hipEvent_t ev0, hipEvent_t ev1, int mode, fr* coset2) {
+                          hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot) {
     constexpr uint32_t B = 1u << LOG2B;
     const size_t th1 = rows * B;
     static const int kmask = [] { const char* e = std::getenv("LIG_ENCODE_KMASK"); return e ? std::atoi(e) : 15; }();   // experiments only: 1 = K1, 6 = K2, 8 = K3
     if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     if (ev0) (void)hipEventRecord(ev0, s);
     if (kmask & 6) {
-        if (mode == 1) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+        if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
         else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
     }
     if (ev1) (void)hipEventRecord(ev1, s);
     if (!(kmask & 8)) return;
+    if (mode == 3) {
+        const uint32_t groups = (uint32_t)((rows + dot->group_rows - 1) / dot->group_rows);
+        hipLaunchKernelGGL(k_encode_out_dot<LOG2B>, dim3((B + 255) / 256, groups), dim3(B < 256 ? B : 256), 0, s, Z, ep.w8_fwd, dot->cw2, dot->cw2_stride, rows,
+                           dot->group_rows, dot->part);
+        return;
+    }
     const size_t th3 = rows * B * (mode == 0 ? 4 : mode == 1 ? 1 : 3);
     const dim3 g3((uint32_t)((th3 + 255) / 256));
-    if (mode == 0) hipLaunchKernelGGL((k_encode_out<LOG2B, 0>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
-    else if (mode == 1) hipLaunchKernelGGL((k_encode_out<LOG2B, 1>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
-    else hipLaunchKernelGGL((k_encode_out<LOG2B, 2>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows, coset2);
+    if (mode == 0) hipLaunchKernelGGL((k_encode_out<LOG2B, 0>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    else if (mode == 1) hipLaunchKernelGGL((k_encode_out<LOG2B, 1>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    else hipLaunchKernelGGL((k_encode_out<LOG2B, 2>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
 }
 
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
-                      hipEvent_t ev0, hipEvent_t ev1, int mode, fr* coset2) {
+                      hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot) {
     switch (ep.log2B) {
-        case 6: encode_rows_t<6>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
-        case 7: encode_rows_t<7>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
-        case 8: encode_rows_t<8>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
-        case 9: encode_rows_t<9>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
-        case 10: encode_rows_t<10>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, coset2); break;
+        case 6: encode_rows_t<6>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 7: encode_rows_t<7>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 8: encode_rows_t<8>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 9: encode_rows_t<9>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 10: encode_rows_t<10>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
         default: break;
     }
 }

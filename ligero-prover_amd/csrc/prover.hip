@@ -182,7 +182,7 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     TRY(dm((void**)&T->randb, 2 * chunk * (size_t)k * 32));          // double-buffered
     TRY(dm((void**)&T->rcw, chunk * (size_t)n * 32));
     TRY(dm((void**)&T->acc, 4 * (size_t)n * 32));
-    TRY(dm((void**)&T->parts, 3 * groups * (size_t)n * 32));
+    TRY(dm((void**)&T->parts, (2 * groups * (size_t)n + (chunk + lig_tune::DOT_GROUP - 1) / lig_tune::DOT_GROUP * k) * 32));
     TRY(dm((void**)&T->dots, 32));
     TRY(dm((void**)&T->samples, (R + 3) * (size_t)t * 32));
     TRY(dm((void**)&T->sha_state, lig_sha_state_bytes(n)));
@@ -340,7 +340,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // group partials of the three k-column accumulators: group g of every chunk adds into slot g, combined once at the end
     const size_t groups = (lig_tune::CHUNK + lig_tune::GROUP - 1) / lig_tune::GROUP;
     fr* p_code = T->parts; fr* p_linH = T->parts + groups * (size_t)n; fr* p_linC = T->parts + 2 * groups * (size_t)n;
-    HIP_TRY(c, hipMemsetAsync(T->parts, 0, 3 * groups * (size_t)n * 32, s));
+    const size_t dot_groups = (lig_tune::CHUNK + lig_tune::DOT_GROUP - 1) / lig_tune::DOT_GROUP;      // p_linC: dot_groups x k
+    HIP_TRY(c, hipMemsetAsync(T->parts, 0, (2 * groups * (size_t)n + dot_groups * k) * 32, s));
     HIP_TRY(c, hipMemsetAsync(T->acc, 0, 4 * (size_t)n * 32, s));
     fr* rhalf = T->rcw;                                   // chunk x 2k
     // The randomness rows of chunk b+1 (AES sampling: LDS-bound; or the upload of the caller's rows) are formed on the side
@@ -397,9 +398,15 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
-        TRY(lig_internal_encode_rows(c, rb, rhalf, nb, true));
+        if (c->fast) {
+            // coset-2 values of the randomness rows times the coset-2 plane of the codewords, summed per group of rows inside the
+            // encoder's output kernel: the values themselves are never written
+            TRY(lig_internal_encode_dot(c, rb, nb, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, lig_tune::DOT_GROUP, p_linC));
+        } else {
+            TRY(lig_internal_encode_rows(c, rb, rhalf, nb, lig::ENC_HALF));
+            lig::launch_rlc_accumulate29(s, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::DOT_GROUP);
+        }
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        lig::launch_rlc_accumulate29(s, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);   // plane of coset 2
         lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
@@ -407,7 +414,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         const uint32_t pg = (uint32_t)((lig_tune::CHUNK + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4));
         lig::launch_rlc_combine(s, tmp, p_code, pg, k);         // the code test's k message values (tmp was zeroed with acc)
         lig::launch_rlc_combine(s, linH, p_linH, pg, k);
-        lig::launch_rlc_combine(s, linC, p_linC, pg, k);
+        lig::launch_rlc_combine(s, linC, p_linC, (uint32_t)dot_groups, k);
     }
     mark("stage2 rows (rng+dot+encode+rlc)");
     lig::launch_sum_elems(s, linH, k, 1, T->dots, nullptr);       // sum of all <witness row, randomness row> (prover_kernels.hip)

@@ -308,6 +308,10 @@ const H::Fr R261 = {{0x2fd4e1568fffff57ull, 0x75bba827a494b01aull, 0x5301fa84819
 struct lig_tune {
     static constexpr size_t CHUNK = 512;       // rows per encode / hash / accumulate launch group
     static constexpr uint32_t GROUP = 64;      // rows per lazily accumulated group (n-column passes; k-column passes use GROUP / 4)
+#ifndef LIG_DOT_GROUP
+#define LIG_DOT_GROUP 8
+#endif
+    static constexpr uint32_t DOT_GROUP = LIG_DOT_GROUP;   // rows per group of the fused coset-2 encode + dot (lig_internal_encode_dot): 64 groups x 1024 threads per chunk
 };
 
 // the batch program of a job on the device: committed rows are written to rows_out in program order (prover.hip)

@@ -181,7 +181,7 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
     TRY(dm((void**)&S->randb, 2 * chunk * (size_t)k * 32));         // double-buffered
     TRY(dm((void**)&S->rhalf, chunk * 2 * (size_t)k * 32));
     TRY(dm((void**)&S->acc, 4 * (size_t)n * 32));
-    TRY(dm((void**)&S->parts, 3 * ((chunk + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4)) * (size_t)k * 32));
+    TRY(dm((void**)&S->parts, (2 * ((chunk + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4)) + (chunk + lig_tune::DOT_GROUP - 1) / lig_tune::DOT_GROUP) * (size_t)k * 32));
     TRY(dm((void**)&S->accp, 5 * (size_t)k * 32));
     TRY(dm((void**)&S->accg, (size_t)world * 5 * k * 32));
     TRY(dm((void**)&S->dots, 32));
@@ -387,7 +387,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     // while the main stream encodes / accumulates chunk c; group partials persist across chunks, one combine per accumulator
     const uint32_t pg = (uint32_t)((CAP + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4));
     fr* p_code = S->parts; fr* p_linH = S->parts + (size_t)pg * k; fr* p_linC = S->parts + 2 * (size_t)pg * k;
-    HIP_TRY(c, hipMemsetAsync(S->parts, 0, 3 * (size_t)pg * k * 32, s));
+    const uint32_t dot_groups = (uint32_t)((CAP + lig_tune::DOT_GROUP - 1) / lig_tune::DOT_GROUP);      // p_linC: dot_groups x k
+    HIP_TRY(c, hipMemsetAsync(S->parts, 0, (2 * (size_t)pg + dot_groups) * k * 32, s));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key + memsets above
     HIP_TRY(c, hipStreamWaitEvent(s_hash, c->ev_fork, 0));
     auto form_rand_chunk = [&](size_t cidx) -> int {           // on the side stream
@@ -412,15 +413,19 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         if (cidx + 1 < S->rounds) TRY(form_rand_chunk(cidx + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, S->ev_enc[cidx & 1], 0));
         if (nb) {
-            TRY(lig_internal_encode_rows(c, rb, S->rhalf, nb, true));
-            lig::launch_rlc_accumulate29(s, S->cw + lb * 3 * (size_t)k + k, 3 * (size_t)k, 1, S->rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::GROUP / 4);   // plane of coset 2
+            if (c->fast) {      // as in lig_synth_prove: coset-2 values times the codewords' coset-2 plane inside the encoder's output kernel
+                TRY(lig_internal_encode_dot(c, rb, nb, S->cw + lb * 3 * (size_t)k + k, 3 * (size_t)k, lig_tune::DOT_GROUP, p_linC));
+            } else {
+                TRY(lig_internal_encode_rows(c, rb, S->rhalf, nb, lig::ENC_HALF));
+                lig::launch_rlc_accumulate29(s, S->cw + lb * 3 * (size_t)k + k, 3 * (size_t)k, 1, S->rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::DOT_GROUP);
+            }
             lig::launch_rlc_accumulate29(s, S->msgs + lb * (size_t)k, k, 1, rb, k, nb, k, S->coef_dev + lb, p_code, p_linH, lig_tune::GROUP / 4);
         }
         HIP_TRY(c, hipEventRecord(S->ev_comm[cidx & 1], s));
     }
     lig::launch_rlc_combine(s, tmp, p_code, pg, k);
     lig::launch_rlc_combine(s, linH, p_linH, pg, k);
-    lig::launch_rlc_combine(s, linC, p_linC, pg, k);
+    lig::launch_rlc_combine(s, linC, p_linC, dot_groups, k);
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     const lig::CwView view{S->msgs, S->cw, k};
     lig::launch_quad_rows29_view(s, view, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
