@@ -124,7 +124,7 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
         if ((rc = upload29(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
     }
     // twist[r-1][j1][i2] = k^-1 * w_n^(r*(j1 + 8*i2)), r = 1..3.  The 1/k of the inverse transform rides on the twist (every
-    // computed coset has one; coset 0 is copied from the message), so K2a stores unscaled coefficients.
+    // computed coset has one; coset 0 is copied from the message), so the inverse tile transforms keep unscaled coefficients.
     {
         std::vector<lig::f29s> tw((size_t)3 * k);
         const H::Fr kinv = H::inv(H::from_u64(k));

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
 #undef LIG_SEAM
 }
 
-// ---------------------------------------------------------------------------------------------------- K2 (fused K2a + K2b)
+// ---------------------------------------------------------------------------------------------------- K2
 // workgroup = (row, j1): the coefficient tile C[j1][.] is produced (inverse tile transform of Y[j1][.]) and consumed (one
 // forward tile transform per coset) without leaving the CU.  Between the two, the tile changes ownership once through
 // LDS: the inverse transform leaves thread t with coefficients t + q*T, the forward transforms start from the bit-reversed
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
 // MODE 1 (half): out row = k elements, element q = q2 + B*q1 is P(w_n^(4q + 2)).
 // MODE 2 (planar): out row = 3k elements, the computed cosets as planes: element (r-1)*k + q is P(w_n^(4q + r)), r = 1, 2, 3.
 //        Coset 0 is not stored at all (it IS the message row, reversed); the batched prover reads its columns from there.
-//        Per row this writes 3k*32 bytes instead of 4k*32 (+ k*32 for the compact coset-2 copy) and does not read the message.
+//        Per row this writes 3k*32 bytes instead of 4k*32 and does not read the message.
 template <int LOG2B, int MODE>
 __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8,
                                                     const fr* __restrict__ msgs, size_t rows) {
