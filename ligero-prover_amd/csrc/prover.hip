@@ -203,7 +203,13 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
     for (int a3 = 0; a3 < 3; a3++) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_acc[a3], hipEventDisableTiming));
     if (!T->triples.empty()) HIP_TRY(c, hipMemcpyAsync(T->tri_dev, T->triples.data(), T->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
-    T->sched1 = chunk_schedule(R, lig_tune::CHUNK, 0, 96);
+    {   // a short first chunk (the column hash -- the longest chain of stage 1 -- starts after 128 rows instead of 512) and a short
+        // last one (the hash tail after the last encode); LIG_S1_HEAD / LIG_S1_TAIL override for experiments
+        // (profiles/r02_stage1_schedule_ab.md: head 128 is +3 % proofs/s with two proofs in flight; one stage 1 at a time -- a
+        // process-wide lock around this stage -- measured 3-5 % slower)
+        const char* eh = std::getenv("LIG_S1_HEAD"); const char* et = std::getenv("LIG_S1_TAIL");
+        T->sched1 = chunk_schedule(R, lig_tune::CHUNK, eh ? (size_t)std::atoi(eh) : 128, et ? (size_t)std::atoi(et) : 96);
+    }
     TRY(lig_internal_reserve_scratch(c, R < lig_tune::CHUNK ? (R ? R : 1) : lig_tune::CHUNK));     // sized once: never re-allocated under a running stream
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LIG_OK;
