@@ -306,7 +306,10 @@ const H::Fr R261 = {{0x2fd4e1568fffff57ull, 0x75bba827a494b01aull, 0x5301fa84819
 
 // launch granularity shared by the prover, the sharded prover and the verifier
 struct lig_tune {
-    static constexpr size_t CHUNK = 512;       // rows per encode / hash / accumulate launch group
+#ifndef LIG_CHUNK
+#define LIG_CHUNK 512
+#endif
+    static constexpr size_t CHUNK = LIG_CHUNK;       // rows per encode / hash / accumulate launch group
     static constexpr uint32_t GROUP = 64;      // rows per lazily accumulated group (n-column passes; k-column passes use GROUP / 4)
 #ifndef LIG_DOT_GROUP
 #define LIG_DOT_GROUP 8
