@@ -398,7 +398,7 @@ def main():
 
     # PCIe-inclusive figure: the same proofs with the witness matrix starting in pinned host memory (caller-rows entry)
     incl = None
-    if a.workload == "full" and not a.no_h2d:
+    if a.workload == "full" and not a.no_h2d and world == 1:      # informational, N = 1 only (like cpu_baseline): keeps the scaling runs lean
         try:
             hw = RowsFromHostWorkload(ctx, 1 << log2c, pkg, max(1, a.h2d_inflight), local_rank)
             hw.run(3)                                   # warm-up: the second message matrix is allocated by the first prefetch, pages are touched
