@@ -12,6 +12,16 @@
 
 namespace lig {
 
+// view of a windowed twiddle table on the device (fr29.hpp: f29_mulw): seven planes of 16-byte words, `stride` entries each
+// (the entry index is kept apart from the uniform base so that all seven loads of an entry share one 32-bit lane offset)
+struct f29wt {
+    const uint4* base;
+    uint32_t stride;
+    uint32_t idx;
+    __host__ __device__ f29wt operator+(size_t i) const { return f29wt{base, stride, idx + (uint32_t)i}; }
+};
+
+
 struct alignas(16) fr {
     uint32_t v[8];
 };

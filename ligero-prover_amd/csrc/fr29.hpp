@@ -108,6 +108,49 @@ __device__ __forceinline__ f29 f29_montmul(const f29& a, const f29& b) {
     return t;
 }
 
+// ---- products with a TABLE operand in windowed form.  Every multiply of the encoder has a constant from a table on one
+// side (stage twiddles, twists, seams).  A windowed entry for the constant w stores W_g = w * 2^(87 g) * 2^116 mod p, g = 0, 1, 2;
+// with a = A_0 + A_1 2^87 + A_2 2^174 the sum A_0 W_0 + A_1 W_1 + A_2 W_2 = a * w * 2^116 (mod p) is below 2^91 p, so FOUR
+// Montgomery steps bring it back to 9 limbs: 81 + 36 = 117 v_mad_u64_u32, 4 v_mul_lo_u32, 12 v_lshrrev_b64 against
+// 162 / 9 / 17 for f29_montmul; the entry is 108 bytes instead of 36 (seven 16-byte loads).
+// a: lazy, limbs <= 2.5 * 2^30 + 8.  Result: normalised limbs, value < p (1 + 2^-20) -- tighter than f29_montmul's 1.2 p.
+// Column bound: 9 * (2.5*2^30 + 8) * 2^29 + 4 * 2^58 + carry < 2^64.
+struct f29w {            // host-side entry
+    uint32_t v[28];      // v[9 g + j] = limb j of W_g; v[27] unused
+};
+struct f29wv {
+    uint32_t v[28];
+};
+// Device layout: SEVEN PLANES of 16-byte words, plane i holding words 4i .. 4i+3 of every entry (`stride` entries per plane).
+// Adjacent lanes use adjacent entries in every table of the encoder, so each of the seven loads of a product touches 8
+// consecutive 128-byte lines per wave instead of 64 scattered ones (array-of-entries measured 22 % SLOWER than the 36-byte
+// Montgomery-form tables it replaced: the L1 tag rate, not the multiplier, was the limit).
+// (struct f29wt {base, stride}: fr.hpp, shared with the host-side plan structs)
+__device__ __forceinline__ f29wv f29_load_w(const f29wt p) {
+    f29wv r;
+    const uint32_t off = p.idx << 4;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const char* pl = reinterpret_cast<const char*>(p.base + (size_t)i * p.stride);      // uniform: a scalar base per plane
+        const uint4 x = *reinterpret_cast<const uint4*>(pl + off);          // + one 32-bit lane offset (tables < 4 GiB)
+        r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
+    }
+    return r;
+}
+__device__ __forceinline__ f29 f29_mulw(const f29& a, const f29wv& W) {
+    uint32_t m[4];
+    f29 t;
+    uint64_t acc = 0;
+    const uint32_t p0 = f29_p0_opaque();
+#include "fr29_mulw_gen.hpp"         // 12 columns, one chained v_mad_u64_u32 block each (tools/gen_fr29_mulw.py)
+    return t;
+}
+// uniform access to both table formats (tile_dft.hpp is shared by kernels on either)
+__device__ __forceinline__ f29 tab_get(const f29s* p) { return f29_load_tab(p); }
+__device__ __forceinline__ f29wv tab_get(const f29wt p) { return f29_load_w(p); }
+__device__ __forceinline__ f29 tab_mul(const f29& a, const f29& w) { return f29_montmul(a, w); }
+__device__ __forceinline__ f29 tab_mul(const f29& a, const f29wv& w) { return f29_mulw(a, w); }
+
 // limb-wise lazy add
 __device__ __forceinline__ f29 f29_add(const f29& a, const f29& b) {
     f29 r;

@@ -16,16 +16,19 @@ struct NttPlan {
     fr ninv;              // N^-1 * R
 };
 
-// Tables of the batched row-encode path (ntt_encode.hip), all in 9 x 29-bit limbs, Montgomery radix 2^261.
+// Tables of the batched row-encode path (ntt_encode.hip) in 9 x 29-bit limbs: the per-element tables (stage twiddles, seams,
+// twists) in windowed form (f29w: three shifted copies of every constant, fr29.hpp: f29_mulw), the radix-8 constants in
+// Montgomery form (f29s, radix 2^261).
 struct f29s;
 struct EncodePlan {
     uint32_t k = 0, n = 0, log2k = 0;
     uint32_t A = 0, B = 0, log2B = 0;      // k = A * B, A = 8 outer radix, B = tile length
-    f29s* tw_b = nullptr;       // DIT stage twiddles of the size-B forward transform (root psi^8, psi = w_n^4): span M' at M'/2-1
-    f29s* tw_b_inv = nullptr;   // same for the inverse size-B transform (root w_k^-8)
-    f29s* seam_inv = nullptr;   // w_k^(-i2*j1), [8][B]
-    f29s* twist = nullptr;      // w_n^(r*(j1 + 8*i2)), [3][8][B] for r = 1..3
-    f29s* seam_fwd = nullptr;   // psi^(i1*q2), [8][B]
+    f29wt tw_b{nullptr, 0, 0};       // DIT stage twiddles of the size-B forward transform (root psi^8, psi = w_n^4): span M' at M'/2-1
+    f29wt tw_b_inv{nullptr, 0, 0};   // same for the inverse size-B transform (root w_k^-8)
+    f29wt seam_inv{nullptr, 0, 0};   // w_k^(-i2*j1), [8][B]
+    f29wt twist{nullptr, 0, 0};      // w_n^(r*(j1 + 8*i2)) / k, [3][8][B] for r = 1..3, inside a tile in THREAD order: entry q*B/4 + t belongs to
+                                  // position i2 = brev(4t + q), the element thread t loads as its q-th (adjacent lanes, adjacent entries)
+    f29wt seam_fwd{nullptr, 0, 0};   // psi^(i1*q2), [8][B]
     f29s* w8_inv = nullptr;     // powers of w_k^-(k/8): radix-8 constants (inverse), 8 entries
     f29s* w8_fwd = nullptr;     // powers of psi^(k/8): radix-8 constants (forward), 8 entries
     f29s* kinv = nullptr;       // k^-1, 1 entry

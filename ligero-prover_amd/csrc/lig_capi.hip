@@ -78,12 +78,50 @@ static lig::f29s to_f29s(const H::Fr& plain) {
     }
     return o;
 }
-static int upload29(lig_ctx* c, const std::vector<lig::f29s>& host, lig::f29s** dev) {
+// windowed table entry (fr29.hpp: f29_mulw): W_g = x * 2^(116 + 87 g) mod p for g = 0, 1, 2, nine 29-bit limbs each
+static lig::f29w to_f29w(const H::Fr& plain) {
+    static const std::vector<H::Fr> shift = [] {
+        std::vector<H::Fr> s(3);
+        H::Fr c = H::from_u64(1);
+        for (int i = 0; i < 116; i++) c = H::add(c, c);
+        for (int g = 0; g < 3; g++) { s[g] = c; for (int i = 0; i < 87; i++) c = H::add(c, c); }
+        return s;
+    }();
+    lig::f29w o;
+    std::memset(&o, 0, sizeof o);
+    for (int g = 0; g < 3; g++) {
+        const H::Fr m = H::mul(plain, shift[g]);
+        for (int i = 0; i < 9; i++) {
+            const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+            uint64_t v = m.v[w] >> sh;
+            if (sh > 35 && w < 3) v |= m.v[w + 1] << (64 - sh);
+            o.v[9 * g + i] = (uint32_t)(i < 8 ? (v & 0x1FFFFFFFull) : v);
+        }
+    }
+    return o;
+}
+// windowed table -> device planes (fr29.hpp: f29wt): plane i = words 4i .. 4i+3 of every entry
+static int upload29w(lig_ctx* c, const std::vector<lig::f29w>& host, lig::f29wt* dev) {
+    const size_t E = host.size();
+    std::vector<uint32_t> planes(7 * E * 4);
+    for (size_t e = 0; e < E; e++)
+        for (int i = 0; i < 7; i++) std::memcpy(&planes[((size_t)i * E + e) * 4], &host[e].v[4 * i], 16);
     void* p = nullptr;
-    HIP_TRY(c, hipMalloc(&p, host.size() * sizeof(lig::f29s)));
+    HIP_TRY(c, hipMalloc(&p, planes.size() * 4));
     c->owned.push_back(p);
-    HIP_TRY(c, hipMemcpy(p, host.data(), host.size() * sizeof(lig::f29s), hipMemcpyHostToDevice));
-    *dev = (lig::f29s*)p;
+    HIP_TRY(c, hipMemcpy(p, planes.data(), planes.size() * 4, hipMemcpyHostToDevice));
+    dev->base = (const uint4*)p;
+    dev->stride = (uint32_t)E;
+    dev->idx = 0;
+    return LIG_OK;
+}
+template <class T>
+static int upload29(lig_ctx* c, const std::vector<T>& host, T** dev) {
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, host.size() * sizeof(T)));
+    c->owned.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (T*)p;
     return LIG_OK;
 }
 // plain powers base^0 .. base^(count-1)
@@ -105,35 +143,40 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
     // DIT stage twiddles of the size-B transforms: the stage of span M starts at entry M/2-1, rho^(j*B/M), j < M/2
     auto stage_table = [&](const H::Fr& rho) {
         std::vector<H::Fr> pw = powers_plain(rho, B / 2);
-        std::vector<lig::f29s> t(B);                            // B-1 used
+        std::vector<lig::f29w> t(B);                            // B-1 used
         for (uint32_t M = 2; M <= B; M <<= 1)
-            for (uint32_t j = 0; j < M / 2; j++) t[(M / 2 - 1) + j] = to_f29s(pw[(size_t)j * (B / M)]);
-        t[B - 1] = to_f29s(H::from_u64(1));
+            for (uint32_t j = 0; j < M / 2; j++) t[(M / 2 - 1) + j] = to_f29w(pw[(size_t)j * (B / M)]);
+        t[B - 1] = to_f29w(H::from_u64(1));
         return t;
     };
-    if ((rc = upload29(c, stage_table(H::pow_u64(wk_inv, A)), &ep.tw_b_inv)) != LIG_OK) return rc;
-    if ((rc = upload29(c, stage_table(H::pow_u64(psi, A)), &ep.tw_b)) != LIG_OK) return rc;
+    if ((rc = upload29w(c, stage_table(H::pow_u64(wk_inv, A)), &ep.tw_b_inv)) != LIG_OK) return rc;
+    if ((rc = upload29w(c, stage_table(H::pow_u64(psi, A)), &ep.tw_b)) != LIG_OK) return rc;
     // seams: seam_inv[j1][i2] = w_k^(-i2*j1), seam_fwd[i1][q2] = psi^(i1*q2)
     {
-        std::vector<lig::f29s> si((size_t)A * B), sf((size_t)A * B);
+        std::vector<lig::f29w> si((size_t)A * B), sf((size_t)A * B);
         for (uint32_t j1 = 0; j1 < A; j1++) {
             std::vector<H::Fr> a = powers_plain(H::pow_u64(wk_inv, j1), B), b = powers_plain(H::pow_u64(psi, j1), B);
-            for (uint32_t i = 0; i < B; i++) { si[(size_t)j1 * B + i] = to_f29s(a[i]); sf[(size_t)j1 * B + i] = to_f29s(b[i]); }
+            for (uint32_t i = 0; i < B; i++) { si[(size_t)j1 * B + i] = to_f29w(a[i]); sf[(size_t)j1 * B + i] = to_f29w(b[i]); }
         }
-        if ((rc = upload29(c, si, &ep.seam_inv)) != LIG_OK) return rc;
-        if ((rc = upload29(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
+        if ((rc = upload29w(c, si, &ep.seam_inv)) != LIG_OK) return rc;
+        if ((rc = upload29w(c, sf, &ep.seam_fwd)) != LIG_OK) return rc;
     }
     // twist[r-1][j1][i2] = k^-1 * w_n^(r*(j1 + 8*i2)), r = 1..3.  The 1/k of the inverse transform rides on the twist (every
     // computed coset has one; coset 0 is copied from the message), so the inverse tile transforms keep unscaled coefficients.
     {
-        std::vector<lig::f29s> tw((size_t)3 * k);
+        std::vector<lig::f29w> tw((size_t)3 * k);
         const H::Fr kinv = H::inv(H::from_u64(k));
         for (uint32_t r = 1; r < 4; r++) {
             std::vector<H::Fr> pw = powers_plain(H::pow_u64(w4k, r), k);
             for (uint32_t j1 = 0; j1 < A; j1++)
-                for (uint32_t i2 = 0; i2 < B; i2++) tw[((size_t)(r - 1) * A + j1) * B + i2] = to_f29s(H::mul(kinv, pw[j1 + (size_t)A * i2]));
+                for (uint32_t t = 0; t < B / 4; t++)
+                    for (uint32_t q = 0; q < 4; q++) {          // thread order inside a tile: entry q*B/4 + t <-> position brev(4t + q)
+                        uint32_t i2 = 0;
+                        for (uint32_t bit = 0, v = 4 * t + q; bit < ep.log2B; bit++, v >>= 1) i2 = (i2 << 1) | (v & 1);
+                        tw[((size_t)(r - 1) * A + j1) * B + q * (B / 4) + t] = to_f29w(H::mul(kinv, pw[j1 + (size_t)A * i2]));
+                    }
         }
-        if ((rc = upload29(c, tw, &ep.twist)) != LIG_OK) return rc;
+        if ((rc = upload29w(c, tw, &ep.twist)) != LIG_OK) return rc;
     }
     // radix-8 constants: w8[i] = w^i, w = w_k^(-k/8) (inverse) / psi^(k/8) (forward); k^-1
     {

@@ -40,7 +40,7 @@ namespace lig {
 #define LIG_K1_WAVES 2
 #endif
 template <int LOG2B>
-__global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29s* __restrict__ seam_inv,
+__global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29wt seam_inv,
                                                    const f29s* __restrict__ w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
     fr* y = Y + row * K;
     fr_store(y + i2, pack29(f29_reduce_2p(a[0])));
     // explicit unrolling: hipcc leaves a `#pragma unroll` loop over 7 Montgomery products rolled and then keeps a[] in scratch
-#define LIG_SEAM(J1) fr_store(y + (size_t)(J1) * B + i2, pack29(f29_montmul(a[J1], f29_load_tab(seam_inv + (size_t)(J1) * B + i2))))
+#define LIG_SEAM(J1) fr_store(y + (size_t)(J1) * B + i2, pack29(f29_mulw(a[J1], f29_load_w(seam_inv + (size_t)(J1) * B + i2))))
     LIG_SEAM(1); LIG_SEAM(2); LIG_SEAM(3); LIG_SEAM(4); LIG_SEAM(5); LIG_SEAM(6); LIG_SEAM(7);
 #undef LIG_SEAM
 }
@@ -72,8 +72,7 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
 #endif
 template <int LOG2B, bool FULL>
 __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_encode_tiles(const fr* __restrict__ Y, fr* __restrict__ Z,
-                                                                   const f29s* __restrict__ tw_inv, const f29s* __restrict__ tw_fwd,
-                                                                   const f29s* __restrict__ twist, const f29s* __restrict__ seam_fwd) {
+                                                                   const f29wt tw_inv, const f29wt tw_fwd, const f29wt twist, const f29wt seam_fwd) {
     constexpr uint32_t B = 1u << LOG2B, T = B / 4, NC = FULL ? 3 : 1;
     __shared__ TileLds<LOG2B> L;
     const uint32_t t = threadIdx.x;
@@ -94,20 +93,20 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
 #pragma unroll 1
     for (uint32_t ci = 0; ci < NC; ci++) {
         const uint32_t r = FULL ? ci + 1 : 2;
-        const f29s* tws = twist + ((size_t)(r - 1) * 8 + j1) * B;
+        const f29wt tws = twist + ((size_t)(r - 1) * 8 + j1) * B;
         // the thread index is made opaque once per coset: otherwise every t-dependent table / store address of the loop body is
         // hoisted into 64-bit register pairs that do not fit next to the coefficients and end up in scratch memory
         uint32_t tt = t;
         asm volatile("" : "+v"(tt));
 #pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = f29_montmul(cb[q], f29_load_tab(tws + (__brev(4 * tt + q) >> (32 - LOG2B))));   // w_n^(r*(j1 + 8*pos))
+        for (int q = 0; q < 4; q++) x[q] = f29_mulw(cb[q], f29_load_w(tws + (q * T + tt)));   // w_n^(r*(j1 + 8*pos))
         __syncthreads();                               // the exchange buffer is free again (ownership change / previous coset)
         tile_dft<LOG2B>(x, tw_fwd, L, tt);
         fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
         if (j1 != 0) {
-            const f29s* sf = seam_fwd + (size_t)j1 * B;
+            const f29wt sf = seam_fwd + (size_t)j1 * B;
 #pragma unroll
-            for (int q = 0; q < 4; q++) fr_store(z + tt + q * T, pack29(f29_montmul(x[q], f29_load_tab(sf + tt + q * T))));
+            for (int q = 0; q < 4; q++) fr_store(z + tt + q * T, pack29(f29_mulw(x[q], f29_load_w(sf + tt + q * T))));
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) fr_store(z + tt + q * T, pack29(f29_reduce_2p(x[q])));

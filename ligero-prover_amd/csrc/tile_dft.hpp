@@ -104,8 +104,8 @@ __device__ __forceinline__ void quad_transpose(f29 (&x)[4], const uint32_t lane)
 
 // One radix-2^2 DIT step (spans M/2 and M, M = 4^(S+1)) of the size-B transform.  Thread t owns positions
 // base + q*Q (Q = M/4).  tw: the stage of span M' starts at entry M'/2 - 1 (M'/2 entries rho^(j*B/M')).
-template <int LOG2B, int S>
-__device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
+template <int LOG2B, int S, class TW>
+__device__ __forceinline__ void tile_step(f29 (&x)[4], const TW tw, TileLds<LOG2B>& L, const uint32_t t) {
     constexpr int STEPS = LOG2B / 2;
     constexpr uint32_t M = 4u << (2 * S), Q = M >> 2;
     const uint32_t p = t & (Q - 1);
@@ -123,18 +123,18 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
         // spans 2 and 4: twiddles 1 | 1, W_4^1.  inputs normalised, < 3p.
         u = f29_add(x[0], x[1]); x[1] = f29_sub_k4(x[0], x[1]); x[0] = u;         // u: limbs < 2^30, < 6p; v: limbs < 2^31, < 7p
         u = f29_add(x[2], x[3]); x[3] = f29_sub_k4(x[2], x[3]); x[2] = u;
-        t3 = f29_montmul(x[3], f29_load_tab(tw + 2));                               // W_4^1
+        t3 = tab_mul(x[3], tab_get(tw + 2));                               // W_4^1
         u = f29_add(x[0], x[2]); x[2] = f29_sub_k8(x[0], x[2]); x[0] = u;           // < 12p | limbs < 3.5*2^30, < 14p
         u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 3*2^30, < 9p
     } else {
         // operands at rest: limbs < 2^29 + 8.  every output gains at most 4p.
-        const f29 wa = f29_load_tab(tw + (Q - 1) + p);                               // W_{M/2}^p
-        t1 = f29_montmul(x[1], wa);
-        t3 = f29_montmul(x[3], wa);
+        const auto wa = tab_get(tw + (Q - 1) + p);                                   // W_{M/2}^p
+        t1 = tab_mul(x[1], wa);
+        t3 = tab_mul(x[3], wa);
         u = f29_add(x[0], t1); x[1] = f29_sub_k2(x[0], t1); x[0] = u;               // limbs < 2^30+8 | < 1.5*2^30+8
         u = f29_add(x[2], t3); x[3] = f29_sub_k2(x[2], t3); x[2] = u;
-        t1 = f29_montmul(x[2], f29_load_tab(tw + (2 * Q - 1) + p));                 // W_M^p
-        t3 = f29_montmul(x[3], f29_load_tab(tw + (2 * Q - 1) + p + Q));             // W_M^(p+Q)
+        t1 = tab_mul(x[2], tab_get(tw + (2 * Q - 1) + p));                 // W_M^p
+        t3 = tab_mul(x[3], tab_get(tw + (2 * Q - 1) + p + Q));             // W_M^(p+Q)
         u = f29_add(x[0], t1); x[2] = f29_sub_k2(x[0], t1); x[0] = u;               // limbs < 2^31 + 8
         u = f29_add(x[1], t3); x[3] = f29_sub_k2(x[1], t3); x[1] = u;               // limbs < 2.5*2^30 + 8
     }
@@ -144,14 +144,14 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 4; q++) x[q] = f29_qnorm(x[q]);
             quad_transpose(x, t);
-            tile_step<LOG2B, S + 1>(x, tw, L, t);
+            tile_step<LOG2B, S + 1, TW>(x, tw, L, t);
             return;
         }
 #endif
 #pragma unroll
         for (int q = 0; q < 4; q++) lds_put(L, base + q * Q, f29_qnorm(x[q]));
         tile_sync<4 * M, (1u << LOG2B) / 4>();
-        tile_step<LOG2B, S + 1>(x, tw, L, t);
+        tile_step<LOG2B, S + 1, TW>(x, tw, L, t);
     } else if constexpr (LOG2B & 1) {
         // B = 2 * 4^STEPS: the radix-4 steps have built the two half-size transforms; one radix-2 stage of span B joins
         // them.  Thread t owns positions t + q*B/4 from here on (the exit ownership), i.e. the pairs (t, t + B/2) and
@@ -162,8 +162,8 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
         tile_sync<B, T>();
 #pragma unroll
         for (int q = 0; q < 4; q++) x[q] = lds_get(L, t + q * T);
-        const f29 ta = f29_montmul(x[2], f29_load_tab(tw + (B / 2 - 1) + t));
-        const f29 tb = f29_montmul(x[3], f29_load_tab(tw + (B / 2 - 1) + t + T));
+        const f29 ta = tab_mul(x[2], tab_get(tw + (B / 2 - 1) + t));
+        const f29 tb = tab_mul(x[3], tab_get(tw + (B / 2 - 1) + t + T));
         u = f29_add(x[0], ta); x[2] = f29_sub_k2(x[0], ta); x[0] = u;               // at-rest operands: + at most 2p
         u = f29_add(x[1], tb); x[3] = f29_sub_k2(x[1], tb); x[1] = u;
     }
@@ -171,10 +171,10 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const f29s* __restrict__ 
 // Size-B DIT transform.  Entry: x[q] = input number brev(4t + q) (bit-reversed load), normalised, < 3p.
 // Exit: x[q] = output number t + q*B/4 (natural order, the coalesced ownership pattern), lazy:
 // limbs < 2.5*2^30 + 8, value < 14p + 4p*(STEPS-1) + 2p <= 30p.
-template <int LOG2B>
-__device__ __forceinline__ void tile_dft(f29 (&x)[4], const f29s* __restrict__ tw, TileLds<LOG2B>& L, const uint32_t t) {
+template <int LOG2B, class TW>
+__device__ __forceinline__ void tile_dft(f29 (&x)[4], const TW tw, TileLds<LOG2B>& L, const uint32_t t) {
     static_assert(LOG2B >= 4 && LOG2B <= 10, "tile length 16 .. 1024 (36 bytes of LDS per element, static LDS <= 64 KiB)");
-    tile_step<LOG2B, 0>(x, tw, L, t);
+    tile_step<LOG2B, 0, TW>(x, tw, L, t);
 }
 
 }  // namespace lig
