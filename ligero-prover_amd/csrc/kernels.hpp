@@ -29,8 +29,8 @@ struct EncodePlan {
     f29wt twist{nullptr, 0, 0};      // w_n^(r*(j1 + 8*i2)) / k, [3][8][B] for r = 1..3, inside a tile in THREAD order: entry q*B/4 + t belongs to
                                   // position i2 = brev(4t + q), the element thread t loads as its q-th (adjacent lanes, adjacent entries)
     f29wt seam_fwd{nullptr, 0, 0};   // psi^(i1*q2), [8][B]
-    f29s* w8_inv = nullptr;     // powers of w_k^-(k/8): radix-8 constants (inverse), 8 entries
-    f29s* w8_fwd = nullptr;     // powers of psi^(k/8): radix-8 constants (forward), 8 entries
+    f29wt w8_inv{nullptr, 0, 0};     // powers of w_k^-(k/8): radix-8 constants (inverse), 8 entries
+    f29wt w8_fwd{nullptr, 0, 0};     // powers of psi^(k/8): radix-8 constants (forward), 8 entries
     f29s* kinv = nullptr;       // k^-1, 1 entry
 };
 

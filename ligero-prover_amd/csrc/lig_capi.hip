@@ -181,11 +181,12 @@ static int make_encode_plan(lig_ctx* c, const H::Fr& wk, const H::Fr& w4k) {
     // radix-8 constants: w8[i] = w^i, w = w_k^(-k/8) (inverse) / psi^(k/8) (forward); k^-1
     {
         std::vector<H::Fr> a = powers_plain(H::pow_u64(wk_inv, B), 8), b = powers_plain(H::pow_u64(psi, B), 8);
-        std::vector<lig::f29s> da(8), db(8), ki(1);
-        for (int i = 0; i < 8; i++) { da[i] = to_f29s(a[i]); db[i] = to_f29s(b[i]); }
+        std::vector<lig::f29w> da(8), db(8);
+        std::vector<lig::f29s> ki(1);
+        for (int i = 0; i < 8; i++) { da[i] = to_f29w(a[i]); db[i] = to_f29w(b[i]); }
         ki[0] = to_f29s(H::inv(H::from_u64(k)));
-        if ((rc = upload29(c, da, &ep.w8_inv)) != LIG_OK) return rc;
-        if ((rc = upload29(c, db, &ep.w8_fwd)) != LIG_OK) return rc;
+        if ((rc = upload29w(c, da, &ep.w8_inv)) != LIG_OK) return rc;
+        if ((rc = upload29w(c, db, &ep.w8_fwd)) != LIG_OK) return rc;
         if ((rc = upload29(c, ki, &ep.kinv)) != LIG_OK) return rc;
     }
     return LIG_OK;

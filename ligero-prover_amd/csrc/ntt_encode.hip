@@ -41,7 +41,7 @@ namespace lig {
 #endif
 template <int LOG2B>
 __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __restrict__ msgs, fr* __restrict__ Y, const f29wt seam_inv,
-                                                   const f29s* __restrict__ w8, size_t rows) {
+                                                   const f29wt w8, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = gid >> LOG2B;
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
     f29 a[8];
 #pragma unroll
     for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(m + (size_t)brev3(p) * B + i2));      // canonical inputs
-    radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
+    radix8_dit(a, w8);
     fr* y = Y + row * K;
     fr_store(y + i2, pack29(f29_reduce_2p(a[0])));
     // explicit unrolling: hipcc leaves a `#pragma unroll` loop over 7 Montgomery products rolled and then keeps a[] in scratch
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
 //        Coset 0 is not stored at all (it IS the message row, reversed); the batched prover reads its columns from there.
 //        Per row this writes 3k*32 bytes instead of 4k*32 and does not read the message.
 template <int LOG2B, int MODE>
-__global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29s* __restrict__ w8,
+__global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr* __restrict__ cw, const f29wt w8,
                                                     const fr* __restrict__ msgs, size_t rows) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
         f29 a[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
-        radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
+        radix8_dit(a, w8);
         fr* out = cw + rc * (size_t)K + q2;
 #pragma unroll
         for (int q1 = 0; q1 < 8; q1++) fr_store(out + (size_t)B * q1, pack29(f29_canon(a[q1])));
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
             f29 a[8];
 #pragma unroll
             for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
-            radix8_dit(a, f29_load_tab(w8 + 1), f29_load_tab(w8 + 2), f29_load_tab(w8 + 3));
+            radix8_dit(a, w8);
 #pragma unroll
             for (int q1 = 0; q1 < 8; q1++) v[q1] = pack29(f29_canon(a[q1]));
         }
@@ -177,14 +177,13 @@ __global__ void __launch_bounds__(256) k_encode_out(const fr* __restrict__ Z, fr
 // per group and position, ADDED to part[g][.] (the partials persist across chunks, prover_kernels.hip: k_rlc_partial has
 // the same contract).  Saves the k*32-byte write and re-read of the coset values per row and one launch.
 template <int LOG2B>
-__global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict__ Z, const f29s* __restrict__ w8, const fr* __restrict__ cw2,
+__global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict__ Z, const f29wt w8, const fr* __restrict__ cw2,
                                                            size_t cws, size_t rows, uint32_t group_rows, fr* __restrict__ part) {
     constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
     const uint32_t q2 = blockIdx.x * blockDim.x + threadIdx.x;
     if (q2 >= B) return;
     const size_t r0 = (size_t)blockIdx.y * group_rows;
     const size_t r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
-    const f29 w1 = f29_load_tab(w8 + 1), w2 = f29_load_tab(w8 + 2), w3 = f29_load_tab(w8 + 3);
     f29 acc[8];
 #pragma unroll
     for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_zero();
@@ -195,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict_
         f29 a[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
-        radix8_dit(a, w1, w2, w3);                                         // limbs < 2^31 + 8, value < 28p
+        radix8_dit(a, w8);                                                 // limbs < 2^31 + 8, value < 28p
 #pragma unroll
         for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_add(acc[q1], f29_montmul(a[q1], unpack29(fr_load(u + (size_t)B * q1))));   // each term < 1.2p
         if (++since == 6) {

@@ -9,9 +9,12 @@ namespace lig {
 __device__ __forceinline__ constexpr int brev3(int p) { return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1); }
 
 // Radix-8 DIT butterfly in registers.  In: a[p] = input number brev3(p), normalised limbs, value < 3p.
-// Out: a[j] = sum_i in[i] * w^(i*j), lazy (limbs < 2^31 + 8, value < 28p).  w1,w2,w3 = w, w^2, w^3 (Montgomery form).
-__device__ __forceinline__ void radix8_dit(f29 (&a)[8], const f29& w1, const f29& w2, const f29& w3) {
+// Out: a[j] = sum_i in[i] * w^(i*j), lazy (limbs < 2^31 + 8, value < 28p).  w8[1..3] = w, w^2, w^3 (either table format; the
+// entries are uniform, so their loads are broadcasts).
+template <class TW>
+__device__ __forceinline__ void radix8_dit(f29 (&a)[8], const TW w8) {
     f29 t, u;
+    const auto w2 = tab_get(w8 + 2);
     // span 2, twiddle 1.  u: limbs < 2^30, < 6p.  v = x - y + 4p: limbs < 2^31, < 7p.
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
@@ -25,7 +28,7 @@ __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const f29& w1, const f29
         u = f29_add(a[b], a[b + 2]);               // limbs < 2^31, < 12p
         a[b + 2] = f29_sub_k8(a[b], a[b + 2]);     // limbs < 3.5 * 2^30, < 14p
         a[b] = u;
-        t = f29_montmul(a[b + 3], w2);             // input limbs < 2^31
+        t = tab_mul(a[b + 3], w2);                 // input limbs < 2^31
         u = f29_add(a[b + 1], t);                  // limbs < 2.5 * 2^30, < 8.2p
         a[b + 3] = f29_sub_k2(a[b + 1], t);        // limbs < 3 * 2^30, < 9p
         a[b + 1] = u;
@@ -34,9 +37,9 @@ __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const f29& w1, const f29
     for (int i = 0; i < 8; i++) a[i] = f29_qnorm(a[i]);
     // span 8.  pair (0,4): twiddle 1, subtrahend limbs < 2^29+8, < 12p -> + 16p.  others: w, w^2, w^3.
     u = f29_add(a[0], a[4]); a[4] = f29_sub_k16(a[0], a[4]); a[0] = u;                 // < 24p | limbs < 2^31+8, < 28p
-    t = f29_montmul(a[5], w1); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
-    t = f29_montmul(a[6], w2); u = f29_add(a[2], t); a[6] = f29_sub_k2(a[2], t); a[2] = u;
-    t = f29_montmul(a[7], w3); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
+    t = tab_mul(a[5], tab_get(w8 + 1)); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
+    t = tab_mul(a[6], w2); u = f29_add(a[2], t); a[6] = f29_sub_k2(a[2], t); a[2] = u;
+    t = tab_mul(a[7], tab_get(w8 + 3)); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
 }
 
 // ---------------------------------------------------------------------------------------------------- tile transform
