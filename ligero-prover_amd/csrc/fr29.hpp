@@ -126,13 +126,18 @@ struct f29wv {
 // consecutive 128-byte lines per wave instead of 64 scattered ones (array-of-entries measured 22 % SLOWER than the 36-byte
 // Montgomery-form tables it replaced: the L1 tag rate, not the multiplier, was the limit).
 // (struct f29wt {base, stride}: fr.hpp, shared with the host-side plan structs)
+// Seven buffer loads that share ONE 32-bit lane offset: the plane offset travels in the scalar offset operand of
+// buffer_load_dwordx4, so a table access costs no vector address arithmetic at all (with global loads the compiler formed a
+// 64-bit address per plane: 6.6 v_lshl_add_u64 per product in the tile kernel).
 __device__ __forceinline__ f29wv f29_load_w(const f29wt p) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     f29wv r;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.base), 0, -1, 0x00020000);   // raw buffer, gfx9 data format word
     const uint32_t off = p.idx << 4;
+    const uint32_t plane = p.stride << 4;
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const char* pl = reinterpret_cast<const char*>(p.base + (size_t)i * p.stride);      // uniform: a scalar base per plane
-        const uint4 x = *reinterpret_cast<const uint4*>(pl + off);          // + one 32-bit lane offset (tables < 4 GiB)
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, i * plane, 0);
         r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
     }
     return r;
