@@ -455,6 +455,9 @@ def main():
                          "avg_launch_ms": 1e3 * avg_launch_s, "rows_per_launch": rows_per_launch, "launches": launches,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
                          "encode_row_bytes_survey_8d": (K_ + N_) * 32,
+                         # the same launches priced with SURVEY 8(d)'s whole-row encode figure (read k*32 + write n*32): this kernel
+                         # carries ~90 % of the encode's arithmetic, the two radix-8 passes around it move the remaining bytes
+                         "frac_with_survey_8d_row_bytes": rows_per_launch * (K_ + N_) * 32 / max(avg_launch_s, 1e-12) / 1e9 / 8000.0,
                          "one_proof_in_flight": None if not single_prof or not single_prof[0] else {
                              "avg_launch_ms": single_prof[2] / single_prof[0], "rows_per_launch": single_prof[1] / single_prof[0],
                              "achieved": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9,
