@@ -272,7 +272,8 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));      // copy stream
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    c->fast = lig::encode_fast_supported(k);
+    // LIG_ENCODE_GENERIC=1 (tests): take the generic radix-2 row path even where the tiled encoder exists
+    c->fast = lig::encode_fast_supported(k) && !(std::getenv("LIG_ENCODE_GENERIC") && std::getenv("LIG_ENCODE_GENERIC")[0] == '1');
     if (c->fast && (rc = make_encode_plan(c, wk, w4k)) != LIG_OK) return rc;
     c->tiled = lig::tiled_supported(ilog2u(k)) && lig::tiled_supported(ilog2u(n));
     if (c->tiled) {
@@ -411,7 +412,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                                   c->scratch_z, nr, e0, e1, mode);
         }
     } else if (mode == lig::ENC_PLANAR) {
-        // generic path (k > 8192), planar: codewords of a few rows at a time in the Z scratch, then one strided copy per plane
+        // generic path (k > 32768), planar: codewords of a few rows at a time in the Z scratch, then one strided copy per plane
         const size_t n = c->n, k = c->k, chunk = 64;
         int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
         if (rc != LIG_OK) return rc;

@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict_
     }
 }
 
-bool encode_fast_supported(uint32_t k) { return k == 512 || k == 1024 || k == 2048 || k == 4096 || k == 8192; }
+// tile length B = k/8 = 64 .. 4096: 36 bytes of LDS per element, i.e. 2.25 .. 144 KiB per workgroup of B/4 threads
+bool encode_fast_supported(uint32_t k) { return k >= 512 && k <= 32768 && (k & (k - 1)) == 0; }
 
 // mode: 0 = codewords rows x n (reference layout), 1 = rows x k (coset 2 only), 2 = rows x 3k (cosets 1..3 as planes),
 // 3 = coset 2 only, not stored: its products with the rows of dot.cw2 are added to the group partials dot.part
@@ -251,6 +252,8 @@ void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* o
         case 8: encode_rows_t<8>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
         case 9: encode_rows_t<9>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
         case 10: encode_rows_t<10>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 11: encode_rows_t<11>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 12: encode_rows_t<12>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
         default: break;
     }
 }

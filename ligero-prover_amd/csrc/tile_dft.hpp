@@ -176,7 +176,7 @@ __device__ __forceinline__ void tile_step(f29 (&x)[4], const TW tw, TileLds<LOG2
 // limbs < 2.5*2^30 + 8, value < 14p + 4p*(STEPS-1) + 2p <= 30p.
 template <int LOG2B, class TW>
 __device__ __forceinline__ void tile_dft(f29 (&x)[4], const TW tw, TileLds<LOG2B>& L, const uint32_t t) {
-    static_assert(LOG2B >= 4 && LOG2B <= 10, "tile length 16 .. 1024 (36 bytes of LDS per element, static LDS <= 64 KiB)");
+    static_assert(LOG2B >= 4 && LOG2B <= 12, "tile length 16 .. 4096 (36 bytes of LDS per element: 144 KiB of the 160 KiB of a CU at most)");
     tile_step<LOG2B, 0, TW>(x, tw, L, t);
 }
 

@@ -340,7 +340,8 @@ def test_rlc_and_gather_vs_oracle(ctx512):
     (320, 512, 2048, 0, 0),              # empty statement: only the three mask rows are committed
     (320, 512, 2048, 0, 321),            # quadratic constraints only (one full + one partial triple)
     (832, 1024, 4096, 2000, 900),        # tile length 128 = 2 * 4^3: fast path with the extra radix-2 stage
-    (16192, 16384, 65536, 20000, 16200), # k above the fast path (tile would not fit static LDS): generic radix-2 kernels end to end
+    (16192, 16384, 65536, 20000, 16200), # twice the production packing: tile length 2048 (72 KiB of LDS per workgroup)
+    (32576, 32768, 131072, 40000, 0),    # four times: tile length 4096 (144 KiB, one workgroup per CU)
     (8000, 8192, 32768, 3 * 8000 + 123, 8000 + 5),
 ])
 def test_batched_prover_equals_reference_structured_oracle(amd, l, k, n, n_linear, n_quad):
@@ -372,6 +373,27 @@ def test_batched_prover_equals_reference_structured_oracle(amd, l, k, n, n_linea
         cs = (C.c_uint64 * 4)(*pr.const_sum)
         buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
         assert ol.lib().lo_verify(C.byref(job), cs, buf, len(proof)) == 1
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
+
+
+@pytest.mark.parametrize("l,k,n,n_linear,n_quad", [(320, 512, 2048, 640, 330), (832, 1024, 4096, 1500, 0)])
+def test_generic_row_path_end_to_end(amd, monkeypatch, l, k, n, n_linear, n_quad):
+    """contexts without the tiled encoder (k > 32768) take the generic radix-2 row path: planar codewords through strided
+    copies, coset-2 values stored and accumulated by the separate pass.  Forced here at small k (LIG_ENCODE_GENERIC=1)."""
+    monkeypatch.setenv("LIG_ENCODE_GENERIC", "1")
+    c = amd.Context(l, k, n)
+    try:
+        tr = c.synth_prepare(n_linear, n_quad, generated_at=77)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+    finally:
+        c.close()
+    job = ol.make_job(l, k, n, 192, n_linear, n_quad, generated_at=77, threads=4)
+    pr = ol.Proof()
+    assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) == 0
+    try:
+        assert proof == bytes(pr.proof[:pr.proof_len])
     finally:
         ol.lib().lo_proof_free(C.byref(pr))
 
