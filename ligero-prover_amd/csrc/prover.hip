@@ -352,7 +352,10 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     fr* rhalf = T->rcw;                                   // chunk x 2k
     // The randomness rows of chunk b+1 (AES sampling: LDS-bound; or the upload of the caller's rows) are formed on the side
     // stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
-    const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_tune::CHUNK, 96, 0);
+    // first chunk 192 rows (the encode stream waits for the first randomness rows); LIG_S2_HEAD overrides for experiments
+    // (profiles/r02_stage1_schedule_ab.md: 192-256 rows +3 % proofs/s over 96 with two proofs in flight)
+    static const size_t s2_head = [] { const char* e = std::getenv("LIG_S2_HEAD"); return e ? (size_t)std::atoi(e) : (size_t)192; }();
+    const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_tune::CHUNK, s2_head, 0);
     const size_t n_chunks = sched2.size();
     std::vector<uint64_t> chunk_pos(n_chunks + 1, 0);
     for (size_t ci = 0; ci < n_chunks; ci++) {
