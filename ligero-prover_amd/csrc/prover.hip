@@ -283,12 +283,13 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
         static const int gate = [] { const char* e = std::getenv("LIG_SHA_GATE"); return e ? std::atoi(e) : 1; }();
-        if (gate && nb > 4) {
+        static const size_t g = [] { const char* e = std::getenv("LIG_SHA_GATE_ROWS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (size_t)v : (size_t)2; }();   // experiments
+        if (gate && nb > 2 * g) {
             // the hash waves must be placed while the chip is idle (one per SIMD, evenly): hash the first two rows, let the
             // encode stream wait for that, and queue the rest of the chunk right behind it on the hash stream
-            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, 2, absorbed, k, T->msgs + b * k);
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, g, absorbed, k, T->msgs + b * k);
             HIP_TRY(c, hipEventRecord(T->ev_gate, s_sha));
-            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + (b + 2) * k3, 0, nb - 2, absorbed + 2, k, T->msgs + (b + 2) * k);
+            lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + (b + g) * k3, 0, nb - g, absorbed + g, k, T->msgs + (b + g) * k);
             HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_gate, 0));
         } else {
             lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, nb, absorbed, k, T->msgs + b * k);
