@@ -11,9 +11,13 @@ HBM (generated on the GPU with the reference's AES-256-CTR field sampler, key SH
            seeds, column sampling, decommitment, prover self-check (3 decodes), column gather, protobuf envelope.
            The timed region ends with the proof bytes in host memory.
   encode : configs[1] -- 2^20 constraints = 132 rows, RS-encode only (INTT_k + NTT_4k)
-N > 1: one process per GPU (torch.distributed over RCCL, launched by torch.distributed.run); traces are
-independent objects, so every rank proves its own trace (weak scaling, no data-path collective); the timed
-region is bracketed by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run the ranks exist already (WORLD_SIZE must equal --gpus);
+a plain `python bench.py --gpus N` spawns the N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each).
+`value`: traces are independent objects, so every rank proves its own traces (weak scaling, no data-path collective); the
+timed region is bracketed by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.  For N > 1 the line also
+carries `sharded`: configs[3] -- ONE 2^26-constraint trace row-sharded over the N ranks (column-partitioned hash after a
+per-round all-to-all of codeword column slices, all-gathered leaves / partial sums / opened columns, all on RCCL), with
+its own barrier-bracketed timing, the number of ranks RCCL reports and the comparison with the oracle's pin.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -267,6 +271,7 @@ class ShardedWorkload:
         self.comm = group.make_comm(pkg, ctx)
         self.shard = ctx.shard_prepare(self.job, group.rank, group.world, self.comm)
         self.rows = -(-constraints // L_)
+        self.rounds = pkg.shard_plan(self.job, L_, group.world)[0]
         self.last = None
         ctx.sync()
 
@@ -275,6 +280,7 @@ class ShardedWorkload:
         if not (info.valid_code and info.valid_linear and info.valid_quad):
             raise SystemExit("prover self-check failed")
         self.last = (addr, length, info.ms_stage1, info.ms_stage2, info.ms_stage3, info.ms_total)
+        self.last_info = info
 
     def describe(self):
         d = {"workload": "configs[3]-style: ONE 2^%d-constraint trace row-sharded over the GPUs, full proof"
@@ -288,6 +294,106 @@ class ShardedWorkload:
 
     def close(self):
         self.ctx.shard_destroy(self.shard)
+
+
+class StubWorkload:
+    """no GPU work at all: the launcher / process-group plumbing of this script under test on CPU (gloo), tests/test_bench_launcher.py"""
+    name = "stub"
+    constraints = 1000
+
+    def step(self):
+        time.sleep(0.001)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one process per GPU) and relay rank 0's output"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()),
+               LIG_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):          # one rank died: the others would wait in a collective forever
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.05)
+    return max(abs(rc) for rc in rcs)
+
+
+def run_stub(a, lig_dist):
+    """--workload stub: barrier / MAX-over-ranks / single JSON line with no GPU in sight"""
+    group = lig_dist.Group(a.backend or "gloo")
+    wl = StubWorkload()
+    for _ in range(a.warmup):
+        wl.step()
+    group.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.step()
+    group.barrier()
+    dt = group.max_over_ranks(time.perf_counter() - t0)
+    total = group.sum_over_ranks(wl.constraints * a.steps)
+    if group.rank == 0:
+        print(json.dumps({"metric": "prover constraints/sec", "value": total / dt, "unit": "constraints/s", "n_gpus": group.world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub (launcher test, no GPU work)"},
+                          "spawned_by_bench": bool(os.environ.get("LIG_BENCH_SPAWNED"))}), flush=True)
+    group.close()
+
+
+def sharded_leg(ctx, group, pkg, log2c, steps, warmup, fence):
+    """configs[3]: ONE trace sharded over all ranks, timed like the main region (barrier + synchronize on both sides, MAX over
+    ranks).  Collective: every rank calls it."""
+    swl = ShardedWorkload(ctx, 1 << log2c, group, pkg)
+    try:
+        for _ in range(warmup):
+            swl.step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            swl.step()
+        fence()
+        dt = group.max_over_ranks(time.perf_counter() - t0)
+        d = swl.describe()
+        out = {"workload": d["workload"], "log2_constraints": log2c, "rows": d["rows"], "ranks": group.world, "steps": steps, "warmup": warmup,
+               "ms_per_proof": 1e3 * dt / steps, "constraints_per_s": (1 << log2c) * steps / dt, "scaling": "strong",
+               "stage_ms": d.get("stage_ms"), "proof_bytes": d.get("proof_bytes"), "proof_sha256": d.get("proof_sha256"),
+               "exchange_rounds": swl.rounds, "collectives": "librccl: grouped ncclSend/ncclRecv per round + ncclAllGather (leaves, partial sums, opened columns)"}
+        try:
+            out["rccl_ranks"] = ctx.rccl_comm_count(swl.comm)          # ncclCommCount of the communicator the proofs ran on
+            out["rccl_library"] = pkg.rccl_available()[1]
+        except pkg.LigError:
+            out["rccl_ranks"] = None
+        pin_path = os.path.join(ROOT, "tests", "golden", "full_pin_2p%d.json" % log2c)
+        if os.path.exists(pin_path):
+            with open(pin_path) as f:
+                pin = json.load(f)
+            out["proof_equals_oracle_pin"] = bool(out["proof_sha256"] == pin["proof_sha256"] and bytes(swl.last_info.root).hex() == pin["root"])
+        digs = group.gather_digests(hashlib.sha256(C.string_at(swl.last[0], swl.last[1])).digest())
+        out["all_ranks_same_envelope"] = len(set(digs)) == 1
+        return out
+    finally:
+        swl.close()
 
 
 def cpu_baseline(workload_name, budget_s=20.0):
@@ -337,7 +443,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded"])
+    ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded", "stub"])
+    ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the stub workload uses gloo)")
+    ap.add_argument("--sharded-log2", type=int, default=26, help="N > 1: size of the ONE trace sharded over the ranks (configs[3]: 2^26)")
+    ap.add_argument("--sharded-steps", type=int, default=5)
+    ap.add_argument("--sharded-leg", action="store_true", help="run the configs[3] leg with one rank as well")
+    ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--log2-constraints", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed, informational) HIP verifier run on the last proof")
@@ -349,19 +460,29 @@ def main():
     global NO_VERIFY
     NO_VERIFY = a.no_verify
     log2c = a.log2_constraints if a.log2_constraints is not None else (20 if a.workload == "encode" else 24)
-
-    import torch
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))         # no launcher around us: be the launcher
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- the line would report the wrong number of GPUs" % (a.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    pkg = load_pkg()
     spec = importlib.util.spec_from_file_location("lig_dist", os.path.join(ROOT, "ligero-prover_amd", "dist.py"))
     lig_dist = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lig_dist)
-    group = lig_dist.Group("nccl")          # RCCL over xGMI; a no-op object when WORLD_SIZE == 1
+    if a.workload == "stub":
+        return run_stub(a, lig_dist)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > 1 and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d of %d has no GPU of its own (%d visible)" % (local_rank, world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    pkg = load_pkg()
+    group = lig_dist.Group(a.backend or "nccl")          # RCCL over xGMI; a no-op object when WORLD_SIZE == 1
     dist = group.dist
 
     ctx = pkg.Context(L_, K_, N_, device=local_rank)
@@ -482,14 +603,21 @@ def main():
             out["value_incl_h2d"] = incl["value"]
             out["incl_h2d"] = incl
             out["incl_h2d"]["same_proof_bytes"] = incl["proof_sha256"] == out["config"].get("proof_sha256")
+    else:
+        out = None
+    wl.close()
+    if a.workload == "full" and not a.no_sharded_leg and (world > 1 or a.sharded_leg):
+        sh = sharded_leg(ctx, group, pkg, a.sharded_log2, a.sharded_steps, 2, fence)       # collective: all ranks
+        if out is not None:
+            out["sharded"] = sh
+    if out is not None:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl.name)
         result = json.dumps(out)
     else:
         result = None
-    wl.close()
+    group.close()               # the RCCL communicator lives on the context's streams: it goes first
     ctx.close()
-    group.close()
     try:                            # RCCL prints its banner through C stdio, which is block-buffered when stdout is a pipe:
         C.CDLL(None).fflush(None)   # push it out now so that the JSON line below really is the last line
     except OSError:

@@ -310,13 +310,27 @@ typedef struct {
      * place for work enqueued on that stream afterwards */
     int (*all_to_all_on)(void *user, const void *send_dev, void *recv_dev, size_t block_bytes, void *hip_stream);
     int (*all_gather_on)(void *user, const void *send_dev, void *recv_dev, size_t bytes, void *hip_stream);
+    /* optional (NULL: nothing to do): the caller is about to free device buffers it has passed as send buffers -- a
+     * communicator that maps the peers' buffers (lig_ipc_comm_create) must not keep them mapped under a recycled address */
+    void (*forget)(void *user);
 } lig_comm;
 /* RCCL communicator: rank 0 calls lig_rccl_unique_id and hands the 128 bytes to every rank through the launcher's
  * rendezvous (torch.distributed / MPI / a file); every rank then calls lig_rccl_comm_create with its context. */
 enum { LIG_RCCL_ID_BYTES = 128 };
 int  lig_rccl_unique_id(uint8_t out[LIG_RCCL_ID_BYTES]);
 int  lig_rccl_comm_create(lig_ctx *ctx, const uint8_t id[LIG_RCCL_ID_BYTES], uint32_t rank, uint32_t world, lig_comm *out);
-void lig_rccl_comm_destroy(lig_comm *comm);
+void lig_rccl_comm_destroy(lig_comm *comm);               /* safe before or after lig_ctx_destroy of its context */
+/* librccl is resolved on first use (the copy already mapped into the process wins, then the loader path, then /opt/rocm/lib;
+ * LIG_RCCL_LIB overrides): LIG_OK and the library's path / ncclGetVersion, or LIG_E_STATE and the reason in path_out */
+int  lig_rccl_available(char *path_out, size_t cap, int *version);
+int  lig_rccl_comm_count(const lig_comm *comm, uint32_t *ranks);      /* ncclCommCount of a communicator made here */
+/* A second communicator with stream-ordered forms, between processes that can map each other's device memory (same GPU, or
+ * GPUs of one node with peer access): every rank pulls its blocks out of the peers' send buffers (hipIpcMemHandle), ordering is
+ * done by the GPU on flags in the POSIX shared-memory segment `shm_name` ("/name"; rank 0 creates it, all ranks must pass the
+ * same fresh name), no host thread waits for GPU work.  This is what the tests use to run the exchange pipeline of
+ * lig_shard_prove with real peers on a one-GPU box (W processes on the device); world <= 16. */
+int  lig_ipc_comm_create(lig_ctx *ctx, const char *shm_name, uint32_t rank, uint32_t world, lig_comm *out);
+void lig_ipc_comm_destroy(lig_comm *comm);                /* collective: returns when every rank has left (or after 15 s) */
 /* host only: the block-cyclic deal of a job's committed rows (masks excluded) for packing size l: *rounds exchange rounds,
  * world * rounds + 1 chunk boundaries (chunk g = rows [b[g], b[g+1]) belongs to rank g mod world).  LIG_E_NOMEM: cap too small. */
 int  lig_shard_plan(const lig_synth_job *job, uint32_t l, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);

@@ -33,7 +33,8 @@ EXPORTS = [
     "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
     "lig_rows_verify_begin", "lig_rows_verify_finish",
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
-    "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_shard_plan",
+    "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
+    "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
 ]
 
 ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
@@ -54,7 +55,7 @@ A2A_ON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
 class Comm(C.Structure):
     """lig_comm: host-synchronous callbacks (tests over gloo) and, when made by lig_rccl_comm_create, the stream-ordered RCCL forms"""
     _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN),
-                ("all_to_all_on", A2A_ON_FN), ("all_gather_on", A2A_ON_FN)]
+                ("all_to_all_on", A2A_ON_FN), ("all_gather_on", A2A_ON_FN), ("forget", C.CFUNCTYPE(None, C.c_void_p))]
 
 
 class SynthJob(C.Structure):
@@ -183,6 +184,11 @@ def load_library():
     L.lig_rccl_comm_create.argtypes = [vp, vp, u32, u32, C.POINTER(Comm)]
     L.lig_rccl_comm_destroy.argtypes = [C.POINTER(Comm)]
     L.lig_rccl_comm_destroy.restype = None
+    L.lig_ipc_comm_create.argtypes = [vp, C.c_char_p, u32, u32, C.POINTER(Comm)]
+    L.lig_ipc_comm_destroy.argtypes = [C.POINTER(Comm)]
+    L.lig_ipc_comm_destroy.restype = None
+    L.lig_rccl_available.argtypes = [C.c_char_p, sz, C.POINTER(C.c_int)]
+    L.lig_rccl_comm_count.argtypes = [C.POINTER(Comm), C.POINTER(u32)]
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -215,6 +221,14 @@ def instance_hash(args):
     if L.lig_instance_hash(_hptr(blob), _hptr(lens), len(args), _hptr(out)) != 0:
         raise LigError("lig_instance_hash failed")
     return out.tobytes()
+
+
+def rccl_available():
+    """-> (ok, path of the librccl the library resolved or the reason it could not, ncclGetVersion code)"""
+    L = load_library()
+    buf, ver = C.create_string_buffer(512), C.c_int()
+    rc = L.lig_rccl_available(buf, 512, C.byref(ver))
+    return rc == 0, buf.value.decode(), ver.value
 
 
 def shard_plan(job, l, world):
@@ -381,6 +395,20 @@ class Context:
 
     def rccl_comm_destroy(self, comm):
         self.L.lig_rccl_comm_destroy(C.byref(comm))
+
+    def ipc_comm(self, shm_name, rank, world):
+        """the process-to-process communicator (csrc/comm_ipc.hip): same fresh "/name" on every rank"""
+        comm = Comm()
+        self.check(self.L.lig_ipc_comm_create(self.h, shm_name.encode(), rank, world, C.byref(comm)))
+        return comm
+
+    def ipc_comm_destroy(self, comm):
+        self.L.lig_ipc_comm_destroy(C.byref(comm))
+
+    def rccl_comm_count(self, comm):
+        n = C.c_uint32()
+        self.check(self.L.lig_rccl_comm_count(C.byref(comm), C.byref(n)))
+        return n.value
 
     # ---- one trace sharded over ranks (comm: a Comm built by dist.Group.make_comm)
     def shard_prepare(self, job, rank, world, comm):

@@ -1,0 +1,259 @@
+// comm_ipc.hip -- stream-ordered collectives between PROCESSES that can map each other's device memory (lig_ipc_*).
+//
+// The second implementation of lig_comm's stream-ordered forms (the product's is comm_rccl.hip).  It exists so that the
+// sharded prover's double-buffered exchange pipeline (shard.hip: ev_enc / ev_comm / ev_hash) runs with REAL peers on a box
+// that has one GPU: W processes share the device, every rank pulls its blocks straight out of the peers' send buffers
+// (hipIpcMemHandle: the peer's allocation is mapped into this process), and all ordering is done by the GPU's command
+// processors on flags in POSIX shared memory (hipStreamWriteValue32 / hipStreamWaitValue32 on a hipHostRegister'ed page):
+// no host thread ever waits for GPU work.  Between GPUs of one node the same code moves the data over xGMI peer access
+// (hipIpcMemLazyEnablePeerAccess); RCCL remains the product path there.
+//
+//   all_to_all_on(send, recv, block, st), call number c (the same on every rank: collectives are called in program order):
+//     host   : publish {IPC handle of send's allocation, offset} as publication c; read the peers' publication c
+//     stream : ready[me] <- c                                   (everything queued on `st` before: my send data is complete)
+//              for each peer h: wait ready[h] >= c; recv[h] <- peer_h.send[me]      (device-to-device copy)
+//              pulled[me] <- c; for each peer h: wait pulled[h] >= c               (my send buffer is free again: like a
+//                                                                                  completed ncclSend)
+// The host side only waits for the peers' HOSTS to reach the same call (a few microseconds of skew), never for a GPU.
+// Verified on the target box by tools/ipc_probe.hip (memory handles: an interior pointer exports its allocation's BASE,
+// hence the explicit offset; stream memory operations on registered shared memory; profiles/r03_ipc_probe.txt).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ctx_internal.hpp"
+
+namespace {
+
+constexpr uint32_t MAXW = 16, RING = 4, MAGIC = 0x4c494743u;      // "LIGC"
+// flags: one 64-byte line per (rank, call mod SLOTS).  Consecutive collectives may be enqueued on different streams of a
+// rank (the exchange on the copy stream, the gathers on the main stream): with a slot per call a late "ready <- c" can
+// never overwrite "ready <- c+1"
+constexpr uint32_t SLOTS = 8, FLAG_STRIDE = 16, FLAGS_PER_KIND = MAXW * SLOTS * FLAG_STRIDE;      // u32 units
+
+struct Pub {
+    std::atomic<uint64_t> seq;
+    hipIpcMemHandle_t handle;
+    uint64_t offset;
+    uint64_t epoch;               // bumped by the exporter's forget(): handles published earlier may name freed allocations
+};
+struct Shm {
+    std::atomic<uint32_t> magic, arrived, departed;
+    uint32_t world;
+    Pub pub[MAXW][RING];
+    alignas(4096) uint32_t ready[FLAGS_PER_KIND];
+    uint32_t pulled[FLAGS_PER_KIND];
+};
+constexpr size_t FLAG_BYTES = 2 * FLAGS_PER_KIND * sizeof(uint32_t);
+static_assert(FLAG_BYTES % 4096 == 0, "whole pages are registered");
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+
+struct Mapping { hipIpcMemHandle_t h; uint64_t epoch; uint8_t* base; };
+
+struct IpcComm {
+    lig_ctx* ctx = nullptr;
+    uint32_t rank = 0, world = 1;
+    std::string name;
+    Shm* shm = nullptr;
+    uint32_t* ready_dev = nullptr;      // device view of shm->ready (pulled follows at + FLAGS_PER_KIND)
+    uint64_t calls = 0, epoch = 0;
+    std::vector<Mapping> maps[MAXW];
+    bool registered = false;
+};
+
+using clk = std::chrono::steady_clock;
+constexpr int HOST_TIMEOUT_S = 120;
+
+int fail(IpcComm* r, const std::string& msg) {
+    if (r && r->ctx) r->ctx->err = "ipc comm: " + msg;
+    return 1;
+}
+
+template <class Pred>
+bool host_wait(Pred done, int timeout_s = HOST_TIMEOUT_S) {
+    const auto t0 = clk::now();
+    for (unsigned spins = 0; !done(); spins++) {
+        if (spins > 2000) usleep(50);
+        if ((spins & 255) == 255 && clk::now() - t0 > std::chrono::seconds(timeout_s)) return false;
+    }
+    return true;
+}
+
+// peer h's pointer for publication `c` (mapped on first sight of the handle)
+int peer_pointer(IpcComm* r, uint32_t h, uint64_t c, const uint8_t** out) {
+    Pub& p = r->shm->pub[h][c % RING];
+    if (!host_wait([&] { return p.seq.load(std::memory_order_acquire) == c; })) return fail(r, "peer " + std::to_string(h) + " never reached collective " + std::to_string(c));
+    const hipIpcMemHandle_t hd = p.handle;
+    const uint64_t off = p.offset, ep = p.epoch;
+    auto& maps = r->maps[h];
+    // mappings of an older epoch name allocations the peer has freed since (it drained its streams first, and its collectives
+    // only complete once every rank has pulled: nothing of ours still reads them) -- the same handle bytes may come back for a
+    // new allocation, so they must go
+    for (size_t i = 0; i < maps.size();)
+        if (maps[i].epoch != ep) { (void)hipIpcCloseMemHandle(maps[i].base); maps.erase(maps.begin() + i); } else i++;
+    for (const Mapping& m : maps)
+        if (!std::memcmp(&m.h, &hd, sizeof hd)) { *out = m.base + off; return 0; }
+    void* base = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&base, hd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(r, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+    maps.push_back({hd, ep, static_cast<uint8_t*>(base)});
+    *out = static_cast<uint8_t*>(base) + off;
+    return 0;
+}
+
+// common part: publish my send buffer, return the call number
+int publish(IpcComm* r, const void* send, uint64_t* call) {
+    const uint64_t c = ++r->calls;
+    Pub& p = r->shm->pub[r->rank][c % RING];
+    void* base = nullptr;
+    size_t size = 0;
+    hipError_t e = hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)send);
+    if (e != hipSuccess) return fail(r, std::string("hipMemGetAddressRange: ") + hipGetErrorString(e));
+    e = hipIpcGetMemHandle(&p.handle, base);
+    if (e != hipSuccess) return fail(r, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    p.offset = (uint64_t)(static_cast<const uint8_t*>(send) - static_cast<const uint8_t*>(base));
+    p.epoch = r->epoch;
+    p.seq.store(c, std::memory_order_release);
+    *call = c;
+    return 0;
+}
+
+#define IPC_TRY(r, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail((r), std::string(#call) + ": " + hipGetErrorString(e__)); } while (0)
+
+// what = 0: all-to-all (recv block h <- peer h's send block `me`), 1: all-gather (recv block h <- peer h's send)
+int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t bytes, hipStream_t st) {
+    if (!r->shm || !r->ctx) return 1;
+    if (hipSetDevice(r->ctx->device) != hipSuccess) return fail(r, "hipSetDevice");
+    const uint32_t W = r->world, me = r->rank;
+    uint64_t c = 0;
+    if (publish(r, send, &c)) return 1;
+    const uint8_t* src[MAXW];
+    for (uint32_t i = 1; i < W; i++) {
+        const uint32_t h = (me + i) % W;
+        if (peer_pointer(r, h, c, &src[h])) return 1;
+    }
+    src[me] = static_cast<const uint8_t*>(send);
+    const uint32_t slot = (uint32_t)(c % SLOTS);
+    uint32_t* ready = r->ready_dev + slot * FLAG_STRIDE;                 // + rank * SLOTS * FLAG_STRIDE
+    uint32_t* pulled = ready + FLAGS_PER_KIND;
+    constexpr uint32_t RS = SLOTS * FLAG_STRIDE;
+    const uint32_t v = (uint32_t)c;
+    IPC_TRY(r, hipStreamWriteValue32(st, ready + me * RS, v, 0));
+    for (uint32_t i = 0; i < W; i++) {
+        const uint32_t h = (me + i) % W;                    // own block first, then the peers in a rotated order (no hot spot)
+        if (h != me) IPC_TRY(r, hipStreamWaitValue32(st, ready + h * RS, v, hipStreamWaitValueGte, 0xffffffffu));
+        const uint8_t* from = src[h] + (what == 0 ? (size_t)me * bytes : 0);
+        if (bytes) IPC_TRY(r, hipMemcpyAsync(static_cast<uint8_t*>(recv) + (size_t)h * bytes, from, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    IPC_TRY(r, hipStreamWriteValue32(st, pulled + me * RS, v, 0));
+    for (uint32_t i = 1; i < W; i++) {
+        const uint32_t h = (me + i) % W;
+        IPC_TRY(r, hipStreamWaitValue32(st, pulled + h * RS, v, hipStreamWaitValueGte, 0xffffffffu));
+    }
+    return 0;
+}
+
+int a2a_on(void* user, const void* send, void* recv, size_t block, void* stream) { return collective_on(static_cast<IpcComm*>(user), 0, send, recv, block, static_cast<hipStream_t>(stream)); }
+int ag_on(void* user, const void* send, void* recv, size_t bytes, void* stream) { return collective_on(static_cast<IpcComm*>(user), 1, send, recv, bytes, static_cast<hipStream_t>(stream)); }
+// the caller is about to free device buffers it has used as send buffers
+void forget(void* user) { static_cast<IpcComm*>(user)->epoch++; }
+int a2a_sync(void* user, const void* send, void* recv, size_t block) {
+    IpcComm* r = static_cast<IpcComm*>(user);
+    if (!r->ctx || a2a_on(user, send, recv, block, r->ctx->stream)) return 1;
+    return hipStreamSynchronize(r->ctx->stream) == hipSuccess ? 0 : 1;
+}
+int ag_sync(void* user, const void* send, void* recv, size_t bytes) {
+    IpcComm* r = static_cast<IpcComm*>(user);
+    if (!r->ctx || ag_on(user, send, recv, bytes, r->ctx->stream)) return 1;
+    return hipStreamSynchronize(r->ctx->stream) == hipSuccess ? 0 : 1;
+}
+
+void finalize(IpcComm* r) {
+    if (r->ctx) {
+        (void)hipSetDevice(r->ctx->device);
+        (void)hipStreamSynchronize(r->ctx->stream); (void)hipStreamSynchronize(r->ctx->stream2); (void)hipStreamSynchronize(r->ctx->stream3);
+    }
+    for (uint32_t h = 0; h < MAXW; h++) {
+        for (const Mapping& m : r->maps[h]) (void)hipIpcCloseMemHandle(m.base);
+        r->maps[h].clear();
+    }
+    if (r->shm) {
+        // nobody may unmap / unlink while a peer's stream still polls the flags: leave together
+        r->shm->departed.fetch_add(1);
+        (void)host_wait([&] { return r->shm->departed.load() >= r->world; }, 15);
+        if (r->registered) (void)hipHostUnregister(r->shm->ready);
+        (void)munmap(r->shm, sizeof(Shm));
+        if (r->rank == 0) (void)shm_unlink(r->name.c_str());
+    }
+    r->shm = nullptr;
+    r->ctx = nullptr;
+}
+void finalize_erased(void* p) { finalize(static_cast<IpcComm*>(p)); }
+
+}  // namespace
+
+extern "C" {
+
+int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_t world, lig_comm* out) {
+    CHECK_CTX(c);
+    if (!shm_name || shm_name[0] != '/' || !out || !world || world > MAXW || rank >= world) return LIG_E_ARG;
+    std::memset(out, 0, sizeof *out);
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+    if (!can) FAIL(c, LIG_E_STATE, "ipc comm: the device has no stream memory operations");
+    IpcComm* r = new IpcComm();
+    r->ctx = c; r->rank = rank; r->world = world; r->name = shm_name;
+    auto bail = [&](const std::string& msg, int code) { c->err = "ipc comm: " + msg; if (r->shm) (void)munmap(r->shm, sizeof(Shm)); delete r; return code; };
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(shm_name);
+        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(Shm)) != 0) { if (fd >= 0) close(fd); return bail("shm_open(create) failed", LIG_E_STATE); }
+    } else if (!host_wait([&] { fd = shm_open(shm_name, O_RDWR, 0600); if (fd < 0) usleep(1000); return fd >= 0; })) {
+        return bail("the shared segment never appeared", LIG_E_STATE);
+    }
+    // (rank 0 may have created the name but not sized the segment yet: touching pages beyond the end would raise SIGBUS)
+    if (!host_wait([&] { struct stat sb; return fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(Shm); }, 30)) { close(fd); return bail("segment has the wrong size", LIG_E_STATE); }
+    void* m = mmap(nullptr, sizeof(Shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return bail("mmap failed", LIG_E_STATE);
+    r->shm = static_cast<Shm*>(m);
+    if (rank == 0) {                               // a fresh segment is zero-filled: publication counters and flags start at 0
+        r->shm->world = world;
+        r->shm->magic.store(MAGIC, std::memory_order_release);
+    } else if (!host_wait([&] { return r->shm->magic.load(std::memory_order_acquire) == MAGIC; }) || r->shm->world != world) {
+        return bail("segment not initialised by rank 0 (or another world size)", LIG_E_STATE);
+    }
+    if (hipHostRegister(r->shm->ready, FLAG_BYTES, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&r->ready_dev, r->shm->ready, 0) != hipSuccess)
+        return bail("hipHostRegister of the flag page failed", LIG_E_HIP);
+    r->registered = true;
+    r->shm->arrived.fetch_add(1);
+    if (!host_wait([&] { return r->shm->arrived.load() >= world; })) { (void)hipHostUnregister(r->shm->ready); return bail("not all ranks arrived", LIG_E_STATE); }
+    c->comms.push_back({r, finalize_erased});
+    out->user = r;
+    out->all_to_all = a2a_sync;
+    out->all_gather = ag_sync;
+    out->all_to_all_on = a2a_on;
+    out->all_gather_on = ag_on;
+    out->forget = forget;
+    return LIG_OK;
+}
+
+void lig_ipc_comm_destroy(lig_comm* comm) {
+    if (!comm || !comm->user || comm->all_to_all_on != a2a_on) return;
+    IpcComm* r = static_cast<IpcComm*>(comm->user);
+    if (r->ctx) lig_internal_comm_unregister(r->ctx, r);
+    finalize(r);
+    delete r;
+    std::memset(comm, 0, sizeof *comm);
+}
+
+}  // extern "C"

@@ -44,7 +44,20 @@ struct lig_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
     uint64_t prof_rows = 0;
+    // communicators made on this context (comm_rccl.hip, comm_ipc.hip): (object, its finalizer); ended with the context
+    std::vector<std::pair<void*, void (*)(void*)>> comms;
 };
+
+// end every communicator that still lives on the context (each finalizer drains the context's streams first and clears the
+// object's back pointer); called by lig_ctx_destroy
+inline void lig_internal_comms_release(lig_ctx* c) {
+    auto v = std::move(c->comms);
+    c->comms.clear();
+    for (auto& e : v) e.second(e.first);
+}
+inline void lig_internal_comm_unregister(lig_ctx* c, void* obj) {
+    for (size_t i = 0; i < c->comms.size(); i++) if (c->comms[i].first == obj) { c->comms.erase(c->comms.begin() + i); return; }
+}
 
 // mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes)
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr);

@@ -300,7 +300,10 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
 void lig_ctx_destroy(lig_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // the provers and the verifier queue work on all three streams (hash / sampler / RCCL gathers on stream2, uploads and the
+    // exchange on stream3): an early error return may have left some of it in flight
+    for (hipStream_t st : {c->stream, c->stream2, c->stream3}) if (st) (void)hipStreamSynchronize(st);
+    lig_internal_comms_release(c);
     for (void* p : c->owned) (void)hipFree(p);
     (void)hipFree(c->scratch_y); (void)hipFree(c->scratch_z); (void)hipFree(c->sample_idx);
     (void)hipFree(c->rk_dev); (void)hipFree(c->small_dev); (void)hipFree(c->tri_dev);

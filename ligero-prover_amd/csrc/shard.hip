@@ -244,6 +244,7 @@ void lig_shard_destroy(lig_shard* S) {
     (void)hipStreamSynchronize(S->c->stream);
     (void)hipStreamSynchronize(S->c->stream2);
     (void)hipStreamSynchronize(S->c->stream3);
+    if (S->comm.forget) S->comm.forget(S->comm.user);       // the send buffers below are about to be freed
     S->c->sha.erase(S->sha_state);
     for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->maskcw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
                     (void*)S->parts, (void*)S->accp, (void*)S->accg, (void*)S->dots, (void*)S->smp, (void*)S->smpg, (void*)S->sha_state,

@@ -73,6 +73,15 @@ class Group:
         import numpy as np
         import torch
         g = self
+        if os.environ.get("LIG_COMM") == "ipc":
+            # the process-to-process communicator (csrc/comm_ipc.hip): peers map each other's send buffers, the GPU orders the
+            # copies on flags in a POSIX shared-memory segment; torch.distributed (any backend) is only the launcher's rendezvous.
+            # Every communicator needs a fresh segment name, the same on all ranks: launcher tag + a per-group counter.
+            self._ipc_n = getattr(self, "_ipc_n", 0) + 1
+            name = "/lig_ipc_%s_%s_%d" % (os.environ.get("LIG_COMM_TAG", "0"), os.environ.get("MASTER_PORT", "0"), self._ipc_n)
+            comm = ctx.ipc_comm(name, g.rank, g.world)
+            self._ipc = getattr(self, "_ipc", []) + [(ctx, comm)]
+            return comm
         if g.backend == "nccl":
             uid = ctx.rccl_unique_id() if g.rank == 0 else bytes(128)
             if g.dist is not None:
@@ -124,6 +133,9 @@ class Group:
         return comm
 
     def close(self):
+        for ctx, comm in getattr(self, "_ipc", []):
+            ctx.ipc_comm_destroy(comm)
+        self._ipc = []
         if getattr(self, "_rccl", None):
             ctx, comm = self._rccl
             ctx.rccl_comm_destroy(comm)

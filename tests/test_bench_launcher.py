@@ -1,0 +1,56 @@
+"""bench.py's own launcher (CPU, gloo, stub workload): `python bench.py --gpus N` with no launcher around it must start N
+ranks itself and print ONE JSON line with n_gpus = N; a world size that disagrees with --gpus is an error, not a silent
+N = 1 run (`--gpus` was parsed and never read)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "3", "--warmup", "1"],
+                       env=_env(), capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["spawned_by_bench"] is True
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 1000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]      # whole-job units / MAX time
+
+
+def test_under_an_external_launcher_the_ranks_are_used_as_given():
+    port = "29957"
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "2", "--warmup", "0"],
+                              env=_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1].decode()[-2000:]
+    line0 = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")]
+    assert len(line0) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
+    out = json.loads(line0[0])
+    assert out["n_gpus"] == 2 and out["spawned_by_bench"] is False
+
+
+def test_world_size_that_disagrees_with_gpus_fails_loudly():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub"],
+                       env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in p.stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub"],
+                       env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29958"), capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"--gpus 1 but WORLD_SIZE=2" in p.stderr
+
+
+def test_a_dying_rank_ends_the_launcher():
+    """rank 1 has no GPU here (no GPU at all in the CPU container): the launcher must return non-zero instead of hanging"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=_env(HIP_VISIBLE_DEVICES=""), capture_output=True, timeout=300)
+    assert p.returncode != 0

@@ -51,10 +51,14 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch=False):
+def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch=False, comm=None):
+    """comm=None: host-synchronous gloo callbacks; comm="ipc": the stream-ordered process-to-process communicator
+    (csrc/comm_ipc.hip) -- the double-buffered exchange pipeline of lig_shard_prove with real peers on the one GPU"""
     script = tmp_path / "shard_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if comm:
+        env.update(LIG_COMM=comm, LIG_COMM_TAG=str(os.getpid()))
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad), "1" if batch else "0"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
              for r in range(world)]
@@ -85,6 +89,31 @@ def test_sharded_proof_with_batch_rows_equals_single_gpu_proof(tmp_path, world):
     """the batch program's rows are dealt to the ranks like any other rows (every rank runs the small program and keeps
     its slice; equality pairs and product triples are never split across ranks)"""
     outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, 29791 + world, batch=True)
+    assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
+    assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
+
+
+@pytest.mark.parametrize("world,l,k,n,n_lin,n_quad", [
+    (2, 320, 512, 2048, 2000, 900),               # one round
+    (4, 320, 512, 2048, 700, 0),                  # one round, a rank without rows
+    (2, 320, 512, 2048, 320 * 1500 + 7, 330),     # two rounds: both halves of the send / receive buffers
+    (4, 320, 512, 2048, 320 * 4300 + 1, 0),       # three rounds on 4 ranks: buffer REUSE gated by ev_comm / ev_hash with real peers
+    (2, 320, 512, 2048, 320 * 5200 + 3, 960),     # six rounds on 2 ranks
+    (2, 8000, 8192, 32768, 5 * 8000 + 17, 8000),
+])
+def test_sharded_over_stream_ordered_ipc_comm_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, n_quad):
+    """W processes on the one GPU, collectives = comm_ipc.hip: peers pull from each other's send buffers, ordering on the
+    GPU (stream memory operations), so lig_shard_prove takes its `ordered` branch (exchange of round c on the copy stream
+    under the encode of round c+1 and the hash of round c-1) with W > 1"""
+    outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, 29841 + world, comm="ipc")
+    assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
+    assert len({o["sha"] for o in outs}) == 1
+    assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_batch_rows_over_ipc_comm(tmp_path, world):
+    outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, 29861 + world, batch=True, comm="ipc")
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
 
@@ -141,7 +170,7 @@ BIG_WORKER = textwrap.dedent('''
     torch.cuda.set_device(0)
     pkg = load("ligero_prover_amd", "__init__.py")
     dist = load("lig_dist", "dist.py")
-    g = dist.Group("nccl", force_init=True)
+    g = dist.Group(sys.argv[3] if len(sys.argv) > 3 else "nccl", force_init=True)
     ctx = pkg.Context(8000, 8192, 32768, device=0)
     job = pkg.Context.make_job(1 << lg, 0, synth_seed=1, generated_at=0)
     sh = ctx.shard_prepare(job, g.rank, g.world, g.make_comm(pkg, ctx))
@@ -168,3 +197,23 @@ def test_sharded_configs3_trace_full_size_equals_oracle_pin(tmp_path):
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
     assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_configs3_trace_full_size_over_ipc_comm_equals_oracle_pin(tmp_path, world):
+    """configs[3]'s 2^26-constraint trace sharded over W REAL ranks (processes on the one GPU, comm_ipc.hip): 9 / 5 exchange
+    rounds with the stream-ordered double-buffered pipeline; every rank's envelope equals the oracle's pin"""
+    with open(os.path.join(ROOT, "tests", "golden", "full_pin_2p26.json")) as f:
+        pin = json.load(f)
+    script = tmp_path / "big_worker.py"
+    script.write_text(BIG_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world), WORLD_SIZE=str(world), LIG_COMM="ipc",
+               LIG_COMM_TAG=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, "26", "gloo"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    for p in procs:
+        o, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err.decode()[-3000:]
+        out = json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1])
+        assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
+        assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
