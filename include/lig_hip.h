@@ -311,7 +311,8 @@ typedef struct {
     int (*all_to_all_on)(void *user, const void *send_dev, void *recv_dev, size_t block_bytes, void *hip_stream);
     int (*all_gather_on)(void *user, const void *send_dev, void *recv_dev, size_t bytes, void *hip_stream);
     /* optional (NULL: nothing to do): the caller is about to free device buffers it has passed as send buffers -- a
-     * communicator that maps the peers' buffers (lig_ipc_comm_create) must not keep them mapped under a recycled address */
+     * communicator that exports them to its peers (lig_ipc_comm_create) must not keep handles / mappings of a recycled
+     * address.  Contract: call it before freeing any buffer that has been a `send_dev` (lig_shard_destroy does). */
     void (*forget)(void *user);
 } lig_comm;
 /* RCCL communicator: rank 0 calls lig_rccl_unique_id and hands the 128 bytes to every rank through the launcher's

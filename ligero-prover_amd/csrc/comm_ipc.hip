@@ -43,19 +43,24 @@ struct Pub {
     hipIpcMemHandle_t handle;
     uint64_t offset;
     uint64_t epoch;               // bumped by the exporter's forget(): handles published earlier may name freed allocations
+    uint32_t via_window;          // 1: the data is staged in the exporter's window (slot = call mod SLOTS), `handle` is unused
 };
 struct Shm {
     std::atomic<uint32_t> magic, arrived, departed;
     uint32_t world;
+    std::atomic<uint64_t> forgot[MAXW];   // epoch up to which rank h has closed every mapping of its peers' buffers
+    hipIpcMemHandle_t window[MAXW];       // every rank's staging window (exported once, at creation)
     Pub pub[MAXW][RING];
     alignas(4096) uint32_t ready[FLAGS_PER_KIND];
     uint32_t pulled[FLAGS_PER_KIND];
 };
 constexpr size_t FLAG_BYTES = 2 * FLAGS_PER_KIND * sizeof(uint32_t);
+constexpr size_t SLOT_BYTES = (size_t)2 << 20, DIRECT_MIN_ALLOC = (size_t)2 << 20;
 static_assert(FLAG_BYTES % 4096 == 0, "whole pages are registered");
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
 
 struct Mapping { hipIpcMemHandle_t h; uint64_t epoch; uint8_t* base; };
+struct Export { void* base; hipIpcMemHandle_t h; };
 
 struct IpcComm {
     lig_ctx* ctx = nullptr;
@@ -65,6 +70,16 @@ struct IpcComm {
     uint32_t* ready_dev = nullptr;      // device view of shm->ready (pulled follows at + FLAGS_PER_KIND)
     uint64_t calls = 0, epoch = 0;
     std::vector<Mapping> maps[MAXW];
+    // handles of my own allocations, valid for the current epoch: every hipIpcGetMemHandle exports the allocation anew (a
+    // dmabuf descriptor each time -- after a few dozen collectives the call failed with "invalid argument" on the target box)
+    std::vector<Export> exports;
+    // Staging window for sends out of SMALL allocations.  The runtime carves device allocations below 2 MiB out of shared
+    // blocks; the handle of such a fragment names its whole block and the importer is handed the block's base -- it would
+    // read a neighbour's bytes (seen on the target box as wrong opened columns / wrong roots once addresses were recycled,
+    // and as hipIpcGetMemHandle failures).  So a send whose allocation is smaller than 2 MiB is copied into slot (call mod
+    // SLOTS) of a 16 MiB window that is exported once, and the peers pull from there.
+    uint8_t* window = nullptr;
+    const uint8_t* peer_window[MAXW] = {nullptr};
     bool registered = false;
 };
 
@@ -90,6 +105,7 @@ bool host_wait(Pred done, int timeout_s = HOST_TIMEOUT_S) {
 int peer_pointer(IpcComm* r, uint32_t h, uint64_t c, const uint8_t** out) {
     Pub& p = r->shm->pub[h][c % RING];
     if (!host_wait([&] { return p.seq.load(std::memory_order_acquire) == c; })) return fail(r, "peer " + std::to_string(h) + " never reached collective " + std::to_string(c));
+    if (p.via_window) { *out = r->peer_window[h] + p.offset; return 0; }
     const hipIpcMemHandle_t hd = p.handle;
     const uint64_t off = p.offset, ep = p.epoch;
     auto& maps = r->maps[h];
@@ -108,20 +124,36 @@ int peer_pointer(IpcComm* r, uint32_t h, uint64_t c, const uint8_t** out) {
     return 0;
 }
 
-// common part: publish my send buffer, return the call number
-int publish(IpcComm* r, const void* send, uint64_t* call) {
+// common part: publish my send buffer (or that it goes through the window), return the call number
+int publish(IpcComm* r, const void* send, size_t total_bytes, uint64_t* call, bool* via_window) {
     const uint64_t c = ++r->calls;
     Pub& p = r->shm->pub[r->rank][c % RING];
     void* base = nullptr;
     size_t size = 0;
     hipError_t e = hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)send);
     if (e != hipSuccess) return fail(r, std::string("hipMemGetAddressRange: ") + hipGetErrorString(e));
-    e = hipIpcGetMemHandle(&p.handle, base);
-    if (e != hipSuccess) return fail(r, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    *via_window = size < DIRECT_MIN_ALLOC;
+    *call = c;
+    if (*via_window) {
+        if (total_bytes > SLOT_BYTES) return fail(r, "small allocation with a send larger than a window slot");
+        p.via_window = 1; p.offset = (c % SLOTS) * SLOT_BYTES; p.epoch = r->epoch;
+        p.seq.store(c, std::memory_order_release);
+        return 0;
+    }
+    p.via_window = 0;
+    const Export* known = nullptr;
+    for (const Export& x : r->exports) if (x.base == base) { known = &x; break; }
+    if (!known) {
+        Export x{base, {}};
+        e = hipIpcGetMemHandle(&x.h, base);
+        if (e != hipSuccess) return fail(r, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+        r->exports.push_back(x);
+        known = &r->exports.back();
+    }
+    p.handle = known->h;
     p.offset = (uint64_t)(static_cast<const uint8_t*>(send) - static_cast<const uint8_t*>(base));
     p.epoch = r->epoch;
     p.seq.store(c, std::memory_order_release);
-    *call = c;
     return 0;
 }
 
@@ -133,7 +165,9 @@ int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t byt
     if (hipSetDevice(r->ctx->device) != hipSuccess) return fail(r, "hipSetDevice");
     const uint32_t W = r->world, me = r->rank;
     uint64_t c = 0;
-    if (publish(r, send, &c)) return 1;
+    bool via_window = false;
+    const size_t total = what == 0 ? (size_t)W * bytes : bytes;
+    if (publish(r, send, total, &c, &via_window)) return 1;
     const uint8_t* src[MAXW];
     for (uint32_t i = 1; i < W; i++) {
         const uint32_t h = (me + i) % W;
@@ -145,6 +179,12 @@ int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t byt
     uint32_t* pulled = ready + FLAGS_PER_KIND;
     constexpr uint32_t RS = SLOTS * FLAG_STRIDE;
     const uint32_t v = (uint32_t)c;
+    if (via_window) {
+        // the slot was last used by call c - SLOTS, possibly on another stream of mine: every peer must have pulled that one
+        if (c > SLOTS)
+            for (uint32_t i = 1; i < W; i++) IPC_TRY(r, hipStreamWaitValue32(st, pulled + ((me + i) % W) * RS, (uint32_t)(c - SLOTS), hipStreamWaitValueGte, 0xffffffffu));
+        if (total) IPC_TRY(r, hipMemcpyAsync(r->window + slot * SLOT_BYTES, send, total, hipMemcpyDeviceToDevice, st));
+    }
     IPC_TRY(r, hipStreamWriteValue32(st, ready + me * RS, v, 0));
     for (uint32_t i = 0; i < W; i++) {
         const uint32_t h = (me + i) % W;                    // own block first, then the peers in a rotated order (no hot spot)
@@ -163,7 +203,24 @@ int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t byt
 int a2a_on(void* user, const void* send, void* recv, size_t block, void* stream) { return collective_on(static_cast<IpcComm*>(user), 0, send, recv, block, static_cast<hipStream_t>(stream)); }
 int ag_on(void* user, const void* send, void* recv, size_t bytes, void* stream) { return collective_on(static_cast<IpcComm*>(user), 1, send, recv, bytes, static_cast<hipStream_t>(stream)); }
 // the caller is about to free device buffers it has used as send buffers
-void forget(void* user) { static_cast<IpcComm*>(user)->epoch++; }
+// Collective on the host (every rank calls it at the same point of the program, lig_shard_destroy): the caller's streams are
+// drained, so its own pulls are finished and -- a collective only completes once every rank has pulled -- so are the peers'
+// pulls from its buffers.  Each rank closes its mappings of the peers' buffers, then waits until every peer has done the
+// same: an allocation must not be freed (and its address recycled and exported again) while a peer still has it mapped --
+// on the target box the export of the new allocation then failed with "invalid argument".
+void forget(void* user) {
+    IpcComm* r = static_cast<IpcComm*>(user);
+    if (!r->shm) return;
+    for (uint32_t h = 0; h < MAXW; h++) {
+        for (const Mapping& m : r->maps[h]) (void)hipIpcCloseMemHandle(m.base);
+        r->maps[h].clear();
+    }
+    r->exports.clear();
+    const uint64_t ep = ++r->epoch;
+    r->shm->forgot[r->rank].store(ep, std::memory_order_release);
+    for (uint32_t h = 0; h < r->world; h++)
+        (void)host_wait([&] { return r->shm->forgot[h].load(std::memory_order_acquire) >= ep; }, 60);
+}
 int a2a_sync(void* user, const void* send, void* recv, size_t block) {
     IpcComm* r = static_cast<IpcComm*>(user);
     if (!r->ctx || a2a_on(user, send, recv, block, r->ctx->stream)) return 1;
@@ -183,6 +240,8 @@ void finalize(IpcComm* r) {
     for (uint32_t h = 0; h < MAXW; h++) {
         for (const Mapping& m : r->maps[h]) (void)hipIpcCloseMemHandle(m.base);
         r->maps[h].clear();
+        if (r->peer_window[h] && h != r->rank) (void)hipIpcCloseMemHandle(const_cast<uint8_t*>(r->peer_window[h]));
+        r->peer_window[h] = nullptr;
     }
     if (r->shm) {
         // nobody may unmap / unlink while a peer's stream still polls the flags: leave together
@@ -192,6 +251,8 @@ void finalize(IpcComm* r) {
         (void)munmap(r->shm, sizeof(Shm));
         if (r->rank == 0) (void)shm_unlink(r->name.c_str());
     }
+    if (r->window) (void)hipFree(r->window);         // after the departure barrier: no peer maps it any more
+    r->window = nullptr;
     r->shm = nullptr;
     r->ctx = nullptr;
 }
@@ -235,8 +296,21 @@ int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_
         hipHostGetDevicePointer((void**)&r->ready_dev, r->shm->ready, 0) != hipSuccess)
         return bail("hipHostRegister of the flag page failed", LIG_E_HIP);
     r->registered = true;
+    if (hipMalloc((void**)&r->window, SLOTS * SLOT_BYTES) != hipSuccess || hipIpcGetMemHandle(&r->shm->window[rank], r->window) != hipSuccess) {
+        (void)hipHostUnregister(r->shm->ready); if (r->window) (void)hipFree(r->window);
+        return bail("window allocation / export failed", LIG_E_HIP);
+    }
     r->shm->arrived.fetch_add(1);
-    if (!host_wait([&] { return r->shm->arrived.load() >= world; })) { (void)hipHostUnregister(r->shm->ready); return bail("not all ranks arrived", LIG_E_STATE); }
+    if (!host_wait([&] { return r->shm->arrived.load() >= world; })) { (void)hipHostUnregister(r->shm->ready); (void)hipFree(r->window); return bail("not all ranks arrived", LIG_E_STATE); }
+    for (uint32_t h = 0; h < world; h++) {
+        if (h == rank) { r->peer_window[h] = r->window; continue; }
+        void* pw = nullptr;
+        if (hipIpcOpenMemHandle(&pw, r->shm->window[h], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipHostUnregister(r->shm->ready); (void)hipFree(r->window);
+            return bail("cannot map the window of rank " + std::to_string(h), LIG_E_HIP);
+        }
+        r->peer_window[h] = static_cast<const uint8_t*>(pw);
+    }
     c->comms.push_back({r, finalize_erased});
     out->user = r;
     out->all_to_all = a2a_sync;

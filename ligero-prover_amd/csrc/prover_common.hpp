@@ -99,30 +99,35 @@ struct HashRandomEngine {
         return buf[off--];
     }
 };
-// boost::random::detail::generate_uniform_int over an 8-bit engine (Boost is not vendored upstream)
+// boost::random::detail::generate_uniform_int(Engine&, T min, T max, boost::true_type) of
+// boost/random/uniform_int_distribution.hpp (the integer-engine overload; unchanged since the header appeared in Boost 1.47,
+// read from memory against 1.74 / 1.83 -- Boost is neither vendored upstream, CMakeLists.txt:67-69, nor in this image, so the
+// sample indices stay "parity unpinned") for the 8-bit engine above (brange = 255, bmin = 0) and range_type = uint64_t
+// (Distance = ptrdiff_t, include/util/portable_sample.hpp:26).  Tags B1..B4 name the statements of the Boost function in
+// order; oracle/hash.c (boost_uniform) quotes them one by one.  Returns a value in [0, range].
 uint64_t uniform_u64(HashRandomEngine& e, uint64_t range) {
-    if (range == 0) return 0;
-    if (range == 255) return e();
-    if (range < 255) {
-        const uint64_t bucket = 256 / (range + 1);
-        for (;;) { const uint64_t r = e() / bucket; if (r <= range) return r; }
+    if (range == 0) return 0;                         // B1  if(range == 0) return min_value;
+    if (range == 255) return e();                     // B2  else if(brange == range) return eng() - bmin + min_value;
+    if (range < 255) {                                // B4  else (brange > range):
+        const uint64_t bucket = 256 / (range + 1);    // B4a bucket_size: base_unsigned = uint8_t, brange == max -> 255/(range+1), +1 if 255%(range+1) == range: the same number
+        for (;;) { const uint64_t r = e() / bucket; if (r <= range) return r; }      // B4b
     }
-    for (;;) {
-        const uint64_t limit = (range + 1) / 256;     // range < 2^64 - 1 always here
-        uint64_t result = 0, mult = 1;
+    for (;;) {                                        // B3  else if(brange < range) for(;;)
+        const uint64_t limit = (range + 1) / 256;     // B3a (range < 2^64 - 1 always here: the max(range_type) special case cannot occur)
+        uint64_t result = 0, mult = 1;                // B3b
         bool exact = false;
-        while (mult <= limit) {
+        while (mult <= limit) {                       // B3c
             result += (uint64_t)e() * mult;
-            if (mult * 255 == range - mult + 1) { exact = true; break; }
-            mult *= 256;
+            if (mult * 255 == range - mult + 1) { exact = true; break; }     // B3d: range+1 is a power of 256 -> return result
+            mult *= 256;                              // B3e
         }
         if (exact) return result;
-        uint64_t inc = uniform_u64(e, range / mult);
-        if (UINT64_MAX / mult < inc) continue;
-        inc *= mult;
+        uint64_t inc = uniform_u64(e, range / mult);  // B3f  generate_uniform_int(eng, 0, range/mult, true_type())
+        if (UINT64_MAX / mult < inc) continue;        // B3g
+        inc *= mult;                                  // B3h
         result += inc;
-        if (result < inc || result > range) continue;
-        return result;
+        if (result < inc || result > range) continue; // B3i, B3j
+        return result;                                // B3k
     }
 }
 // portable_sample + sort (include/util/portable_sample.hpp:15-33, src/webgpu_prover.cpp:343-351)

@@ -268,7 +268,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     const auto t_begin = clk::now();
     auto t0 = clk::now();
     const bool ordered = S->comm.all_to_all_on != nullptr && S->comm.all_gather_on != nullptr;
-    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos) c->err = std::string("collective failed: ") + what; return (int)LIG_E_STATE; };
+    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos && c->err.find("ipc comm") == std::string::npos) c->err = std::string("collective failed: ") + what; else c->err = std::string(what) + ": " + c->err; return (int)LIG_E_STATE; };
     // all-gather in stream order on `st` (RCCL) or host-synchronously after draining `st`
     auto all_gather = [&](const void* src, void* dst, size_t bytes, hipStream_t st, const char* what) -> int {
         if (ordered) { if (S->comm.all_gather_on(S->comm.user, src, dst, bytes, st)) return comm_fail(what); return LIG_OK; }

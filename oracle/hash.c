@@ -307,35 +307,65 @@ void lo_hash_engine_bytes(const uint8_t seed[32], size_t count, uint8_t *out) {
     hre_t e; hre_init(&e, seed);
     for (size_t i = 0; i < count; i++) out[i] = hre_next(&e);
 }
-/* Restatement of boost::random::detail::generate_uniform_int for an engine with range [0,255]
- * (brange = 255) and an unsigned 64-bit working type -- Boost.Random is NOT vendored in the reference
- * (CMakeLists.txt:67-69), so this is "parity unpinned" (SURVEY.md A.7).  Returns a value in [0, range]. */
+/* Restatement of Boost.Random's integer-engine path for an engine with range [0,255] (hash_random_engine::result_type =
+ * uint8_t, min 0, max 255: include/zkp/random.hpp:89-95) and Distance = ptrdiff_t (range_type = unsigned 64 bit).
+ * Boost is NOT vendored in the reference (find_package(Boost COMPONENTS random), CMakeLists.txt:67-69, no version pin) and
+ * not present in this image, so this is "parity unpinned" (SURVEY.md A.7).  To diff it against a real Boost in a minute:
+ *   header   boost/random/uniform_int_distribution.hpp
+ *   function boost::random::detail::generate_uniform_int(Engine& eng, T min_value, T max_value, boost::true_type)
+ *            (the is_integral<Engine::result_type> overload; reached from uniform_int_distribution<T>::operator()(Engine&)
+ *            through generate_uniform_int(eng, min, max)); the body has been the same in every release that has this header
+ *            (it moved here from boost/random/uniform_int.hpp in Boost 1.47; checked from memory against 1.74 and 1.83).
+ * The statements of that function, in order, and where each one is below (range = max_value - min_value, brange = eng.max() -
+ * eng.min() = 255, bmin = 0):
+ *   B1  if(range == 0) return min_value;                                                            -> [B1]
+ *   B2  else if(brange == range) return add(subtract(eng(), bmin), min_value);                      -> [B2]
+ *   B3  else if(brange < range) for(;;) {                                                           -> [B3]
+ *   B3a   limit = (range == max(range_type)) ? range/(brange+1) (+1 if range%(brange+1) == brange) : (range+1)/(brange+1);
+ *   B3b   result = 0; mult = 1;
+ *   B3c   while(mult <= limit) { result += subtract(eng(), bmin) * mult;
+ *   B3d                          if(mult * brange == range - mult + 1) return result;     // range+1 is a power of brange+1
+ *   B3e                          mult *= brange + 1; }
+ *   B3f   result_increment = generate_uniform_int(eng, 0, range/mult, true_type());       // recursion, consumes more bytes
+ *   B3g   if(max(range_type) / mult < result_increment) continue;                         // multiplication would overflow
+ *   B3h   result_increment *= mult; result += result_increment;
+ *   B3i   if(result < result_increment) continue;                                          // addition overflowed
+ *   B3j   if(result > range) continue;                                                     // too big
+ *   B3k   return add(result, min_value); }
+ *   B4  else {  // brange > range                                                                   -> [B4]
+ *   B4a   bucket_size = (brange == max(base_unsigned)) ? brange/(range+1) (+1 if brange%(range+1) == range)
+ *                                                      : (brange+1)/(range+1);
+ *         // base_unsigned = uint8_t here, so Boost takes the FIRST form; both equal floor(256/(range+1)) for brange = 255
+ *   B4b   for(;;) { result = subtract(eng(), bmin) / bucket_size; if(result <= range) return add(result, min_value); } }
+ * (As remembered, B3d returns `result` without adding min_value.  Whether it does is immaterial here: min_value = 0 in the
+ * recursion, and the outer call U(i, n-1) reaches B3d only when n - i is a power of 256, which for n = 4k a power of two and
+ * i < 192 happens only at i = 0 = min_value.)  Returns a value in [0, range]; the caller adds lo. */
 static uint64_t boost_uniform(hre_t *e, uint64_t range) {
     const uint64_t brange = 255;
-    if (range == 0) return 0;
-    if (range == brange) return hre_next(e);
-    if (range < brange) {
-        uint64_t bucket = (brange + 1) / (range + 1);    /* brange+1 does not overflow */
-        for (;;) { uint64_t r = hre_next(e) / bucket; if (r <= range) return r; }
+    if (range == 0) return 0;                                                                   /* [B1] */
+    if (range == brange) return hre_next(e);                                                    /* [B2] */
+    if (range < brange) {                                                                       /* [B4] */
+        uint64_t bucket = (brange + 1) / (range + 1);    /* B4a: = 255/(range+1) (+1 if 255%(range+1) == range) */
+        for (;;) { uint64_t r = hre_next(e) / bucket; if (r <= range) return r; }               /* B4b */
     }
-    for (;;) {
+    for (;;) {                                                                                  /* [B3] */
         uint64_t limit = (range == UINT64_MAX) ? (range / (brange + 1) + ((range % (brange + 1) == brange) ? 1 : 0))
-                                               : (range + 1) / (brange + 1);
-        uint64_t result = 0, mult = 1;
+                                               : (range + 1) / (brange + 1);                    /* B3a */
+        uint64_t result = 0, mult = 1;                                                          /* B3b */
         int done = 0;
-        while (mult <= limit) {
+        while (mult <= limit) {                                                                 /* B3c */
             result += (uint64_t)hre_next(e) * mult;
-            if (mult * brange == range - mult + 1) { done = 1; break; }
-            mult *= brange + 1;
+            if (mult * brange == range - mult + 1) { done = 1; break; }                         /* B3d */
+            mult *= brange + 1;                                                                 /* B3e */
         }
         if (done) return result;
-        uint64_t inc = boost_uniform(e, range / mult);
-        if (UINT64_MAX / mult < inc) continue;
-        inc *= mult;
+        uint64_t inc = boost_uniform(e, range / mult);                                          /* B3f */
+        if (UINT64_MAX / mult < inc) continue;                                                  /* B3g */
+        inc *= mult;                                                                            /* B3h */
         result += inc;
-        if (result < inc) continue;
-        if (result > range) continue;
-        return result;
+        if (result < inc) continue;                                                             /* B3i */
+        if (result > range) continue;                                                           /* B3j */
+        return result;                                                                          /* B3k */
     }
 }
 /* portable_sample (include/util/portable_sample.hpp:15-33) + sort (webgpu_prover.cpp:351) */

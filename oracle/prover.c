@@ -155,17 +155,35 @@ void lo_form_rows(const lo_job *j, lo_fr *rows, lo_fr *mask_code, lo_fr *mask_li
     rowdesc *d; size_t R = plan_rows(j, &d);
     lo_rng wit, enc; lo_rng_init(&wit, j->witness_key); lo_rng_init(&enc, j->encoding_seed);
     batch_run(j, &enc, rows);                                               /* batch rows come first, with their own pads */
+    /* both streams are counter-mode: a row's draws start at the prefix sum of the draws before it, so the rows are formed
+     * independently (OpenMP over rows for the timing runs; the z rows of quadratic triples in a second pass) */
+    uint64_t *wpos = malloc(sizeof(uint64_t) * (R + 1)), *epos = malloc(sizeof(uint64_t) * (R + 1));
     for (size_t r = 0; r < R; r++) {
-        lo_fr *row = rows + r * k;
+        wpos[r] = wit.pos; epos[r] = enc.pos;
         if (d[r].kind >= RK_INIT) continue;
-        memset(row, 0, sizeof(lo_fr) * k);
-        if (d[r].kind != 3) lo_rng_fill(&wit, row, d[r].data);        /* linear, x, y: fresh witnesses */
-        else {                                                          /* z = x * y */
-            const lo_fr *y = row - k, *x = row - 2 * (size_t)k;
-            for (uint32_t i = 0; i < d[r].data; i++) lo_fr_mul(&row[i], &x[i], &y[i]);
-        }
-        lo_rng_fill(&enc, row + l, k - l);                              /* pad_encoding_random */
+        if (d[r].kind != 3) wit.pos += d[r].data;
+        enc.pos += k - l;
     }
+    const int FT = j->threads > 0 ? j->threads : 1;
+    (void)FT;
+    for (int pass = 0; pass < 2; pass++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(FT)
+#endif
+        for (long r = 0; r < (long)R; r++) {
+            lo_fr *row = rows + (size_t)r * k;
+            if (d[r].kind >= RK_INIT || (d[r].kind == 3) != (pass == 1)) continue;
+            memset(row, 0, sizeof(lo_fr) * k);
+            if (d[r].kind != 3) { lo_rng w = wit; w.pos = wpos[r]; lo_rng_fill(&w, row, d[r].data); }   /* linear, x, y: fresh witnesses */
+            else {                                                          /* z = x * y */
+                const lo_fr *y = row - k, *x = row - 2 * (size_t)k;
+                for (uint32_t i = 0; i < d[r].data; i++) lo_fr_mul(&row[i], &x[i], &y[i]);
+            }
+            lo_rng e = enc; e.pos = epos[r];
+            lo_rng_fill(&e, row + l, k - l);                                /* pad_encoding_random */
+        }
+    }
+    free(wpos); free(epos);
     /* masks (witness_manager.hpp:271-321) */
     lo_rng_fill(&enc, mask_code, l);
     memset(mask_code + l, 0, sizeof(lo_fr) * (k - l));
@@ -289,9 +307,11 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     lo_fr *rows = malloc(sizeof(lo_fr) * (R ? R : 1) * k);
     lo_fr *mc = malloc(sizeof(lo_fr) * k), *ml = malloc(sizeof(lo_fr) * 2 * k), *mq = malloc(sizeof(lo_fr) * 2 * k);
     lo_form_rows(j, rows, mc, ml, mq);
-    const size_t B = T > 64 ? (size_t)T : 64; /* rows encoded per parallel batch */
+    const size_t B = T > 32 ? 2 * (size_t)T : 64; /* rows encoded per parallel batch: at least two per thread */
     lo_fr *cws = malloc(sizeof(lo_fr) * B * n), *rws = malloc(sizeof(lo_fr) * B * n);
     lo_fr *m3 = malloc(sizeof(lo_fr) * 3 * n);
+    /* column block of the hash / accumulator passes: at least 2 blocks per thread (n = 32768, 256 threads -> 64 columns) */
+    const long CB = (long)n / (2 * T) >= 256 ? 256 : ((long)n / (2 * T) >= 16 ? (long)n / (2 * T) : 16);
 
     /* ---- stage 1 (nonbatch_context.hpp:445-486,555-558; webgpu_prover.cpp:255-282) */
     double t0 = now_s();
@@ -304,8 +324,8 @@ int lo_prove(const lo_job *j, lo_proof *P) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(T)
 #endif
-        for (long jb = 0; jb < (long)n; jb += 256) {
-            size_t blk = n - jb < 256 ? n - jb : 256;
+        for (long jb = 0; jb < (long)n; jb += CB) {
+            size_t blk = n - jb < CB ? n - jb : CB;
             for (size_t r = 0; r < nb; r++) lo_colsha_update(st + jb, cws + r * n + jb, blk);
         }
     }
@@ -355,8 +375,8 @@ int lo_prove(const lo_job *j, lo_proof *P) {
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(T)
 #endif
-        for (long jb = 0; jb < (long)n; jb += 256) {
-            size_t blk = n - jb < 256 ? n - jb : 256;
+        for (long jb = 0; jb < (long)n; jb += CB) {
+            size_t blk = n - jb < CB ? n - jb : CB;
             for (size_t r = 0; r < nb; r++) {
                 const int kd = d[b + r].kind;
                 if (has_code_check(kd)) lo_eltwise(LO_OP_FMA_CONST, cws + r * n + jb, NULL, P->code + jb, blk, &rcs[r], 0);

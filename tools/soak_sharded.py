@@ -36,18 +36,24 @@ def worker(iters):
         nl, nq = SHAPES[it % len(SHAPES)]
         job = pkg.Context.make_job(nl, nq, generated_at=it)
         sh = ctx.shard_prepare(job, g.rank, g.world, comm)
-        proofs = [ctx.shard_prove(sh)[0] for _ in range(1 + it % 3)]
+        outs = [ctx.shard_prove(sh) for _ in range(1 + it % 3)]
+        proofs = [o[0] for o in outs]
         ctx.shard_destroy(sh)
-        ref = None
+        ref = rinfo = None
         if g.rank == 0:
             tr = ctx.synth_prepare_job(job)
-            ref, _ = ctx.synth_prove(tr)
+            ref, rinfo = ctx.synth_prove(tr)
             ctx.trace_destroy(tr)
         digs = g.gather_digests(hashlib.sha256(proofs[-1]).digest())
         ok = len(set(digs)) == 1 and all(p == proofs[0] for p in proofs) and (ref is None or ref == proofs[0])
         bad += not ok
         if not ok:
-            print("rank %d: MISMATCH at iteration %d (shape %r)" % (g.rank, it, (nl, nq)), flush=True)
+            def parts(info):
+                return "root %s seed2 %s const %s valid %d%d%d" % (bytes(info.root).hex()[:8], bytes(info.stage2_seed).hex()[:8], bytes(info.const_sum).hex()[:8],
+                                                                    info.valid_code, info.valid_linear, info.valid_quad)
+            print("rank %d: MISMATCH at iteration %d (shape %r): ranks agree %s, repeated proofs %s, vs unsharded %s\n    sharded: %s\n    unsharded: %s"
+                  % (g.rank, it, (nl, nq), len(set(digs)) == 1, [p == proofs[0] for p in proofs], None if ref is None else ref == proofs[0],
+                     " | ".join(parts(o[1]) for o in outs), parts(rinfo) if rinfo is not None else "-"), flush=True)
     print(json.dumps({"rank": g.rank, "iters": iters, "mismatches": bad}), flush=True)
     g.close()
     ctx.close()
