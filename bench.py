@@ -378,7 +378,9 @@ def sharded_leg(ctx, group, pkg, log2c, steps, warmup, fence):
         out = {"workload": d["workload"], "log2_constraints": log2c, "rows": d["rows"], "ranks": group.world, "steps": steps, "warmup": warmup,
                "ms_per_proof": 1e3 * dt / steps, "constraints_per_s": (1 << log2c) * steps / dt, "scaling": "strong",
                "stage_ms": d.get("stage_ms"), "proof_bytes": d.get("proof_bytes"), "proof_sha256": d.get("proof_sha256"),
-               "exchange_rounds": swl.rounds, "collectives": "librccl: grouped ncclSend/ncclRecv per round + ncclAllGather (leaves, partial sums, opened columns)"}
+               "exchange_rounds": swl.rounds,
+               "collectives": "comm_ipc (test mode: peers map each other's buffers, GPU-ordered)" if os.environ.get("LIG_COMM") == "ipc" else
+                              "librccl: grouped ncclSend/ncclRecv per round + ncclAllGather (leaves, partial sums, opened columns)"}
         try:
             out["rccl_ranks"] = ctx.rccl_comm_count(swl.comm)          # ncclCommCount of the communicator the proofs ran on
             out["rccl_library"] = pkg.rccl_available()[1]
@@ -488,6 +490,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("LIG_BENCH_SHARE_GPU") == "1":
+        # test mode (tests/test_gpu_sharded.py): all ranks on GPU 0 of a one-GPU box, collectives through the process-to-process
+        # communicator (LIG_COMM=ipc) over a gloo rendezvous -- RCCL cannot put two ranks on one device.  Not a benchmark.
+        local_rank = 0
     if world > 1 and torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d of %d has no GPU of its own (%d visible)" % (local_rank, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)

@@ -41,7 +41,7 @@ struct hip_proof_meta {
 class hip_row_batcher {
 public:
     hip_row_batcher(lig_ctx* ctx, hip_proof_meta meta)
-        : ctx_(ctx), meta_(std::move(meta)), k_(lig_padding_size(ctx)) {
+        : ctx_(ctx), meta_(std::move(meta)), k_(lig_padding_size(ctx)), l_(lig_message_size(ctx)) {
         if (!ctx_) throw std::invalid_argument("hip_row_batcher: null context");
     }
     hip_row_batcher(const hip_row_batcher&) = delete;
@@ -57,8 +57,18 @@ public:
     void mask_callback(size_t code_size, size_t linear_size, size_t quad_size) const {
         if (code_size != k_ || linear_size != 2 * (size_t)k_ || quad_size != 2 * (size_t)k_) throw std::invalid_argument("mask_callback: unexpected mask sizes");
     }
-    // vbn254fr hooks (nonbatch_context.hpp:497-553, :782-850): device rows of k elements; they carry no linear-test randomness
-    void on_batch_init(const void* dev_x) { dev_row(LIG_ROW_INIT, dev_x); }
+    // vbn254fr hooks (nonbatch_context.hpp:497-553, :782-850): device rows of k elements; they carry no linear-test randomness.
+    // on_batch_init (:497-510) first draws params::sample_size = 192 elements from the encoding stream
+    // (pad_encoding_random) and writes them INTO the variable at slot message_size, then commits the row -- the pad is part of
+    // the variable from then on and flows into every batch row derived from it.  Every stage re-runs the guest with the
+    // encoding engine re-seeded, so pass 2 writes the same 192 elements again.
+    void on_batch_init(void* dev_x) {
+        if (pass_ != 1 && pass_ != 2) throw std::logic_error("hip_row_batcher: callback after prove");
+        if (k_ - l_ != init_pad) throw std::invalid_argument("hip_row_batcher::on_batch_init: k - l must be params::sample_size (192)");
+        check(lig_rng_fill(ctx_, meta_.encoding_seed, enc_pos_, static_cast<uint8_t*>(dev_x) + (size_t)l_ * 32, init_pad), "lig_rng_fill(init pad)");
+        enc_pos_ += init_pad;
+        dev_row(LIG_ROW_INIT, dev_x);
+    }
     void on_batch_bit(const void* dev_x) { dev_row(LIG_ROW_BIT, dev_x); }
     void on_batch_equal(const void* dev_x, const void* dev_y) { dev_row(LIG_ROW_EQX, dev_x); dev_row(LIG_ROW_EQY, dev_y); }
     void on_batch_quadratic(const void* dev_x, const void* dev_y, const void* dev_z) {
@@ -89,7 +99,7 @@ public:
         check(lig_rows_commit(trace_, root, stage1_seed), "lig_rows_commit");
         rows_.clear(); rows_.shrink_to_fit();            // the message rows are resident on the device now
         rands_.assign(kinds_.size() * (size_t)k_ * 4, 0);
-        pass_ = 2; next_ = 0;
+        pass_ = 2; next_ = 0; enc_pos_ = 0;              // the guest's second run starts the encoding stream over
     }
 
     // ---- end of pass 2: stages 2 + 3 on the GPU.  const_sum = the public constant of the linear test, 32 bytes little
@@ -112,6 +122,9 @@ private:
     }
     void row(uint8_t kind, const uint64_t* val, const uint64_t* rand) {
         const size_t words = (size_t)k_ * 4;
+        // witness_manager pads every linear row and every row of a quadratic triple with k - l stream elements when it forms
+        // it (the rows arrive with their pads): the position of the next on_batch_init pad moves past them
+        if (kind <= LIG_ROW_QZ) enc_pos_ += k_ - l_;
         if (pass_ == 1) {
             if (!val) throw std::invalid_argument("hip_row_batcher: null row");
             kinds_.push_back(kind);
@@ -125,17 +138,20 @@ private:
     }
     void dev_row(uint8_t kind, const void* dev) {
         if (pass_ == 1) {
+            check(lig_sync(ctx_), "lig_sync");           // (lig_read is ordered on the context stream; kept explicit: the row must be final)
             std::vector<uint64_t> host((size_t)k_ * 4);
             check(lig_read(ctx_, host.data(), dev, host.size() * 8), "lig_read(batch row)");
             row(kind, host.data(), nullptr);
         } else row(kind, nullptr, nullptr);
     }
 
+    static constexpr uint32_t init_pad = 192;            // params::sample_size (include/params.hpp:27)
     lig_ctx* ctx_;
     hip_proof_meta meta_;
-    uint32_t k_;
+    uint32_t k_, l_;
     int pass_ = 1;
     size_t next_ = 0;
+    uint64_t enc_pos_ = 0;                                // encoding-stream position (elements) of the next row's pad
     std::vector<uint8_t> kinds_;
     std::vector<uint64_t> rows_, rands_;
     lig_trace* trace_ = nullptr;

@@ -8,6 +8,7 @@
 // T-table AES with the four rotated tables staged in LDS (4 KiB per workgroup): the sampler runs next to the VALU-bound
 // encode kernels, so it is written for the fewest VALU instructions -- no rotates (v_alignbit is a half-rate
 // instruction on gfx950), three-input xors (v_bitop3_b32), and the last round masks S-box bytes out of the same tables.
+#include "fr29.hpp"
 #include "kernels.hpp"
 
 namespace lig {
@@ -154,6 +155,45 @@ __global__ void __launch_bounds__(256) k_rng_fill_rows_dense(const uint32_t* __r
         fr_store(out + e, i < per_row ? aes_field_elem<LOGR>(rk, tl, first + r * (uint64_t)per_row + i) : fr_zero());
     }
 }
+// Sampler + stage-2 accumulation in one pass (the dense randomness rows of the synthetic stream, nonbatch_context.hpp:756-780
+// check_code / check_linear on the message domain): thread = position j of a group of rows.  Per row it draws the row's
+// randomness element (AES, LDS-bound), stores it for the encoder (K1 reads the row next), and -- while the element is in
+// registers -- adds rc_r * msg_r[j] to the code partial and msg_r[j] * rand_r[j] to the linear partial of its group
+// (VALU-bound: the two halves of k_rng_fill_rows_dense + k_rlc_partial fill each other's idle slots, and the randomness row
+// is read once less).  Partials have k_rlc_partial's contract: code_part = running lazy sums (< 2p), lin_part plain values
+// (< 2p), both ADDED to (zeroed by the caller before the first chunk).  Persistent workgroups over (group, 256 positions) tiles.
+template <int LOGR>
+__global__ void __launch_bounds__(256) k_rand_rlc(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ rand_out,
+                                                  const fr* __restrict__ msgs, size_t rows, uint32_t per_row, uint32_t k,
+                                                  const f29s* __restrict__ rc, uint32_t group_rows, fr* __restrict__ code_part,
+                                                  fr* __restrict__ lin_part) {
+    __shared__ uint32_t te[1024 << LOGR];
+    const uint32_t* tl = te_stage<LOGR>(te);
+    const uint32_t jblocks = k >> 8, groups = (uint32_t)((rows + group_rows - 1) / group_rows), tiles = jblocks * groups;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t g = tile / jblocks, j = ((tile - g * jblocks) << 8) + threadIdx.x;
+        const size_t r0 = (size_t)g * group_rows, r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
+        const bool live = j < per_row;                         // positions >= per_row of a dense row are zero
+        f29 ac = unpack29(fr_load(code_part + (size_t)g * k + j)), al = f29_zero();
+        int since = 0;
+        for (size_t r = r0; r < r1; r++) {
+            const f29 u = unpack29(fr_load(msgs + r * k + j));
+            ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));
+            fr v = fr_zero();
+            if (live) {
+                v = aes_field_elem<LOGR>(rk, tl, first + r * (uint64_t)per_row + j);
+                al = f29_add(al, f29_montmul(u, unpack29(v)));
+            }
+            fr_store(rand_out + r * k + j, v);
+            if (++since == 6) { ac = f29_qnorm(ac); al = f29_qnorm(al); since = 0; }
+        }
+        fr_store(code_part + (size_t)g * k + j, pack29(f29_reduce_2p(ac)));
+        f29 w = f29_montmul(f29_qnorm(al), f29_const_r2());                                   // plain value, < 1.2p
+        w = f29_reduce_2p(f29_add(w, unpack29(fr_load(lin_part + (size_t)g * k + j))));
+        fr_store(lin_part + (size_t)g * k + j, pack29(w));
+    }
+}
+
 // launch shape: big fills = persistent workgroups (<= 2 per CU, 64 KiB of replicated tables each); small ones = one copy of
 // the tables (4 KiB), many workgroups
 static constexpr size_t BIG_FILL = (size_t)1 << 20;      // below this the 64 KiB table staging per workgroup does not pay
@@ -168,6 +208,19 @@ void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_
     if (!total) return;
     if (total >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill_rows_dense<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
     else hipLaunchKernelGGL(k_rng_fill_rows_dense<0>, dim3(small_blocks(total, 8192)), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
+}
+
+// rows x k dense randomness rows into `out` + the message-domain partials of the code and linear tests (k % 256 == 0)
+void launch_rand_rlc(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, const fr* msgs, size_t rows, uint32_t per_row, uint32_t k,
+                     const f29s* rc_dev, uint32_t group_rows, fr* code_part, fr* lin_part) {
+    if (!rows) return;
+    const size_t tiles = (size_t)(k >> 8) * ((rows + group_rows - 1) / group_rows);
+    if (rows * k >= BIG_FILL)
+        hipLaunchKernelGGL(k_rand_rlc<REP>, dim3((uint32_t)(tiles < BIG_BLOCKS ? tiles : BIG_BLOCKS)), dim3(256), 0, s, rk60_dev, first, out, msgs, rows, per_row, k,
+                           rc_dev, group_rows, code_part, lin_part);
+    else
+        hipLaunchKernelGGL(k_rand_rlc<0>, dim3((uint32_t)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, s, rk60_dev, first, out, msgs, rows, per_row, k, rc_dev,
+                           group_rows, code_part, lin_part);
 }
 
 void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row,

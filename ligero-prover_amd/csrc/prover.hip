@@ -365,6 +365,9 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         chunk_pos[ci + 1] = chunk_pos[ci] + cnt;
     }
     auto rand_buf = [&](size_t ci) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + sched2[ci].first * (size_t)k : T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k; };
+    // Generated (dense) randomness rows: the sampler also accumulates the message-domain halves of the code and linear tests
+    // while the elements are in registers (aes.hip: k_rand_rlc) -- all of it on the side stream; the main stream only encodes.
+    const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
@@ -378,18 +381,15 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
                 size_t run = 1;
                 const uint32_t d = T->rows[b + r].data;
                 while (r + run < nb && T->rows[b + r + run].data == d) run++;
-                lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
+                if (fused_rlc) lig::launch_rand_rlc(s2, c->rk_dev, lpos, rb + r * k, T->msgs + (b + r) * k, run, d, k, T->coef_dev + b + r, lig_tune::GROUP / 4, p_code, p_linH);
+                else lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
                 lpos += (uint64_t)run * d; r += run;
             }
         }
         HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2));
         return LIG_OK;
     };
-    HIP_TRY(c, hipEventRecord(c->ev_fork, s));            // the side stream starts after the key upload / memset above
-    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
-    if (n_chunks) TRY(form_rand_chunk(0));
-    {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple -- computed on the host while the
-        // side stream already samples the first randomness rows
+    {   // coefficients: one code-stream draw per row, one quadratic-stream draw per triple (the sampler's fused pass reads them)
         std::vector<H::Fr> rc, rq;
         FieldStream code_s(info->stage1_seed), quad_s(info->stage1_seed);
         size_t n_code = 0;
@@ -403,6 +403,9 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         for (size_t i = 0; i < NT; i++) { coef[R + i] = to_f29s_host(rq[i], R261sq); coef[R + NT + i] = to_f29s_host(rq[i], R261); }
         TRY(lig_internal_upload_small(c, T->coef_dev, coef.data(), coef.size() * sizeof(lig::f29s), s));
     }
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));            // the side stream starts after the key / coefficient uploads and the memsets above
+    HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+    if (n_chunks) TRY(form_rand_chunk(0));
     for (size_t ci = 0; ci < n_chunks; ci++) {
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
@@ -417,7 +420,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
             lig::launch_rlc_accumulate29(s, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::DOT_GROUP);
         }
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
+        if (!fused_rlc) lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
     {   // one combine per accumulator and proof
@@ -551,6 +554,7 @@ static int synth_prepare_impl(lig_ctx* c, const lig_synth_job* job, lig_trace* T
     // would silently stop being zero-knowledge
     if (l >= k || l < 2 || t > n || k - l < t) FAIL(c, LIG_E_ARG, "synthetic trace: need 2 <= l <= k - 192 (k - l random pads cover the 192 opened columns)");
     if (!plan_rows(*job, l, T->rows, T->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
+    if (T->n_init && k - l != 192) FAIL(c, LIG_E_ARG, "batch program: on_batch_init draws params::sample_size = 192 pads, k - l must be 192");
     if (!instance_hash_of(job->public_args, job->public_arg_lens, job->n_public_args, T->ih)) FAIL(c, LIG_E_ARG, "public arguments: null pointer");
     std::memcpy(T->encoding_seed, job->encoding_seed, 32);
     std::memcpy(T->program_hash, job->program_hash, 32);
@@ -674,6 +678,10 @@ static int rows_begin_impl(lig_ctx* c, const lig_rows_job* job, lig_trace* T) {
         const bool follower = kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ;
         if (follower && !(r > 0 && (job->kinds[r - 1] & 0x7f) == kd - 1)) FAIL(c, LIG_E_ARG, "rows job: row of a group without its predecessor");
         const bool draws = kd <= 3 || kd == RK_INIT;
+        // on_batch_init draws params::sample_size = 192 elements (nonbatch_context.hpp:497-510), the rows of witness_manager
+        // k - l; upstream the two are the same number (params.hpp:27-30).  Batch rows are only accepted in that geometry:
+        // otherwise the encoding stream would run out of step with the reference's
+        if (kd == RK_INIT && pad != 192) FAIL(c, LIG_E_ARG, "rows job: on_batch_init rows need k - l = 192 (params::sample_size)");
         if ((job->kinds[r] & LIG_ROW_DRAW_PAD) && !draws) FAIL(c, LIG_E_ARG, "rows job: LIG_ROW_DRAW_PAD on a row kind that draws no padding upstream");
         draw[r] = (job->kinds[r] & LIG_ROW_DRAW_PAD) ? 1 : 0;
         pos[r + 1] = pos[r] + (draws ? pad : 0);

@@ -32,6 +32,8 @@ void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stri
 void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
                              const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k);
+void launch_rand_rlc(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, const fr* msgs, size_t rows, uint32_t per_row, uint32_t k,
+                     const f29s* rc_dev, uint32_t group_rows, fr* code_part, fr* lin_part);
 void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* accC, uint32_t k);
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
 void launch_copy_from_host(hipStream_t s, uint8_t* dst_dev, const uint8_t* src_mapped, size_t bytes);

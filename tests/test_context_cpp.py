@@ -100,3 +100,33 @@ def test_row_batcher_shim_gives_the_oracle_envelope(l, k, n, n_lin, n_quad):
     the envelope of the oracle's reference-structured prover, public arguments included"""
     out = subprocess.check_output([build_batcher_exe(), str(l), str(k), str(n), str(n_lin), str(n_quad)]).decode()
     assert out.startswith("equal 1 "), out
+
+
+BBSRC = os.path.join(ROOT, "tests", "cpp", "row_batcher_batch_prog.cpp")
+BBEXE = os.path.join(ROOT, "tests", "cpp", "row_batcher_batch_prog")
+
+
+def build_batch_batcher_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    odir = os.path.join(ROOT, "oracle")
+    ol.build()
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"), BBSRC, "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip",
+                           "-L" + odir, "-llig_oracle", "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-Wl,-rpath," + odir, "-o", BBEXE])
+    return BBEXE
+
+
+def test_row_batcher_batch_hooks_compile_and_link():
+    assert os.path.exists(build_batch_batcher_exe())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lin,n_quad,with_bits,k", [(0, 0, 0, 512), (900, 330, 1, 512), (320 * 3, 0, 1, 512), (20000, 8001, 0, 8192)])
+def test_row_batcher_batch_hooks_give_the_oracle_envelope(n_lin, n_quad, with_bits, k):
+    """on_batch_init / _bit / _equal / _quadratic of the shim, raised by the vbn254fr layer itself over two runs of a guest:
+    the init pads are drawn at the row's encoding-stream position and written INTO the variable (they flow into the product,
+    quotient, copy and bit rows derived from it), and the envelope equals the oracle's for batch program + synthetic stream
+    (the shim used to commit init rows without their pads)"""
+    out = subprocess.check_output([build_batch_batcher_exe(), str(n_lin), str(n_quad), str(with_bits), str(k)]).decode()
+    assert out.startswith("equal 1 "), out

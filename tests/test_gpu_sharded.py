@@ -217,3 +217,22 @@ def test_sharded_configs3_trace_full_size_over_ipc_comm_equals_oracle_pin(tmp_pa
         out = json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1])
         assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
         assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
+
+
+def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_path):
+    """`python bench.py --gpus 2` (its own launcher) with both ranks on the one GPU (LIG_BENCH_SHARE_GPU, collectives =
+    comm_ipc over a gloo rendezvous): the N > 1 code path of the bench -- weak leg on every rank, then ONE trace sharded over
+    the ranks -- prints one JSON line with n_gpus = 2 and a `sharded` object whose envelope equals the oracle pin"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--log2-constraints", "22", "--sharded-log2", "24", "--sharded-steps", "2", "--no-cpu-baseline", "--no-verify"],
+                       env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    sh = out["sharded"]
+    assert sh["ranks"] == 2 and sh["log2_constraints"] == 24 and sh["scaling"] == "strong"
+    assert sh["proof_equals_oracle_pin"] is True and sh["all_ranks_same_envelope"] is True
