@@ -465,8 +465,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed, informational) HIP verifier run on the last proof")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive second measurement (value_incl_h2d)")
-    ap.add_argument("--h2d-inflight", type=int, default=1, help="traces in flight for the PCIe-inclusive measurement (one context "
-                    "already pipelines upload i+1 under proof i; two contexts share the PCIe link and were measured slower)")
+    ap.add_argument("--h2d-inflight", type=int, default=2, help="contexts alternating in the PCIe-inclusive measurement: each pipelines "
+                    "upload i+1 under proof i, the uploads of all contexts go through one uploader thread (one at a time), so two "
+                    "contexts keep the link busy: commit / prove of one under the upload of the other")
     ap.add_argument("--inflight", type=int, default=2, help="full workload: proofs (traces) proved concurrently per GPU in one step")
     a = ap.parse_args()
     global NO_VERIFY
@@ -540,6 +541,18 @@ def main():
             hw = RowsFromHostWorkload(ctx, 1 << log2c, pkg, max(1, a.h2d_inflight), local_rank)
             hw.run(3)                                   # warm-up: the second message matrix is allocated by the first prefetch, pages are touched
             fence()
+            # the link itself: the same pinned matrix copied to the device by a plain stream copy (best of 3)
+            link_ms = None
+            try:
+                dev_buf = torch.empty_like(hw.host, device="cuda")
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); dev_buf.copy_(hw.host, non_blocking=True); e1.record(); e1.synchronize()
+                    link_ms = e0.elapsed_time(e1) if link_ms is None else min(link_ms, e0.elapsed_time(e1))
+                del dev_buf
+            except RuntimeError:
+                pass
+            fence()
             t0 = time.perf_counter()
             hw.run(a.steps)
             fence()
@@ -547,8 +560,11 @@ def main():
             incl = {"value": hw.constraints * a.steps * world / dth, "ms_per_step": 1e3 * dth / a.steps,
                     "proof_sha256": hw.proof_sha256(),
                     "witness_bytes_per_trace": int(hw.host.numel() * 4),
+                    "link_ms_per_trace": link_ms, "link_GBps": None if not link_ms else hw.host.numel() * 4 / link_ms / 1e6,
+                    "frac_of_link_bound": None if not link_ms else (link_ms * 1e-3) / (dth / (a.steps * hw.inflight)),
                     "how": "lig_rows_restart/commit/prove: witness rows uploaded from pinned host memory inside the timed region "
-                           "(chunked on a copy stream under the encodes), %d traces in flight" % hw.inflight}
+                           "(chunk by chunk by the library's uploader thread, each chunk encoded as it arrives; upload i+1 under proof i), "
+                           "%d contexts alternating" % hw.inflight}
             hw.close()
         except (RuntimeError, MemoryError, pkg.LigError) as e:      # e.g. no pinned memory left: the resident figure below stands on its own
             incl = None

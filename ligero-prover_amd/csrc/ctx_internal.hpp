@@ -69,6 +69,9 @@ int lig_internal_encode_2k_rows(lig_ctx* c, void* buf, size_t rows, hipStream_t 
 int lig_internal_encode_generic(lig_ctx* c, void* buf, hipStream_t on = nullptr);
 // dst (device) <- src (host, any memory), `bytes` a multiple of 4, enqueued on `st`; src may be reused as soon as this returns
 int lig_internal_upload_small(lig_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);
+// host_pinned (hipHostMalloc'ed, 16-byte aligned) <- src (device), enqueued on `st` as a copy kernel (no DMA engine); the data is
+// visible to the host once work queued behind it on `st` has been waited for (event / stream synchronize)
+int lig_internal_download(lig_ctx* c, void* host_pinned, const void* src, size_t bytes, hipStream_t st);
 // make the shared encode scratch large enough for `rows` rows per launch group (all context streams are drained first)
 int lig_internal_reserve_scratch(lig_ctx* c, size_t rows);
 

@@ -221,6 +221,51 @@ int lig_internal_upload_small(lig_ctx* c, void* dst, const void* src, size_t byt
     return LIG_OK;
 }
 
+// ---- device -> pinned host without the DMA engines (ctx_internal.hpp): the proof's downloads (accumulators, decoded
+// accumulators, Merkle nodes, opened columns: 1 .. 13 MB each) as stores of a copy kernel into the mapped host buffer.  With a
+// 550 MB witness upload of the NEXT trace in flight, hipMemcpyAsync D2H of the current proof was seen to finish only when the
+// upload did (stage 2 4.9 -> 11.0 ms in three of five proofs, tools/time_rows2.py, profiles/r03_h2d_pipeline.md).
+__global__ void __launch_bounds__(256) k_copy_u128(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// dst at any byte address (the opened columns land inside the protobuf envelope): aligned dword stores assembled from two
+// source dwords, the up to three bytes on either edge stored one by one.  src 4-byte aligned, bytes % 4 == 0.
+__global__ void __launch_bounds__(256) k_copy_to_unaligned(uint8_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t words) {
+    const uint32_t sh = (uint32_t)((uintptr_t)dst & 3u);                  // 1..3
+    uint32_t* D = reinterpret_cast<uint32_t*>(dst - sh);                  // D[w] = dst bytes [4w - sh, 4w - sh + 4)
+    const uint32_t lo = 8u * (4u - sh), hi = 8u * sh;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t w = gid + 1; w < words; w += (size_t)gridDim.x * blockDim.x) D[w] = (src[w - 1] >> lo) | (src[w] << hi);
+    if (gid == 0) {
+        const uint8_t* sb = reinterpret_cast<const uint8_t*>(src);
+        for (uint32_t b = 0; b < 4u - sh; b++) dst[b] = sb[b];                                  // head: the upper part of D[0]
+        for (uint32_t b = 0; b < sh; b++) dst[4 * words - sh + b] = sb[4 * words - sh + b];     // tail: the lower part of D[words]
+    }
+}
+int lig_internal_download(lig_ctx* c, void* host_pinned, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return LIG_OK;
+    static const bool by_kernel = [] { const char* e = std::getenv("LIG_D2H_KERNEL"); return !e || std::atoi(e) != 0; }();
+    if (!by_kernel || (bytes & 3) || ((uintptr_t)src & 15)) {
+        HIP_TRY(c, hipMemcpyAsync(host_pinned, src, bytes, hipMemcpyDeviceToHost, st));
+        return LIG_OK;
+    }
+    if (!((uintptr_t)host_pinned & 15) && !(bytes & 15)) {
+        const size_t n16 = bytes / 16;
+        const uint32_t blocks = (uint32_t)((n16 + 255) / 256 < 128 ? (n16 + 255) / 256 : 128);
+        hipLaunchKernelGGL(k_copy_u128, dim3(blocks), dim3(256), 0, st, (uint4*)host_pinned, (const uint4*)src, n16);
+    } else if (!((uintptr_t)host_pinned & 3)) {
+        const size_t words = bytes / 4;
+        const uint32_t blocks = (uint32_t)((words + 255) / 256 < 256 ? (words + 255) / 256 : 256);
+        hipLaunchKernelGGL(k_copy_u32, dim3(blocks), dim3(256), 0, st, (uint32_t*)host_pinned, (const uint32_t*)src, words);
+    } else {
+        const size_t words = bytes / 4;
+        const uint32_t blocks = (uint32_t)((words + 255) / 256 < 256 ? (words + 255) / 256 : 256);
+        hipLaunchKernelGGL(k_copy_to_unaligned, dim3(blocks), dim3(256), 0, st, (uint8_t*)host_pinned, (const uint32_t*)src, words);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
 // ---- tables of the two-launch single-row transforms (ntt_tiled.hip)
 static int make_tiled_plan(lig_ctx* c, lig::TiledPlan& tp, uint32_t N, const H::Fr& root, bool inverse) {
     const H::Fr w = inverse ? H::inv(root) : root;

@@ -15,7 +15,12 @@
 #include "prover_common.hpp"
 #include <cerrno>
 #include <functional>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 struct lig_trace {
     lig_ctx* c = nullptr;
@@ -33,7 +38,11 @@ struct lig_trace {
     uint64_t mask_pos = 0;              // encoding-stream position of the first mask element
     std::vector<std::pair<size_t, size_t>> sched1;     // stage-1 chunk schedule
     const uint8_t* host_msgs = nullptr; // lig_rows_begin with host memory: uploaded chunk by chunk under the encodes
-    std::vector<hipEvent_t> ev_up;      // one per stage-1 chunk: its rows have arrived
+    std::vector<hipEvent_t> ev_up;      // one per stage-1 chunk: its rows have arrived (per-context copy stream, LIG_UPLOAD_MODE=1)
+    volatile uint32_t* up_flag = nullptr; uint32_t* up_flag_dev = nullptr;   // pinned: word ci = sequence number of the last upload whose chunk ci has arrived
+    uint32_t up_seq = 0;
+    bool up_by_thread = false;
+    std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
     lig_proof_info info1;               // stage-1 results kept between lig_rows_commit and lig_rows_prove
     size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
@@ -57,6 +66,8 @@ struct lig_trace {
     hipEvent_t ev_gate = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
     uint8_t* h_small = nullptr;                            // pinned: the device-side sum (32 B) | 3 decoded accumulators (3 x n x 32)
 };
+
+static void uploader_drain(lig_trace* T);      // (below, with the uploader thread)
 
 // The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
 // kernel into a temporary + a copy (as vbn254fr_module does), every hook a device-to-device copy of the rows it names
@@ -273,7 +284,8 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     for (size_t ci = 0; ci < T->sched1.size(); ci++) {
         const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
         if (streamed) {
-            HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_up[ci], 0));                   // this chunk's rows have arrived
+            if (T->up_by_thread) HIP_TRY(c, hipStreamWaitValue32(s_enc, T->up_flag_dev + ci, T->up_seq, hipStreamWaitValueGte, 0xffffffffu));
+            else HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_up[ci], 0));                   // this chunk's rows have arrived
             for (; pr_i < T->pad_runs.size() && T->pad_runs[pr_i].first < b + nb; pr_i++) {      // runs never straddle chunks (split in begin)
                 const PadRun& pr = T->pad_runs[pr_i];
                 lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
@@ -307,9 +319,9 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     mark("encode mask rows + column sha tail");
     lig::launch_sha_final(s, T->sha_state, n, absorbed, T->leaves, k);       // plane-major instances -> leaves in column order
     TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
-    HIP_TRY(c, hipMemcpyAsync(info->root, T->nodes, 32, hipMemcpyDeviceToHost, s));
+    TRY(lig_internal_download(c, T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, s));      // root now, the rest for the decommitment (stage 3)
     HIP_TRY(c, hipStreamSynchronize(s));
-    HIP_TRY(c, hipMemcpyAsync(T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, hipMemcpyDeviceToHost, s));   // for the decommitment (stage 3)
+    std::memcpy(info->root, T->h_nodes, 32);
     Sha256().add("LigetronStage1", 15).add(info->root, 32).add(T->ih, 32).finish(info->stage1_seed);
     mark("merkle + seed");
     return LIG_OK;
@@ -442,25 +454,25 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     uint8_t* enc = T->h_enc;
     const size_t vec_bytes = (size_t)n * 32;
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
-    HIP_TRY(c, hipMemcpyAsync(T->h_small, T->dots, 32, hipMemcpyDeviceToHost, s));
+    TRY(lig_internal_download(c, T->h_small, T->dots, 32, s));
     TRY(lig_internal_encode_rows(c, tmp, code, 1, false));      // out of place: no device-to-device staging copy
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
-    HIP_TRY(c, hipMemcpyAsync(enc, code, vec_bytes, hipMemcpyDeviceToHost, s));
+    TRY(lig_internal_download(c, enc, code, vec_bytes, s));
     HIP_TRY(c, hipEventRecord(T->ev_acc[0], s));
     TRY(lig_internal_extend_2k(c, lin));
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
-    HIP_TRY(c, hipMemcpyAsync(enc + vec_bytes, lin, vec_bytes, hipMemcpyDeviceToHost, s));
+    TRY(lig_internal_download(c, enc + vec_bytes, lin, vec_bytes, s));
     HIP_TRY(c, hipEventRecord(T->ev_acc[1], s));
     TRY(lig_internal_extend_2k(c, quad));
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mquad, nullptr, quad, n, fr{}, 0);
-    HIP_TRY(c, hipMemcpyAsync(enc + 2 * vec_bytes, quad, vec_bytes, hipMemcpyDeviceToHost, s));
+    TRY(lig_internal_download(c, enc + 2 * vec_bytes, quad, vec_bytes, s));
     HIP_TRY(c, hipEventRecord(T->ev_acc[2], s));
     // prover self-check (src/webgpu_prover.cpp:355-386,465-469): the three decodes run on the GPU while the host hashes
     H::Fr* dec = reinterpret_cast<H::Fr*>(T->h_small + 32);    // 3 x n
     const fr* accs[3] = {code, lin, quad};
     for (int a3 = 0; a3 < 3; a3++) {
         TRY(lig_internal_decode_to(c, accs[a3], tmp));
-        HIP_TRY(c, hipMemcpyAsync(dec + (size_t)a3 * n, tmp, vec_bytes, hipMemcpyDeviceToHost, s));
+        TRY(lig_internal_download(c, dec + (size_t)a3 * n, tmp, vec_bytes, s));
     }
     HIP_TRY(c, hipEventRecord(c->ev_join, s));
     {
@@ -496,7 +508,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, T->version, T->program_hash, T->generated_at, k, n, t,
                                               info->root, sib, idx, enc, smp_bytes);
     if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
-    HIP_TRY(c, hipMemcpyAsync(T->h_proof + lay.samples_off, T->samples, smp_bytes, hipMemcpyDeviceToHost, s));   // opened columns land in place
+    TRY(lig_internal_download(c, T->h_proof + lay.samples_off, T->samples, smp_bytes, s));   // opened columns land in place (16-byte aligned, else the DMA path)
     HIP_TRY(c, hipEventSynchronize(c->ev_join));          // decoded accumulators are on the host
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
     info->valid_code = 1;
@@ -580,6 +592,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream);
     (void)hipStreamSynchronize(T->c->stream2);
     (void)hipStreamSynchronize(T->c->stream3);
+    uploader_drain(T);                                    // an upload still in flight
     T->c->sha.erase(T->sha_state);
     for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->tri_dev,
@@ -589,6 +602,7 @@ void lig_trace_destroy(lig_trace* T) {
     if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
     for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
     for (hipEvent_t e : T->ev_up) (void)hipEventDestroy(e);
+    if (T->up_flag) (void)hipHostFree((void*)T->up_flag);
     (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
     delete T;
 }
@@ -610,6 +624,80 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     return LIG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Host rows -> device without a HIP stream of the prover in the path.
+//
+// What was measured (tools/time_rows2.py, tools/h2d_under_load.py; profiles/r03_h2d_pipeline.md): the PCIe link delivers
+// 57 GB/s to this process whatever the GPU is doing (550 MB = one 2^24-constraint trace in 9.7 ms, idle or under two proving
+// contexts), and a foreign stream's upload does not slow the proofs down.  The prover's own chunked upload did: HIP maps the
+// streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues, every event recorded behind a copy (and every wait for one)
+// is a barrier packet in such a queue, and while it waits for a 2 ms .. 10 ms transfer the kernels of whichever proof stream
+// shares the queue do not start (stage 2 of a proof 4.9 -> 10-16 ms; two alternating contexts: 12.8 ms per proof, slower
+// than one).  Priorities (own queue pool) and a shared copy stream move the problem around (A/B table in the profile).
+// So: one uploader thread per device copies chunk after chunk on a stream of its own and waits for each copy ON THE HOST
+// (no event, no packet behind the copy), then publishes the chunk's arrival in pinned host memory; the encode stream of the
+// trace waits for that word with a stream memory operation (hipStreamWaitValue32 -- a wait in ITS OWN queue, where it has to
+// wait anyway).  Uploads of all contexts go through the one thread: one at a time, in the order of the calls -- two contexts
+// that alternate keep the link busy without ever sharing it.
+struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; };
+namespace {
+struct Uploader {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<UploadJob, std::atomic<int>*>> q;
+    std::thread th;
+    hipStream_t st = nullptr;
+    int device = 0;
+    bool ok = false;
+    void run() {
+        if (hipSetDevice(device) != hipSuccess) return;
+        for (;;) {
+            std::pair<UploadJob, std::atomic<int>*> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                j = q.front();
+                q.pop_front();
+            }
+            const hipError_t e = hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st);
+            const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
+            // (a failed copy publishes too: the prover must not hang; the rows are then wrong and the self-check / verifier says so)
+            (void)e2;
+            __atomic_store_n(j.first.flag, j.first.seq, __ATOMIC_RELEASE);
+            j.second->fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+};
+Uploader* g_uploader[64] = {nullptr};
+std::mutex g_uploader_mu;
+}  // namespace
+static bool uploader_available(lig_ctx* c) {
+    if (c->device < 0 || c->device >= 64) return false;
+    std::lock_guard<std::mutex> lk(g_uploader_mu);
+    Uploader*& u = g_uploader[c->device];
+    if (!u) {
+        int can = 0;
+        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+        u = new Uploader();                         // lives for the process: its thread sleeps on the condition variable
+        u->device = c->device;
+        u->ok = can && hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking) == hipSuccess;
+        if (u->ok) { u->th = std::thread([u] { u->run(); }); u->th.detach(); }
+    }
+    return u->ok;
+}
+static void uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending) {
+    Uploader* u = g_uploader[device];
+    pending->fetch_add((int)jobs.size(), std::memory_order_acq_rel);
+    {
+        std::lock_guard<std::mutex> lk(u->mu);
+        for (const UploadJob& j : jobs) u->q.push_back({j, pending});
+    }
+    u->cv.notify_one();
+}
+// every copy of this trace's uploads has been made (its host rows and its device matrix are no longer touched by the thread)
+static void uploader_drain(lig_trace* T) {
+    while (T->up_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+}
 // message rows of a rows job -> T->msgs.  Device rows: one copy on the main stream.  Host rows: the upload starts now, on
 // the copy stream, one event per stage-1 chunk: lig_rows_commit encodes chunk b while chunk b+1 is still on the bus.
 static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device) {
@@ -632,14 +720,34 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         return LIG_OK;
     }
     T->host_msgs = (const uint8_t*)msgs;
-    if (T->ev_up.empty()) {
-        T->ev_up.resize(T->sched1.size(), nullptr);
-        for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     // (every earlier reader of `dst` has finished: lig_rows_prove returns only after its stream work is done)
     // (A copy kernel reading the pinned rows over PCIe instead of the DMA engine was measured: 37 GB/s against 56 GB/s, and
     // the long-running kernel serialises with the proof's kernels whenever both streams share a hardware queue:
     // stage 2 5.6 -> 13.8 ms.  The DMA engine it is.)
+    static const int mode = [] { const char* e = std::getenv("LIG_UPLOAD_MODE"); return e ? std::atoi(e) : 2; }();   // 2: uploader thread (default), 1: per-context copy stream + events
+    if (mode == 2 && uploader_available(c)) {
+        if (!T->up_flag) {
+            HIP_TRY(c, hipHostMalloc((void**)&T->up_flag, 4096, hipHostMallocDefault));
+            std::memset((void*)T->up_flag, 0, 4096);
+            HIP_TRY(c, hipHostGetDevicePointer((void**)&T->up_flag_dev, (void*)T->up_flag, 0));
+            if (T->sched1.size() > 1024) FAIL(c, LIG_E_ARG, "rows job: too many stage-1 chunks");
+        }
+        T->up_seq++;
+        std::vector<UploadJob> jobs;
+        for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+            const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
+            const size_t off = b * (size_t)k * 32, bytes = nb * (size_t)k * 32;
+            jobs.push_back(UploadJob{(uint8_t*)dst + off, T->host_msgs + off, bytes, T->up_flag + ci, T->up_seq});
+        }
+        uploader_submit(c->device, jobs, &T->up_pending);
+        T->up_by_thread = true;
+        return LIG_OK;
+    }
+    T->up_by_thread = false;
+    if (T->ev_up.empty()) {
+        T->ev_up.resize(T->sched1.size(), nullptr);
+        for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     for (size_t ci = 0; ci < T->sched1.size(); ci++) {
         const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
         const size_t off = b * (size_t)k * 32, bytes = nb * (size_t)k * 32;
@@ -721,7 +829,7 @@ int lig_rows_restart(lig_trace* T, const void* msgs, int msgs_on_device) {
     CHECK_CTX(c);
     if (!T->from_rows) FAIL(c, LIG_E_STATE, "lig_rows_restart: not a rows trace");
     if (T->R && !msgs) FAIL(c, LIG_E_ARG, "lig_rows_restart: null rows");
-    if (T->loaded && T->host_msgs) HIP_TRY(c, hipStreamSynchronize(c->stream3));      // an upload nobody committed: let it finish first
+    if (T->loaded && T->host_msgs) { uploader_drain(T); HIP_TRY(c, hipStreamSynchronize(c->stream3)); }      // an upload nobody committed: let it finish first
     return rows_load(c, T, msgs, msgs_on_device != 0);
 }
 int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {

@@ -392,6 +392,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemsetAsync(S->parts, 0, (2 * (size_t)pg + dot_groups) * k * 32, s));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key + memsets above
     HIP_TRY(c, hipStreamWaitEvent(s_hash, c->ev_fork, 0));
+    // as in lig_synth_prove: the sampler also accumulates the message-domain halves of the code / linear tests (k_rand_rlc)
+    const bool fused_rlc = (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
     auto form_rand_chunk = [&](size_t cidx) -> int {           // on the side stream
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
         fr* rb = S->randb + (cidx & 1) * CAP * (size_t)k;
@@ -401,7 +403,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
             const size_t gr = S->grow[lb + r];
             const uint32_t d = S->rows[gr].data;
             while (r + run < nb && S->rows[gr + run].data == d) run++;
-            lig::launch_rng_fill_rows_dense(s_hash, c->rk_dev, S->lin_pos[gr], rb + r * k, run, d, k);
+            if (fused_rlc) lig::launch_rand_rlc(s_hash, c->rk_dev, S->lin_pos[gr], rb + r * k, S->msgs + (lb + r) * (size_t)k, run, d, k, S->coef_dev + lb + r, lig_tune::GROUP / 4, p_code, p_linH);
+            else lig::launch_rng_fill_rows_dense(s_hash, c->rk_dev, S->lin_pos[gr], rb + r * k, run, d, k);
             r += run;
         }
         HIP_TRY(c, hipEventRecord(S->ev_enc[cidx & 1], s_hash));
@@ -420,7 +423,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
                 TRY(lig_internal_encode_rows(c, rb, S->rhalf, nb, lig::ENC_HALF));
                 lig::launch_rlc_accumulate29(s, S->cw + lb * 3 * (size_t)k + k, 3 * (size_t)k, 1, S->rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::DOT_GROUP);
             }
-            lig::launch_rlc_accumulate29(s, S->msgs + lb * (size_t)k, k, 1, rb, k, nb, k, S->coef_dev + lb, p_code, p_linH, lig_tune::GROUP / 4);
+            if (!fused_rlc) lig::launch_rlc_accumulate29(s, S->msgs + lb * (size_t)k, k, 1, rb, k, nb, k, S->coef_dev + lb, p_code, p_linH, lig_tune::GROUP / 4);
         }
         HIP_TRY(c, hipEventRecord(S->ev_comm[cidx & 1], s));
     }
