@@ -339,6 +339,22 @@ int  lig_shard_prepare(lig_ctx *ctx, const lig_synth_job *job, uint32_t rank, ui
 int  lig_shard_prove(lig_shard *shard, const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
 void lig_shard_destroy(lig_shard *shard);
 
+/* ==== one trace sharded over the GPUs, rows SUPPLIED BY THE CALLER (configs[4]: a real constraint generator on N GPUs): what
+ * lig_rows_* is to lig_synth_*.  Every rank passes the kinds of ALL committed rows -- the deal (lig_shard_rows_plan: global
+ * chunk g belongs to rank g mod world) and the encoding-stream positions are global -- and the message rows of ITS OWN chunks
+ * only, in commit order (job->rows = all rows, job->msgs = the local rows; dense_rands_per_row, if given, covers all rows).
+ * lig_shard_rows_commit = stage 1 on all ranks (same root and seed everywhere); each rank's constraint generator then derives
+ * the randomness rows of its own rows; lig_shard_rows_prove takes those (local rows x k, zero rows for batch kinds) and the
+ * public linear constant (NULL: minus the sum of all inner products, as lig_rows_prove).  Every rank obtains the envelope of
+ * lig_rows_prove on the whole trace.  Replaces the per-row callbacks of include/zkp/nonbatch_context.hpp:445-471, :654-780,
+ * :924-970 when the rows of one trace live on several GPUs. ==== */
+int lig_shard_rows_plan(const uint8_t *kinds, size_t n_rows, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
+int lig_shard_rows_begin(lig_ctx *ctx, const lig_rows_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
+int lig_shard_rows_restart(lig_shard *shard, const void *local_msgs, int msgs_on_device);   /* next trace, same shape */
+int lig_shard_rows_commit(lig_shard *shard, uint8_t root[32], uint8_t stage1_seed[32]);
+int lig_shard_rows_prove(lig_shard *shard, const void *local_rands, int rands_on_device, const uint8_t *const_sum,
+                         const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+
 /* Measurement hook (no reference counterpart): while enabled, every lig_encode_rows launch group records HIP
  * events on the context stream immediately around the dominant kernel (k_encode_tiles).  lig_profile_read syncs
  * and returns the number of bracketed launches, the rows they covered and the summed kernel time. */

@@ -35,6 +35,7 @@ EXPORTS = [
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
+    "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
 ]
 
 ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
@@ -184,6 +185,11 @@ def load_library():
     L.lig_rccl_comm_create.argtypes = [vp, vp, u32, u32, C.POINTER(Comm)]
     L.lig_rccl_comm_destroy.argtypes = [C.POINTER(Comm)]
     L.lig_rccl_comm_destroy.restype = None
+    L.lig_shard_rows_plan.argtypes = [vp, sz, u32, C.POINTER(u64), vp, sz]
+    L.lig_shard_rows_begin.argtypes = [vp, C.POINTER(RowsJob), u32, u32, C.POINTER(Comm), C.POINTER(vp)]
+    L.lig_shard_rows_restart.argtypes = [vp, vp, C.c_int]
+    L.lig_shard_rows_commit.argtypes = [vp, vp, vp]
+    L.lig_shard_rows_prove.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_ipc_comm_create.argtypes = [vp, C.c_char_p, u32, u32, C.POINTER(Comm)]
     L.lig_ipc_comm_destroy.argtypes = [C.POINTER(Comm)]
     L.lig_ipc_comm_destroy.restype = None
@@ -241,6 +247,27 @@ def shard_plan(job, l, world):
     if L.lig_shard_plan(C.byref(job), l, world, C.byref(rounds), _hptr(b), cap) != 0:
         raise LigError("lig_shard_plan failed")
     return int(rounds.value), [int(x) for x in b[:rounds.value * world + 1]]
+
+
+def shard_rows_plan(kinds, world):
+    """-> (rounds, boundaries): the block-cyclic deal of a rows job's committed rows over `world` ranks (host only):
+    global chunk g = rows [b[g], b[g+1]) belongs to rank g mod world"""
+    L = load_library()
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    rounds = C.c_uint64()
+    cap = 1 << 16
+    b = np.zeros(cap, dtype=np.uint64)
+    if L.lig_shard_rows_plan(_hptr(kinds) if len(kinds) else None, len(kinds), world, C.byref(rounds), _hptr(b), cap) != 0:
+        raise LigError("lig_shard_rows_plan failed")
+    return int(rounds.value), [int(x) for x in b[:rounds.value * world + 1]]
+
+
+def local_rows_of(boundaries, rank, world):
+    """global row indices of `rank`'s chunks, in commit order"""
+    out = []
+    for g in range(rank, len(boundaries) - 1, world):
+        out.extend(range(boundaries[g], boundaries[g + 1]))
+    return out
 
 
 def sample_columns(seed, n, t=192):
@@ -425,6 +452,55 @@ class Context:
 
     def shard_destroy(self, shard):
         self.L.lig_shard_destroy(shard)
+
+    # ---- one trace sharded over ranks, rows supplied by the caller (lig_shard_rows_*)
+    def shard_rows_begin(self, kinds_all, local_msgs, rank, world, comm, on_device=False, encoding_seed=None, generated_at=0,
+                         public_args=None, dense_rands_per_row=None):
+        """kinds_all: the kinds of ALL committed rows; local_msgs: this rank's rows (lig_shard_rows_plan), (rows_local, k, 8) uint32"""
+        kinds = np.ascontiguousarray(kinds_all, dtype=np.uint8)
+        job = RowsJob()
+        job.rows = len(kinds)
+        job.kinds = kinds.ctypes.data if len(kinds) else None
+        keep = (kinds,)
+        if on_device:
+            job.msgs = local_msgs.value if hasattr(local_msgs, "value") else int(local_msgs)
+        else:
+            local_msgs = np.ascontiguousarray(local_msgs, dtype=np.uint32)
+            job.msgs = local_msgs.ctypes.data if local_msgs.size else None
+            keep += (local_msgs,)
+        job.msgs_on_device = int(bool(on_device))
+        es = bytes(range(32)) if encoding_seed is None else bytes(encoding_seed)
+        for i in range(32):
+            job.encoding_seed[i] = es[i]
+            job.program_hash[i] = 0
+        job.generated_at = generated_at
+        job.version = b"1.5.0"
+        job.set_public_args(public_args)
+        if dense_rands_per_row is not None:
+            dr = np.ascontiguousarray(dense_rands_per_row, dtype=np.uint32)
+            job.dense_rands_per_row = dr.ctypes.data if len(dr) else None
+            keep += (dr,)
+        t = C.c_void_p()
+        self.check(self.L.lig_shard_rows_begin(self.h, C.byref(job), rank, world, C.byref(comm), C.byref(t)))
+        return t
+
+    def shard_rows_commit(self, shard):
+        root, seed = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+        self.check(self.L.lig_shard_rows_commit(shard, _hptr(root), _hptr(seed)))
+        return root.tobytes(), seed.tobytes()
+
+    def shard_rows_prove(self, shard, local_rands, const_sum, on_device=False):
+        proof, ln, info = C.POINTER(C.c_uint8)(), C.c_size_t(), ProofInfo()
+        cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy() if const_sum is not None else None
+        if local_rands is None:
+            rp = None
+        elif on_device:
+            rp = local_rands
+        else:
+            local_rands = np.ascontiguousarray(local_rands, dtype=np.uint32)
+            rp = C.c_void_p(local_rands.ctypes.data if local_rands.size else None)
+        self.check(self.L.lig_shard_rows_prove(shard, rp, int(bool(on_device)), _hptr(cs), C.byref(proof), C.byref(ln), C.byref(info)))
+        return C.string_at(proof, ln.value), info
 
     def synth_prepare(self, n_linear, n_quad=0, synth_seed=1, generated_at=0, encoding_seed=None):
         import hashlib

@@ -31,7 +31,15 @@ struct lig_shard {
     std::vector<size_t> lrow0;                 // local row offset of my c-th chunk (rounds + 1 entries)
     std::vector<size_t> grow;                  // global row of every local row
     std::vector<uint64_t> wit_pos, lin_pos;    // stream position of every global row (+1 entry)
-    std::vector<uint64_t> code_ord, pad_ord;   // code-test draws / pad draws before every global row (+1 entry)
+    std::vector<uint64_t> code_ord;            // code-test draws before every global row (+1 entry)
+    std::vector<uint8_t> draw;                 // per global row: its k-l pads are drawn here at commit time (pad_encoding_random)
+    std::vector<uint64_t> enc_pos;             // encoding-stream position of every global row's pads (+1 entry = the masks' position)
+    bool from_rows = false;                    // lig_shard_rows_*: the local rows and their randomness rows come from the caller
+    bool dense_rands = false, committed = false;
+    lig_proof_info info1;                      // stage-1 results kept between lig_shard_rows_commit and lig_shard_rows_prove
+    uint8_t encoding_seed[32] = {0}, program_hash[32] = {0};
+    int64_t generated_at = 0;
+    char version[17] = {0};
     size_t RB = 0, n_init = 0;                 // leading rows committed by the batch program, of those: init rows
     size_t R = 0, Rl = 0, rows_max = 0, ncol = 0, rounds = 0, G = 0, ch_cap = 0;
     fr *msgs = nullptr, *cw = nullptr, *maskcw = nullptr, *send = nullptr, *recv = nullptr, *randb = nullptr, *rhalf = nullptr, *acc = nullptr,
@@ -106,6 +114,10 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
     lig_shard* S = new lig_shard();
     S->c = c; S->job = *job; S->comm = *comm; S->rank = rank; S->world = world;
     S->job.batch_ops = nullptr; S->job.batch_data = nullptr;
+    std::memcpy(S->encoding_seed, job->encoding_seed, 32);
+    std::memcpy(S->program_hash, job->program_hash, 32);
+    std::memcpy(S->version, job->version, 16);
+    S->generated_at = job->generated_at;
     {   // instance_hash over arg0 = "Ligero\0" and the public arguments (src/webgpu_prover.cpp:110-168)
         if (job->n_public_args && (!job->public_args || !job->public_arg_lens)) { delete S; return LIG_E_ARG; }
         std::memset(S->ih, 0, 32);
@@ -124,22 +136,64 @@ int lig_shard_prepare(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint3
     *out = S;
     return LIG_OK;
 }
+// the deal + every buffer of a shard whose global row plan (S->rows) is known
+static int shard_alloc(lig_ctx* c, uint32_t rank, uint32_t world, lig_shard* S);
 static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t rank, uint32_t world, lig_shard* S) {
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, W = world;
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     if (l >= k || l < 2 || t > n || k - l < t || k % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | k");
-    S->ncol = n / world;
-    S->exchange_even_alone = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
     if (!plan_rows(*job, l, S->rows, S->n_init)) FAIL(c, LIG_E_ARG, "malformed batch program");
+    if (S->n_init && k - l != 192) FAIL(c, LIG_E_ARG, "batch program: on_batch_init draws params::sample_size = 192 pads, k - l must be 192");
     const size_t R = S->R = S->rows.size();
     for (S->RB = 0; S->RB < R && S->rows[S->RB].kind >= RK_INIT; S->RB++) {}
-    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0); S->pad_ord.assign(R + 1, 0);
+    S->wit_pos.assign(R + 1, 0); S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0);
+    S->draw.assign(R, 0); S->enc_pos.assign(R + 1, 0);
     for (size_t r = 0; r < R; r++) {
         const uint8_t kd = S->rows[r].kind;
         S->wit_pos[r + 1] = S->wit_pos[r] + ((kd == 3 || kd >= RK_INIT) ? 0 : S->rows[r].data);   // z rows and batch rows draw nothing
         S->lin_pos[r + 1] = S->lin_pos[r] + S->rows[r].data;
         S->code_ord[r + 1] = S->code_ord[r] + has_code_check(kd);                                    // position in the code-test stream
-        S->pad_ord[r + 1] = S->pad_ord[r] + ((kd <= 3 || kd == RK_INIT) ? 1 : 0);                   // rows that draw k-l pads upstream
+        S->draw[r] = kd <= 3;                                                                        // stream rows draw at commit time; init rows drew theirs in the program
+        S->enc_pos[r + 1] = S->enc_pos[r] + ((kd <= 3 || kd == RK_INIT) ? (k - l) : 0);             // rows that draw k-l pads upstream
     }
+    TRY(shard_alloc(c, rank, world, S));
+    const size_t Rl = S->Rl;
+    // local witness rows: same stream positions as in the single-GPU trace
+    uint32_t rk[60];
+    if (S->RB) {          // the batch program is small: every rank runs it and keeps the rows it owns
+        fr* all = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&all, S->RB * (size_t)k * sizeof(fr)));
+        int rc = lig_run_batch_program(c, *job, all);
+        for (size_t lr = 0; lr < Rl && rc == LIG_OK; lr++)
+            if (S->grow[lr] < S->RB && hipMemcpyAsync(S->msgs + lr * (size_t)k, all + S->grow[lr] * (size_t)k, (size_t)k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = LIG_E_HIP;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(all);
+        if (rc != LIG_OK) return rc;
+    }
+    lig::aes256_expand_host(job->witness_key, rk);
+    TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, c->stream));
+    for (size_t lr = 0; lr < Rl;) {
+        const size_t gr = S->grow[lr];
+        const RowDesc d = S->rows[gr];
+        if (d.kind >= RK_INIT) { lr++; continue; }
+        if (d.kind == 0) {
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[gr], S->msgs + lr * k, 1, d.data, k, 0, 1, d.data);
+            lr += 1;
+        } else {          // x, y, z are consecutive locally as well: chunks never split a triple
+            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[gr], S->msgs + lr * k, 2, d.data, k, 0, 1, d.data);
+            lig::launch_eltwise(c->stream, LIG_OP_MUL, S->msgs + lr * k, S->msgs + (lr + 1) * k, S->msgs + (lr + 2) * k, d.data, fr{}, 0);
+            lr += 3;
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+static int shard_alloc(lig_ctx* c, uint32_t rank, uint32_t world, lig_shard* S) {
+    const uint32_t k = c->k, n = c->n, t = 192, W = world;
+    const size_t R = S->R;
+    S->ncol = n / world;
+    S->exchange_even_alone = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
     shard_chunks(S->rows, W, S->rounds, S->gb);
     S->G = S->rounds * W;
     for (size_t g = 0; g < S->G; g++) S->ch_cap = std::max(S->ch_cap, S->chunk_rows(g));
@@ -206,35 +260,6 @@ static int shard_prepare_impl(lig_ctx* c, const lig_synth_job* job, uint32_t ran
     if (!S->triples.empty()) HIP_TRY(c, hipMemcpyAsync(S->tri_dev, S->triples.data(), S->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
     TRY(lig_internal_reserve_scratch(c, chunk));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // local witness rows: same stream positions as in the single-GPU trace
-    uint32_t rk[60];
-    if (S->RB) {          // the batch program is small: every rank runs it and keeps the rows it owns
-        fr* all = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&all, S->RB * (size_t)k * sizeof(fr)));
-        int rc = lig_run_batch_program(c, *job, all);
-        for (size_t lr = 0; lr < Rl && rc == LIG_OK; lr++)
-            if (S->grow[lr] < S->RB && hipMemcpyAsync(S->msgs + lr * (size_t)k, all + S->grow[lr] * (size_t)k, (size_t)k * sizeof(fr), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = LIG_E_HIP;
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(all);
-        if (rc != LIG_OK) return rc;
-    }
-    lig::aes256_expand_host(job->witness_key, rk);
-    TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, c->stream));
-    for (size_t lr = 0; lr < Rl;) {
-        const size_t gr = S->grow[lr];
-        const RowDesc d = S->rows[gr];
-        if (d.kind >= RK_INIT) { lr++; continue; }
-        if (d.kind == 0) {
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[gr], S->msgs + lr * k, 1, d.data, k, 0, 1, d.data);
-            lr += 1;
-        } else {          // x, y, z are consecutive locally as well: chunks never split a triple
-            lig::launch_rng_fill_rows(c->stream, c->rk_dev, S->wit_pos[gr], S->msgs + lr * k, 2, d.data, k, 0, 1, d.data);
-            lig::launch_eltwise(c->stream, LIG_OP_MUL, S->msgs + lr * k, S->msgs + (lr + 1) * k, S->msgs + (lr + 2) * k, d.data, fr{}, 0);
-            lr += 3;
-        }
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
     return LIG_OK;
 }
 
@@ -256,42 +281,40 @@ void lig_shard_destroy(lig_shard* S) {
     delete S;
 }
 
-int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
-    if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
-    lig_ctx* c = S->c;
-    CHECK_CTX(c);
-    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l, W = S->world;
-    const size_t R = S->R, Rl = S->Rl, RM = S->rows_max, ncol = S->ncol, CAP = S->ch_cap;
-    hipStream_t s = c->stream, s_hash = c->stream2, s_comm = c->stream3;
-    std::memset(info, 0, sizeof *info);
-    info->rows = R + 3;
-    const auto t_begin = clk::now();
-    auto t0 = clk::now();
-    const bool ordered = S->comm.all_to_all_on != nullptr && S->comm.all_gather_on != nullptr;
-    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos && c->err.find("ipc comm") == std::string::npos) c->err = std::string("collective failed: ") + what; else c->err = std::string(what) + ": " + c->err; return (int)LIG_E_STATE; };
-    // all-gather in stream order on `st` (RCCL) or host-synchronously after draining `st`
-    auto all_gather = [&](const void* src, void* dst, size_t bytes, hipStream_t st, const char* what) -> int {
-        if (ordered) { if (S->comm.all_gather_on(S->comm.user, src, dst, bytes, st)) return comm_fail(what); return LIG_OK; }
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (S->comm.all_gather(S->comm.user, src, dst, bytes)) return comm_fail(what);
-        return LIG_OK;
-    };
+// where the stage-2 randomness rows of the LOCAL rows come from: generated (dense rows of the synthetic stream) or the caller's
+struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
+#define SHARD_COMMON \
+    lig_ctx* c = S->c; \
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l, W = S->world; \
+    const size_t R = S->R, Rl = S->Rl, RM = S->rows_max, ncol = S->ncol, CAP = S->ch_cap; \
+    hipStream_t s = c->stream, s_hash = c->stream2, s_comm = c->stream3; \
+    const bool ordered = S->comm.all_to_all_on != nullptr && S->comm.all_gather_on != nullptr; \
+    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos && c->err.find("ipc comm") == std::string::npos) c->err = std::string("collective failed: ") + what; else c->err = std::string(what) + ": " + c->err; return (int)LIG_E_STATE; }; \
+    auto all_gather = [&](const void* src, void* dst, size_t bytes, hipStream_t st, const char* what) -> int { \
+        if (ordered) { if (S->comm.all_gather_on(S->comm.user, src, dst, bytes, st)) return comm_fail(what); return LIG_OK; } \
+        HIP_TRY(c, hipStreamSynchronize(st)); \
+        if (S->comm.all_gather(S->comm.user, src, dst, bytes)) return comm_fail(what); \
+        return LIG_OK; \
+    }; \
+    (void)l; (void)pad; (void)RM; (void)t; (void)s_comm; (void)W; (void)Rl; (void)R; (void)CAP; (void)ncol; (void)s_hash; (void)all_gather
 
+static int shard_stage1(lig_shard* S, lig_proof_info* info) {
+    SHARD_COMMON;
     // ---------------- stage 1
     uint32_t rk[60];
-    lig::aes256_expand_host(S->job.encoding_seed, rk);
+    lig::aes256_expand_host(S->encoding_seed, rk);
     TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, s));
     // pads of the local rows that draw them at commit time (batch init rows carry theirs from the program): the position
     // of a row's pads = number of pad-drawing rows before it in commit order; runs of consecutive rows = one launch
     for (size_t lr = 0; lr < Rl;) {
         const size_t gr = S->grow[lr];
-        if (S->rows[gr].kind > 3) { lr++; continue; }
+        if (!S->draw[gr]) { lr++; continue; }
         size_t run = 1;
-        while (lr + run < Rl && S->grow[lr + run] == gr + run && S->rows[gr + run].kind <= 3) run++;
-        lig::launch_rng_fill_rows(s, c->rk_dev, S->pad_ord[gr] * pad, S->msgs + lr * (size_t)k, run, pad, k, l, 1, pad);
+        while (lr + run < Rl && S->grow[lr + run] == gr + run && S->draw[gr + run] && S->enc_pos[gr + run] == S->enc_pos[gr + run - 1] + pad) run++;
+        lig::launch_rng_fill_rows(s, c->rk_dev, S->enc_pos[gr], S->msgs + lr * (size_t)k, run, pad, k, l, 1, pad);
         lr += run;
     }
-    uint64_t epos = S->pad_ord[R] * pad;
+    uint64_t epos = S->enc_pos[R];
     fr* mask = S->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;                        // masks: formed by every rank
     const size_t k3 = 3 * (size_t)k, kq = ncol / 4;                                                      // kq = positions per coset of a rank's columns
     HIP_TRY(c, hipMemsetAsync(mask, 0, 3 * (size_t)n * 32, s));
@@ -361,8 +384,13 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     Sha256().add("LigetronStage1", 15).add(info->root, 32).add(S->ih, 32).finish(info->stage1_seed);
-    info->ms_stage1 = ms_since(t0);
-    t0 = clk::now();
+    return LIG_OK;
+}
+
+static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* const_sum_given, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
+    SHARD_COMMON;
+    auto t0 = clk::now();
+    uint32_t rk[60];
 
     // ---------------- stage 2
     const size_t NTl = S->triple_ord.size();
@@ -383,6 +411,9 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     }
     fr* code = S->acc; fr* lin = S->acc + n; fr* quad = S->acc + 2 * (size_t)n; fr* tmp = S->acc + 3 * (size_t)n;
     fr* linH = lin + 2 * (size_t)k; fr* linC = lin + 3 * (size_t)k;
+    fr* mask = S->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;       // the mask codewords of stage 1
+    const size_t kq = ncol / 4;
+    (void)kq;
     HIP_TRY(c, hipMemsetAsync(S->acc, 0, 4 * (size_t)n * 32, s));
     // as in lig_synth_prove: the randomness rows of chunk c+1 are sampled on the side stream (dense rows, double-buffered)
     // while the main stream encodes / accumulates chunk c; group partials persist across chunks, one combine per accumulator
@@ -393,11 +424,19 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key + memsets above
     HIP_TRY(c, hipStreamWaitEvent(s_hash, c->ev_fork, 0));
     // as in lig_synth_prove: the sampler also accumulates the message-domain halves of the code / linear tests (k_rand_rlc)
-    const bool fused_rlc = (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
+    const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
+    // the caller's randomness rows (lig_shard_rows_prove): device rows are used in place, host rows go through the double buffer
+    auto rand_buf = [&](size_t cidx) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + S->lrow0[cidx] * (size_t)k : S->randb + (cidx & 1) * CAP * (size_t)k; };
     auto form_rand_chunk = [&](size_t cidx) -> int {           // on the side stream
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
-        fr* rb = S->randb + (cidx & 1) * CAP * (size_t)k;
+        fr* rb = rand_buf(cidx);
+        if (rs.dev) { HIP_TRY(c, hipEventRecord(S->ev_enc[cidx & 1], s_hash)); return LIG_OK; }
         if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s_hash, S->ev_comm[cidx & 1], 0));        // buffer consumed (event reused: stage 1 is over)
+        if (rs.host) {
+            if (nb) HIP_TRY(c, hipMemcpyAsync(rb, rs.host + lb * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, s_hash));
+            HIP_TRY(c, hipEventRecord(S->ev_enc[cidx & 1], s_hash));
+            return LIG_OK;
+        }
         for (size_t r = 0; r < nb;) {          // a chunk is a run of consecutive global rows: runs of equal fill are contiguous in the linear stream
             size_t run = 1;
             const size_t gr = S->grow[lb + r];
@@ -413,7 +452,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     if (S->rounds) TRY(form_rand_chunk(0));
     for (size_t cidx = 0; cidx < S->rounds; cidx++) {
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
-        fr* rb = S->randb + (cidx & 1) * CAP * (size_t)k;
+        fr* rb = rand_buf(cidx);
         if (cidx + 1 < S->rounds) TRY(form_rand_chunk(cidx + 1));
         HIP_TRY(c, hipStreamWaitEvent(s, S->ev_enc[cidx & 1], 0));
         if (nb) {
@@ -487,7 +526,8 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
         h2.finish(info->stage2_seed);
     }
     (void)enc_bytes;
-    {
+    if (const_sum_given) std::memcpy(info->const_sum, const_sum_given, 32);     // the caller's public constant (linear_sums)
+    else {
         const H::Fr sum = H::neg(dots[0]);                    // (copied before ev_acc[0])
         std::memcpy(info->const_sum, sum.v, 32);
     }
@@ -514,9 +554,9 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     lig::launch_gather_rows(s, S->maskcw, n, 3, c->sample_idx, t, S->smp + Rl * (size_t)t);
     TRY(all_gather(S->smp, S->smpg, RM * (size_t)t * 32, s, "all_gather(opened columns)"));
     char ver[17] = {0};
-    std::memcpy(ver, S->job.version, 16);
+    std::memcpy(ver, S->version, 16);
     const size_t smp_bytes = (R + 3) * (size_t)t * 32;
-    const EnvelopeLayout lay = write_envelope(S->h_proof, S->h_proof_cap, ver, S->job.program_hash, S->job.generated_at, k, n, t,
+    const EnvelopeLayout lay = write_envelope(S->h_proof, S->h_proof_cap, ver, S->program_hash, S->generated_at, k, n, t,
                                               info->root, sib, idx, enc, smp_bytes);
     if (lay.total > S->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
     // opened columns in commit order: global chunk g = the (g / W)-th chunk of rank g mod W
@@ -534,8 +574,160 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     *proof = S->h_proof;
     *proof_len = lay.total;
     info->ms_stage3 = ms_since(t0);
-    info->ms_total = ms_since(t_begin);
     HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+
+int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_proof_info* info) {
+    if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
+    lig_ctx* c = S->c;
+    CHECK_CTX(c);
+    if (S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_prove on a shard made by lig_shard_rows_begin (use lig_shard_rows_commit / _prove)");
+    std::memset(info, 0, sizeof *info);
+    info->rows = S->R + 3;
+    const auto t_begin = clk::now();
+    TRY(shard_stage1(S, info));
+    info->ms_stage1 = ms_since(t_begin);
+    TRY(shard_stage23(S, ShardRands{}, nullptr, proof, proof_len, info));
+    info->ms_total = ms_since(t_begin);
+    return LIG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The sharded prover over rows SUPPLIED BY THE CALLER (include/lig_hip.h: lig_shard_rows_*): what lig_rows_* is to
+// lig_synth_*, for one trace over the GPUs of a node.  Every rank passes the kinds of ALL committed rows (the deal and the
+// stream positions are global) and the message rows of ITS chunks only, in commit order; after the commit every rank's
+// constraint generator derives the randomness rows of its own rows from the stage-1 seed.
+// Replaces the per-row callbacks of include/zkp/nonbatch_context.hpp:445-471 (stage 1), :654-780 (stage 2), :924-970 (stage 3).
+static bool kinds_to_rows(lig_ctx* c, const lig_rows_job* job, std::vector<RowDesc>& rows, std::vector<uint8_t>& draw, std::vector<uint64_t>& pos) {
+    const uint32_t k = c->k, l = c->l, pad = k - l;
+    const size_t R = job->rows;
+    rows.resize(R); draw.assign(R, 0); pos.assign(R + 1, 0);
+    for (size_t r = 0; r < R; r++) {
+        const uint8_t kd = job->kinds[r] & 0x7f;
+        if (kd > RK_BQZ) { c->err = "rows job: unknown row kind"; return false; }
+        const bool first_of_3 = kd == 1 || kd == RK_BQX, first_of_2 = kd == RK_EQX;
+        if (first_of_3 && !(r + 2 < R && (job->kinds[r + 1] & 0x7f) == kd + 1 && (job->kinds[r + 2] & 0x7f) == kd + 2)) { c->err = "rows job: incomplete x,y,z triple"; return false; }
+        if (first_of_2 && !(r + 1 < R && (job->kinds[r + 1] & 0x7f) == RK_EQY)) { c->err = "rows job: incomplete equality pair"; return false; }
+        const bool follower = kd == 2 || kd == 3 || kd == RK_EQY || kd == RK_BQY || kd == RK_BQZ;
+        if (follower && !(r > 0 && (job->kinds[r - 1] & 0x7f) == kd - 1)) { c->err = "rows job: row of a group without its predecessor"; return false; }
+        const bool draws = kd <= 3 || kd == RK_INIT;
+        if (kd == RK_INIT && pad != 192) { c->err = "rows job: on_batch_init rows need k - l = 192 (params::sample_size)"; return false; }
+        if ((job->kinds[r] & LIG_ROW_DRAW_PAD) && !draws) { c->err = "rows job: LIG_ROW_DRAW_PAD on a row kind that draws no padding upstream"; return false; }
+        draw[r] = (job->kinds[r] & LIG_ROW_DRAW_PAD) ? 1 : 0;
+        pos[r + 1] = pos[r] + (draws ? pad : 0);
+        const uint32_t dense = job->dense_rands_per_row ? job->dense_rands_per_row[r] : 0;
+        if (dense > k || (dense && kd > 3)) { c->err = "rows job: dense_rands_per_row out of range or on a batch row"; return false; }
+        rows[r] = RowDesc{kd, dense};
+    }
+    return true;
+}
+
+int lig_shard_rows_plan(const uint8_t* kinds, size_t n_rows, uint32_t world, uint64_t* rounds_out, uint64_t* boundaries, size_t cap) {
+    if ((n_rows && !kinds) || !world || !rounds_out) return LIG_E_ARG;
+    std::vector<RowDesc> rows(n_rows);
+    for (size_t r = 0; r < n_rows; r++) rows[r] = RowDesc{(uint8_t)(kinds[r] & 0x7f), 0};
+    size_t rounds = 0;
+    std::vector<size_t> gb;
+    shard_chunks(rows, world, rounds, gb);
+    *rounds_out = rounds;
+    if (gb.size() > cap || !boundaries) return gb.size() > cap ? LIG_E_NOMEM : LIG_E_ARG;
+    for (size_t i = 0; i < gb.size(); i++) boundaries[i] = gb[i];
+    return LIG_OK;
+}
+
+static int shard_rows_load(lig_shard* S, const void* local_msgs, bool on_device) {
+    lig_ctx* c = S->c;
+    if (S->Rl && !local_msgs) FAIL(c, LIG_E_ARG, "sharded rows job: null local rows");
+    if (S->Rl) HIP_TRY(c, hipMemcpyAsync(S->msgs, local_msgs, S->Rl * (size_t)c->k * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the caller's memory is no longer referenced
+    S->committed = false;
+    return LIG_OK;
+}
+
+int lig_shard_rows_begin(lig_ctx* c, const lig_rows_job* job, uint32_t rank, uint32_t world, const lig_comm* comm, lig_shard** out) {
+    CHECK_CTX(c);
+    if (!job || !out || !comm || world == 0 || rank >= world) return LIG_E_ARG;
+    if (!comm->all_to_all || !comm->all_gather) return LIG_E_ARG;
+    if (job->rows && !job->kinds) FAIL(c, LIG_E_ARG, "sharded rows job: null kinds");
+    const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
+    if (l >= k || l < 2 || t > n || k - l < t || k % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | k");
+    *out = nullptr;
+    lig_shard* S = new lig_shard();
+    S->c = c; S->comm = *comm; S->rank = rank; S->world = world; S->from_rows = true;
+    std::memset(&S->job, 0, sizeof S->job);
+    std::memcpy(S->encoding_seed, job->encoding_seed, 32);
+    std::memcpy(S->program_hash, job->program_hash, 32);
+    std::memcpy(S->version, job->version, 16);
+    S->generated_at = job->generated_at;
+    S->dense_rands = job->dense_rands_per_row != nullptr;
+    auto fail = [&](int rc) { lig_shard_destroy(S); return rc; };
+    if (job->n_public_args && (!job->public_args || !job->public_arg_lens)) return fail(LIG_E_ARG);
+    std::memset(S->ih, 0, 32);
+    Sha256().add(S->ih, 32).add("Ligero", 7).finish(S->ih);
+    const uint8_t* a = job->public_args;
+    for (uint64_t i = 0; i < job->n_public_args; i++) {
+        uint8_t prev[32];
+        std::memcpy(prev, S->ih, 32);
+        Sha256().add(prev, 32).add(a, job->public_arg_lens[i]).finish(S->ih);
+        a += job->public_arg_lens[i];
+    }
+    if (!kinds_to_rows(c, job, S->rows, S->draw, S->enc_pos)) return fail(LIG_E_ARG);
+    const size_t R = S->R = S->rows.size();
+    S->lin_pos.assign(R + 1, 0); S->code_ord.assign(R + 1, 0); S->wit_pos.assign(R + 1, 0);
+    for (size_t r = 0; r < R; r++) {
+        S->lin_pos[r + 1] = S->lin_pos[r] + S->rows[r].data;
+        S->code_ord[r + 1] = S->code_ord[r] + has_code_check(S->rows[r].kind);
+    }
+    int rc = shard_alloc(c, rank, world, S);
+    if (rc == LIG_OK) rc = shard_rows_load(S, job->msgs, job->msgs_on_device != 0);
+    if (rc != LIG_OK) return fail(rc);
+    *out = S;
+    return LIG_OK;
+}
+// the next trace of the same shape: new local rows into the same buffers
+int lig_shard_rows_restart(lig_shard* S, const void* local_msgs, int msgs_on_device) {
+    if (!S) return LIG_E_ARG;
+    lig_ctx* c = S->c;
+    CHECK_CTX(c);
+    if (!S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_rows_restart: not a rows shard");
+    return shard_rows_load(S, local_msgs, msgs_on_device != 0);
+}
+int lig_shard_rows_commit(lig_shard* S, uint8_t root[32], uint8_t stage1_seed[32]) {
+    if (!S) return LIG_E_ARG;
+    lig_ctx* c = S->c;
+    CHECK_CTX(c);
+    if (!S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_rows_commit: not a rows shard");
+    if (S->committed) FAIL(c, LIG_E_STATE, "lig_shard_rows_commit: the committed trace has not been proved yet");
+    std::memset(&S->info1, 0, sizeof S->info1);
+    S->info1.rows = S->R + 3;
+    const auto t_begin = clk::now();
+    TRY(shard_stage1(S, &S->info1));
+    S->info1.ms_stage1 = ms_since(t_begin);
+    S->committed = true;
+    if (root) std::memcpy(root, S->info1.root, 32);
+    if (stage1_seed) std::memcpy(stage1_seed, S->info1.stage1_seed, 32);
+    return LIG_OK;
+}
+int lig_shard_rows_prove(lig_shard* S, const void* local_rands, int rands_on_device, const uint8_t const_sum[32], const uint8_t** proof,
+                         size_t* proof_len, lig_proof_info* info) {
+    if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
+    lig_ctx* c = S->c;
+    CHECK_CTX(c);
+    if (!S->from_rows || !S->committed) FAIL(c, LIG_E_STATE, "lig_shard_rows_prove: lig_shard_rows_commit has not run on this shard");
+    if (S->Rl && !local_rands && !S->dense_rands) FAIL(c, LIG_E_ARG, "lig_shard_rows_prove: null randomness rows");
+    if (const_sum) {
+        H::Fr v;
+        std::memcpy(v.v, const_sum, 32);
+        if (H::geq(v, H::P)) FAIL(c, LIG_E_ARG, "lig_shard_rows_prove: constant not reduced mod p");
+    }
+    *info = S->info1;
+    const auto t_begin = clk::now();
+    ShardRands rs;
+    if (local_rands && rands_on_device) rs.dev = (const fr*)local_rands; else if (local_rands) rs.host = (const uint8_t*)local_rands;
+    TRY(shard_stage23(S, rs, const_sum, proof, proof_len, info));
+    info->ms_total = info->ms_stage1 + ms_since(t_begin);
+    S->committed = false;
     return LIG_OK;
 }
 

@@ -236,3 +236,107 @@ def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_pat
     sh = out["sharded"]
     assert sh["ranks"] == 2 and sh["log2_constraints"] == 24 and sh["scaling"] == "strong"
     assert sh["proof_equals_oracle_pin"] is True and sh["all_ranks_same_envelope"] is True
+
+
+ROWS_WORKER = textwrap.dedent('''
+    import ctypes as C, hashlib, importlib.util, json, os, sys
+    import numpy as np
+    root, l, k, n, n_lin, n_quad, batch, mode = sys.argv[1], *map(int, sys.argv[2:7]), sys.argv[7] == "1", sys.argv[8]
+    sys.path.insert(0, os.path.join(root, "tests"))
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
+        m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+    pkg = load("ligero_prover_amd", "__init__.py")
+    dist = load("lig_dist", "dist.py")
+    import oracle_lib as ol
+    g = dist.Group("gloo")
+    ctx = pkg.Context(l, k, n, device=0)
+    # the oracle plays the guest + witness_manager: ALL rows, their kinds, later the randomness rows (every rank runs the
+    # same deterministic "guest" and keeps its slice, as N copies of a constraint generator would)
+    job = ol.make_job(l, k, n, 192, n_lin, n_quad, generated_at=55, threads=4)
+    if batch:
+        import test_batch_rows
+        test_batch_rows.demo_program().attach(job)
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job).copy()
+    rounds, b = pkg.shard_rows_plan(kinds, g.world)
+    mine = pkg.local_rows_of(b, g.rank, g.world)
+    local = rows[mine] if len(mine) else np.zeros((0, k, 8), dtype=np.uint32)
+    kk = kinds.copy()
+    if mode == "library_pads":                       # the library draws the pads of every row that draws upstream
+        draws = (kinds <= 3) | (kinds == pkg.ROW_KINDS["INIT"])
+        kk[draws] |= pkg.ROW_DRAW_PAD
+        local = local.copy()
+        if len(mine):
+            local[draws[mine], l:] = 0xDEADBEEF
+    comm = g.make_comm(pkg, ctx)
+    if mode == "device_rows":
+        d_local = ctx.upload(local) if len(mine) else ctx.malloc(32)
+        sh = ctx.shard_rows_begin(kk, d_local, g.rank, g.world, comm, on_device=True, generated_at=55)
+    else:
+        sh = ctx.shard_rows_begin(kk, local, g.rank, g.world, comm, generated_at=55)
+    out = []
+    for rep in range(2):                             # the second pass: lig_shard_rows_restart with the same rows
+        if rep:
+            ctx.check(ctx.L.lig_shard_rows_restart(sh, d_local if mode == "device_rows" else C.c_void_p(local.ctypes.data if local.size else None), int(mode == "device_rows")))
+        root_, seed1 = ctx.shard_rows_commit(sh)
+        rands, const_sum = ol.rand_rows(job, seed1)
+        lr = rands[mine] if len(mine) else np.zeros((0, k, 8), dtype=np.uint32)
+        if mode == "device_rows":
+            d_r = ctx.upload(lr) if len(mine) else ctx.malloc(32)
+            proof, info = ctx.shard_rows_prove(sh, d_r, const_sum if rep == 0 else None, on_device=True)
+        else:
+            proof, info = ctx.shard_rows_prove(sh, lr, const_sum if rep == 0 else None)
+        out.append((proof, bytes(info.const_sum) == const_sum, [info.valid_code, info.valid_linear, info.valid_quad]))
+    ctx.shard_destroy(sh)
+    ref = oref = None
+    if g.rank == 0:                                  # the unsharded rows entry on the same rows, and the oracle's prover
+        tr, keep = ctx.rows_begin(kinds, rows, generated_at=55)
+        ctx.rows_commit(tr)
+        ref, _ = ctx.rows_prove(tr, rands, const_sum)
+        ctx.trace_destroy(tr)
+        pr = ol.Proof()
+        assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) == 0
+        oref = bytes(pr.proof[:pr.proof_len])
+        ol.lib().lo_proof_free(C.byref(pr))
+    digs = g.gather_digests(hashlib.sha256(out[0][0]).digest())
+    print(json.dumps({"rank": g.rank, "local_rows": len(mine), "rounds": rounds, "again": out[0][0] == out[1][0], "const": out[0][1] and out[1][1],
+                      "valid": out[0][2], "all_equal": len(set(digs)) == 1,
+                      "equals_rows_prove": None if ref is None else ref == out[0][0], "equals_oracle": None if oref is None else oref == out[0][0]}))
+    g.close(); ctx.close()
+''')
+
+
+def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch, mode, comm):
+    script = tmp_path / "shard_rows_worker.py"
+    script.write_text(ROWS_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if comm:
+        env.update(LIG_COMM=comm, LIG_COMM_TAG=str(os.getpid()))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad), "1" if batch else "0", mode],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    outs = []
+    for p in procs:
+        o, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err.decode()[-3000:]
+        outs.append(json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1]))
+    return sorted(outs, key=lambda d: d["rank"])
+
+
+@pytest.mark.parametrize("world,n_lin,n_quad,batch,mode,comm", [
+    (2, 2000, 900, False, "library_pads", None),          # gloo callbacks, library draws the pads
+    (2, 2000, 900, False, "own_pads", "ipc"),             # stream-ordered peers, rows carry their pads
+    (4, 700, 0, False, "library_pads", "ipc"),            # 3 rows on 4 ranks: a rank without rows
+    (2, 900, 330, True, "own_pads", "ipc"),               # batch rows (init / equal / product / bit) dealt like any other rows
+    (4, 900, 330, True, "library_pads", None),
+    (2, 320 * 1500 + 7, 330, False, "device_rows", "ipc"),      # two exchange rounds, local rows and randomness rows on the device
+    (4, 320 * 4300 + 1, 0, False, "library_pads", "ipc"),       # three rounds on 4 ranks
+])
+def test_sharded_rows_entry_equals_rows_prove_and_oracle(tmp_path, world, n_lin, n_quad, batch, mode, comm):
+    """lig_shard_rows_*: one trace whose rows come from the caller, sharded over W ranks (each rank passes all kinds + its own
+    rows and randomness rows): every rank's envelope == lig_rows_prove on the whole trace == the oracle's prover"""
+    outs = run_rows_world(tmp_path, world, 320, 512, 2048, n_lin, n_quad, 29881 + world, batch, mode, comm)
+    assert all(o["valid"] == [1, 1, 1] and o["again"] and o["const"] and o["all_equal"] for o in outs), outs
+    assert outs[0]["equals_rows_prove"] is True and outs[0]["equals_oracle"] is True, outs
+    if world == 4 and n_lin == 700:
+        assert min(o["local_rows"] for o in outs) == 0
