@@ -251,6 +251,13 @@ typedef struct {
      * successive elements of the stream keyed by stage1_seed, zeros up to k -- so lig_rows_prove(rands = NULL) may
      * generate them on the device (sampled under the encodes, as lig_synth_prove does) instead of reading them */
     const uint32_t *dense_rands_per_row;
+    /* optional (NULL: every row is k full 32-byte elements): the NARROW row format.  One byte per row: 0 or 32 = the row as
+     * above; 4 or 8 = only the row's l data slots are supplied, each as a little-endian unsigned integer of that many bytes
+     * (real traces are mostly bits and machine words: 8x / 4x less to move over PCIe; the reference ships 32 bytes per slot,
+     * include/util/mpz_vector.hpp:108-127).  `msgs` then holds the rows back to back, a narrow row taking l * 4 (or 8)
+     * bytes; the library expands it on the device.  A narrow row must be LINEAR / QX / QY / QZ and flagged
+     * LIG_ROW_DRAW_PAD (its k - l pad slots are drawn by the library).  lig_rows_restart takes the same packed layout. */
+    const uint8_t *elem_bytes;
 } lig_rows_job;
 int lig_rows_begin(lig_ctx *ctx, const lig_rows_job *job, lig_trace **out);
 int lig_rows_commit(lig_trace *trace, uint8_t root[32], uint8_t stage1_seed[32]);

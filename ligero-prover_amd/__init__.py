@@ -76,7 +76,7 @@ class RowsJob(C.Structure):
                 ("reserved", C.c_int32), ("encoding_seed", C.c_uint8 * 32), ("program_hash", C.c_uint8 * 32),
                 ("generated_at", C.c_int64), ("version", C.c_char * 16),
                 ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64),
-                ("dense_rands_per_row", C.c_void_p)]
+                ("dense_rands_per_row", C.c_void_p), ("elem_bytes", C.c_void_p)]
 
     def set_public_args(self, args):
         _attach_public_args(self, args)
@@ -247,6 +247,19 @@ def shard_plan(job, l, world):
     if L.lig_shard_plan(C.byref(job), l, world, C.byref(rounds), _hptr(b), cap) != 0:
         raise LigError("lig_shard_plan failed")
     return int(rounds.value), [int(x) for x in b[:rounds.value * world + 1]]
+
+
+def pack_rows(rows, widths, l):
+    """rows (R, k, 8) uint32 + per-row width (4 / 8 / 32) -> the packed byte array of the narrow row format
+    (lig_rows_job.elem_bytes): a narrow row contributes its l data slots as little-endian integers of that width"""
+    parts = []
+    for r, w in enumerate(widths):
+        if w in (0, 32):
+            parts.append(np.ascontiguousarray(rows[r], dtype=np.uint32).tobytes())
+        else:
+            assert not rows[r, :l, w // 4:].any(), "row %d does not fit %d-byte elements" % (r, w)
+            parts.append(np.ascontiguousarray(rows[r, :l, :w // 4], dtype=np.uint32).tobytes())
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
 
 
 def shard_rows_plan(kinds, world):
@@ -540,7 +553,7 @@ class Context:
 
     # ---- the same prover over rows supplied by the caller (lig_rows_*)
     def rows_begin(self, kinds, msgs, on_device=False, encoding_seed=None, generated_at=0, public_args=None, program_hash=None,
-                   dense_rands_per_row=None):
+                   dense_rands_per_row=None, elem_bytes=None):
         """kinds: uint8 array (ROW_KINDS | ROW_DRAW_PAD); msgs: device pointer (on_device) or a (rows, k, 8) uint32 host array.
         -> (trace, keepalive); keep `keepalive` referenced until rows_commit has returned"""
         kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
@@ -549,9 +562,16 @@ class Context:
         job.kinds = kinds.ctypes.data if len(kinds) else None
         if on_device:
             job.msgs, keep = (msgs.value if hasattr(msgs, "value") else int(msgs)), (kinds,)
+        elif elem_bytes is not None:              # narrow format: msgs is the packed byte string (pack_rows)
+            msgs = np.frombuffer(bytes(msgs), dtype=np.uint8).copy() if not isinstance(msgs, np.ndarray) else np.ascontiguousarray(msgs, dtype=np.uint8)
+            job.msgs, keep = (msgs.ctypes.data if msgs.size else None), (kinds, msgs)
         else:
             msgs = np.ascontiguousarray(msgs, dtype=np.uint32)
             job.msgs, keep = (msgs.ctypes.data if msgs.size else None), (kinds, msgs)
+        if elem_bytes is not None:
+            eb = np.ascontiguousarray(elem_bytes, dtype=np.uint8)
+            job.elem_bytes = eb.ctypes.data if len(eb) else None
+            keep = keep + (eb,)
         job.msgs_on_device = int(bool(on_device))
         es = bytes(range(32)) if encoding_seed is None else bytes(encoding_seed)
         ph = bytes(32) if program_hash is None else bytes(program_hash)

@@ -22,6 +22,28 @@
 #include <mutex>
 #include <thread>
 
+namespace lig {
+// Narrow rows -> message rows: element i < l of row r is the little-endian integer of widths[r] (4 / 8) bytes at
+// packed + off[r] + i * widths[r]; slots l..k-1 are zeroed (their pads are drawn right after); a row of width 32 is copied.
+__global__ void __launch_bounds__(256) k_expand_rows(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ off, const uint8_t* __restrict__ widths,
+                                                     size_t first_row, size_t rows, uint32_t l, uint32_t k, fr* __restrict__ out) {
+    const size_t total = rows * k;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = first_row + e / k;
+        const uint32_t i = (uint32_t)(e % k), w = widths[r];
+        const uint8_t* src = packed + off[r];
+        fr v = fr_zero();
+        if (w == 32) v = fr_load(reinterpret_cast<const fr*>(src) + i);
+        else if (i < l) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (size_t)i * w);
+            v.v[0] = p[0];
+            if (w == 8) v.v[1] = p[1];
+        }
+        fr_store(out + r * k + i, v);
+    }
+}
+}  // namespace lig
+
 struct lig_trace {
     lig_ctx* c = nullptr;
     lig_synth_job job;                  // synthetic jobs only (n_linear / n_quad / witness_key); pointers cleared
@@ -43,6 +65,12 @@ struct lig_trace {
     uint32_t up_seq = 0;
     bool up_by_thread = false;
     std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
+    // narrow row format (lig_rows_job.elem_bytes): packed byte offset of every row (+1 entry), the widths, the device staging
+    // area the packed rows are uploaded to (expanded into `msgs` chunk by chunk in stage 1)
+    bool narrow = false;
+    std::vector<uint64_t> src_off;
+    std::vector<uint8_t> widths;
+    uint64_t* src_off_dev = nullptr; uint8_t* widths_dev = nullptr; uint8_t* packed_dev = nullptr;
     lig_proof_info info1;               // stage-1 results kept between lig_rows_commit and lig_rows_prove
     size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
@@ -286,6 +314,8 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
         if (streamed) {
             if (T->up_by_thread) HIP_TRY(c, hipStreamWaitValue32(s_enc, T->up_flag_dev + ci, T->up_seq, hipStreamWaitValueGte, 0xffffffffu));
             else HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_up[ci], 0));                   // this chunk's rows have arrived
+            if (T->narrow) hipLaunchKernelGGL(lig::k_expand_rows, dim3((uint32_t)std::min<size_t>((nb * k + 255) / 256, 4096)), dim3(256), 0, s_enc, T->packed_dev,
+                                              T->src_off_dev, T->widths_dev, b, nb, l, k, T->msgs);
             for (; pr_i < T->pad_runs.size() && T->pad_runs[pr_i].first < b + nb; pr_i++) {      // runs never straddle chunks (split in begin)
                 const PadRun& pr = T->pad_runs[pr_i];
                 lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
@@ -603,6 +633,7 @@ void lig_trace_destroy(lig_trace* T) {
     for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
     for (hipEvent_t e : T->ev_up) (void)hipEventDestroy(e);
     if (T->up_flag) (void)hipHostFree((void*)T->up_flag);
+    (void)hipFree(T->src_off_dev); (void)hipFree(T->widths_dev); (void)hipFree(T->packed_dev);
     (void)hipHostFree(T->h_proof); (void)hipHostFree(T->h_enc); (void)hipHostFree(T->h_nodes); (void)hipHostFree(T->h_small);
     delete T;
 }
@@ -659,7 +690,7 @@ struct Uploader {
                 j = q.front();
                 q.pop_front();
             }
-            const hipError_t e = hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st);
+            const hipError_t e = j.first.bytes ? hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st) : hipSuccess;
             const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
             // (a failed copy publishes too: the prover must not hang; the rows are then wrong and the self-check / verifier says so)
             (void)e2;
@@ -708,7 +739,9 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
     T->alt_pending = false;
     if (!R) return LIG_OK;
     fr* dst = T->msgs;
-    if (T->committed) {
+    // narrow host rows land in the packed staging area and are expanded into `msgs` by lig_rows_commit (after the previous
+    // proof has finished with it): no second matrix needed
+    if (T->committed && !(T->narrow && !on_device)) {
         // the committed trace still needs its rows for stage 2: the next trace goes to the second matrix and is swapped in
         // by lig_rows_commit -- its upload runs under lig_rows_prove of the current one
         if (!T->msgs_alt) HIP_TRY(c, hipMalloc((void**)&T->msgs_alt, R * (size_t)k * 32));
@@ -716,10 +749,16 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         T->alt_pending = true;
     }
     if (on_device) {
-        HIP_TRY(c, hipMemcpyAsync(dst, msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
+        if (T->narrow) hipLaunchKernelGGL(lig::k_expand_rows, dim3((uint32_t)std::min<size_t>((R * k + 255) / 256, 8192)), dim3(256), 0, c->stream, (const uint8_t*)msgs,
+                                          T->src_off_dev, T->widths_dev, (size_t)0, R, c->l, k, dst);
+        else HIP_TRY(c, hipMemcpyAsync(dst, msgs, R * (size_t)k * 32, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipGetLastError());
         return LIG_OK;
     }
     T->host_msgs = (const uint8_t*)msgs;
+    // byte range of a stage-1 chunk in the caller's matrix / the destination of its copy
+    auto chunk_src = [&](size_t b) -> size_t { return T->narrow ? (size_t)T->src_off[b] : b * (size_t)k * 32; };
+    uint8_t* up_dst = T->narrow ? T->packed_dev : (uint8_t*)dst;
     // (every earlier reader of `dst` has finished: lig_rows_prove returns only after its stream work is done)
     // (A copy kernel reading the pinned rows over PCIe instead of the DMA engine was measured: 37 GB/s against 56 GB/s, and
     // the long-running kernel serialises with the proof's kernels whenever both streams share a hardware queue:
@@ -735,9 +774,9 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         T->up_seq++;
         std::vector<UploadJob> jobs;
         for (size_t ci = 0; ci < T->sched1.size(); ci++) {
-            const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
-            const size_t off = b * (size_t)k * 32, bytes = nb * (size_t)k * 32;
-            jobs.push_back(UploadJob{(uint8_t*)dst + off, T->host_msgs + off, bytes, T->up_flag + ci, T->up_seq});
+            const size_t b = T->sched1[ci].first, e = T->sched1[ci].second;
+            const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
+            jobs.push_back(UploadJob{up_dst + off, T->host_msgs + off, bytes, T->up_flag + ci, T->up_seq});
         }
         uploader_submit(c->device, jobs, &T->up_pending);
         T->up_by_thread = true;
@@ -749,9 +788,9 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     for (size_t ci = 0; ci < T->sched1.size(); ci++) {
-        const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
-        const size_t off = b * (size_t)k * 32, bytes = nb * (size_t)k * 32;
-        HIP_TRY(c, hipMemcpyAsync((uint8_t*)dst + off, T->host_msgs + off, bytes, hipMemcpyHostToDevice, c->stream3));
+        const size_t b = T->sched1[ci].first, e = T->sched1[ci].second;
+        const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
+        if (bytes) HIP_TRY(c, hipMemcpyAsync(up_dst + off, T->host_msgs + off, bytes, hipMemcpyHostToDevice, c->stream3));
         HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
     }
     HIP_TRY(c, hipGetLastError());
@@ -799,7 +838,26 @@ static int rows_begin_impl(lig_ctx* c, const lig_rows_job* job, lig_trace* T) {
     }
     T->dense_rands = job->dense_rands_per_row != nullptr;
     T->mask_pos = pos[R];
+    if (job->elem_bytes) {            // the narrow row format
+        T->src_off.assign(R + 1, 0);
+        T->widths.assign(R ? R : 1, 32);
+        for (size_t r = 0; r < R; r++) {
+            const uint8_t w = job->elem_bytes[r] ? job->elem_bytes[r] : 32;
+            if (w != 4 && w != 8 && w != 32) FAIL(c, LIG_E_ARG, "rows job: elem_bytes must be 0, 4, 8 or 32");
+            if (w != 32 && (T->rows[r].kind > 3 || !draw[r])) FAIL(c, LIG_E_ARG, "rows job: a narrow row must be LINEAR / QX / QY / QZ with LIG_ROW_DRAW_PAD");
+            T->narrow = T->narrow || w != 32;
+            T->widths[r] = w;
+            T->src_off[r + 1] = T->src_off[r] + (w == 32 ? (uint64_t)k * 32 : (uint64_t)l * w);
+        }
+    }
     TRY(trace_alloc(c, T));
+    if (T->narrow) {
+        HIP_TRY(c, hipMalloc((void**)&T->src_off_dev, (R + 1) * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void**)&T->widths_dev, R));
+        HIP_TRY(c, hipMemcpy(T->src_off_dev, T->src_off.data(), (R + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(T->widths_dev, T->widths.data(), R, hipMemcpyHostToDevice));
+        if (!job->msgs_on_device) HIP_TRY(c, hipMalloc((void**)&T->packed_dev, T->src_off[R] ? T->src_off[R] : 16));
+    }
     // pad runs: consecutive flagged rows whose stream positions are consecutive, never straddling a stage-1 chunk
     for (const auto& ch : T->sched1)
         for (size_t r = ch.first; r < ch.second;) {

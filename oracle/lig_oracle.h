@@ -176,6 +176,10 @@ typedef struct {
     /* public arguments after arg0 = "Ligero\0" (src/webgpu_prover.cpp:110-168), byte strings back to back in the form the
      * reference holds them in input_args (i64 = 8 LE bytes, str with its NUL, hex decoded); NULL / 0: none */
     const uint8_t *public_args; const uint64_t *public_arg_lens; uint64_t n_public_args;
+    /* 0: witnesses are full field elements.  32 / 64: every witness DRAW (linear, x, y slots) keeps only its low 32 / 64 bits --
+     * the synthetic counterpart of a real trace, whose witnesses are mostly bits and machine words; used to check the narrow
+     * row format of the HIP rows entry (lig_rows_job.elem_bytes) against this prover */
+    uint32_t witness_bits;
 } lo_job;
 
 typedef struct {

@@ -174,7 +174,11 @@ void lo_form_rows(const lo_job *j, lo_fr *rows, lo_fr *mask_code, lo_fr *mask_li
             lo_fr *row = rows + (size_t)r * k;
             if (d[r].kind >= RK_INIT || (d[r].kind == 3) != (pass == 1)) continue;
             memset(row, 0, sizeof(lo_fr) * k);
-            if (d[r].kind != 3) { lo_rng w = wit; w.pos = wpos[r]; lo_rng_fill(&w, row, d[r].data); }   /* linear, x, y: fresh witnesses */
+            if (d[r].kind != 3) {                                              /* linear, x, y: fresh witnesses */
+                lo_rng w = wit; w.pos = wpos[r]; lo_rng_fill(&w, row, d[r].data);
+                if (j->witness_bits == 32 || j->witness_bits == 64)
+                    for (uint32_t i = 0; i < d[r].data; i++) { row[i].v[0] &= j->witness_bits == 32 ? 0xffffffffull : ~0ull; row[i].v[1] = row[i].v[2] = row[i].v[3] = 0; }
+            }
             else {                                                          /* z = x * y */
                 const lo_fr *y = row - k, *x = row - 2 * (size_t)k;
                 for (uint32_t i = 0; i < d[r].data; i++) lo_fr_mul(&row[i], &x[i], &y[i]);

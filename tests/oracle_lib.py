@@ -28,7 +28,8 @@ class Job(C.Structure):
                 ("encoding_seed", C.c_uint8 * 32), ("witness_key", C.c_uint8 * 32),
                 ("generated_at", C.c_int64), ("threads", C.c_int),
                 ("batch_ops", C.c_void_p), ("n_batch_ops", C.c_uint64), ("batch_data", C.c_void_p), ("batch_data_bytes", C.c_uint64),
-                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64)]
+                ("public_args", C.c_void_p), ("public_arg_lens", C.c_void_p), ("n_public_args", C.c_uint64),
+                ("witness_bits", C.c_uint32)]
 
     def set_public_args(self, args):
         args = [bytes(a) for a in (args or [])]

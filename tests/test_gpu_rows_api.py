@@ -259,3 +259,61 @@ def test_full_size_proof_equals_oracle_pin(amd, lg):
         assert c.synth_verify(job, None, proof).accept == 1
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("bits,n_linear,n_quad,where", [
+    (32, 320 * 5 + 17, 330, "host"),
+    (64, 320 * 600 + 5, 320 + 9, "host"),            # > one 512-row chunk: chunk byte ranges of mixed-width rows
+    (32, 320 * 3, 0, "device"),
+    (64, 8000 * 3 + 11, 8000, "host8192"),
+])
+def test_rows_entry_narrow_row_format_equals_oracle(amd, bits, n_linear, n_quad, where):
+    """lig_rows_job.elem_bytes: witness rows shipped as 4- / 8-byte integers (only the l data slots; the library draws the pads)
+    and expanded on the device give the envelope of the oracle's prover on the same small-witness trace (lo_job.witness_bits);
+    rows that do not fit (the z rows of x*y = z, every 7th linear row here) stay 32 bytes wide in the same matrix"""
+    l, k, n = (8000, 8192, 32768) if where == "host8192" else (320, 512, 2048)
+    job = ol.make_job(l, k, n, 192, n_linear, n_quad, generated_at=31, threads=8)
+    job.witness_bits = bits
+    want = oracle_prove(job)
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job).copy()
+    R = rows.shape[0]
+    assert not rows[kinds <= 2][:, :l, bits // 32:].any(), "the oracle's small-witness rows are small"
+    widths = np.full(R, 32, dtype=np.uint8)
+    for r in range(R):
+        if kinds[r] <= 2 and not (kinds[r] == 0 and r % 7 == 3):
+            widths[r] = bits // 8
+    kk = kinds.copy()
+    kk[kinds <= 3] |= amd.ROW_DRAW_PAD
+    wide = rows.copy()
+    wide[kinds <= 3, l:] = 0x5A5A5A5A                              # pads come from the library in every case
+    packed = amd.pack_rows(wide, widths, l)
+    assert len(packed) < 0.6 * wide.nbytes
+    c = amd.Context(l, k, n)
+    try:
+        if where == "device":
+            d_packed = c.upload(packed)
+            tr, keep = c.rows_begin(kk, d_packed, on_device=True, generated_at=31, elem_bytes=widths)
+        else:
+            tr, keep = c.rows_begin(kk, packed, generated_at=31, elem_bytes=widths)
+        root, seed1 = c.rows_commit(tr)
+        assert root == want["root"] and seed1 == want["seed1"]
+        rands, const_sum = ol.rand_rows(job, seed1)
+        assert const_sum == want["const_sum"]
+        c.rows_restart(tr, d_packed if where == "device" else packed.ctypes.data, on_device=where == "device")     # the next trace arrives under the proof
+        proof, info = c.rows_prove(tr, rands, const_sum)
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert proof == want["proof"]
+        assert c.rows_commit(tr) == (root, seed1)
+        proof2, _ = c.rows_prove(tr, rands, None)
+        assert proof2 == proof
+        c.trace_destroy(tr)
+        # a narrow row without LIG_ROW_DRAW_PAD, a width that does not exist
+        bad = kk.copy(); bad[0] &= 0x7f
+        with pytest.raises(amd.LigError):
+            c.rows_begin(bad, packed, generated_at=31, elem_bytes=widths)
+        w2 = widths.copy(); w2[0] = 16
+        with pytest.raises(amd.LigError):
+            c.rows_begin(kk, packed, generated_at=31, elem_bytes=w2)
+    finally:
+        c.close()
