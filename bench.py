@@ -182,10 +182,10 @@ class RowsFromHostWorkload:
     (lig_rng_fill_rows), as its public definition allows.  This is the PCIe-inclusive figure (value_incl_h2d)."""
     name = "rows_from_host"
 
-    def __init__(self, ctx, constraints, pkg, inflight, device):
+    def __init__(self, ctx, constraints, pkg, inflight, device, narrow_bytes=0):
         import numpy as np
         import torch
-        self.pkg, self.inflight = pkg, inflight
+        self.pkg, self.inflight, self.narrow_bytes = pkg, inflight, narrow_bytes
         self.constraints_per_trace = constraints
         self.constraints = constraints * inflight
         R = -(-constraints // L_)
@@ -201,6 +201,15 @@ class RowsFromHostWorkload:
         ctx.check(ctx.L.lig_read(ctx.h, C.c_void_p(self.host.data_ptr()), d, R * K_ * 32))
         ctx.free(d)
         kinds = np.full(R, pkg.ROW_KINDS["LINEAR"] | pkg.ROW_DRAW_PAD, dtype=np.uint8)
+        self.widths = None
+        if narrow_bytes:
+            # a small-witness trace in the narrow row format (lig_rows_job.elem_bytes): the low narrow_bytes of every witness,
+            # only the l data slots of every row are shipped (the library draws the pads): 8000 x 8 B instead of 8192 x 32 B per row
+            w = narrow_bytes // 4
+            packed = self.host[:, :L_, :w].contiguous()
+            self.host = torch.empty(packed.shape, dtype=torch.int32, pin_memory=True)
+            self.host.copy_(packed)
+            self.widths = np.full(R, narrow_bytes, dtype=np.uint8)
         self.traces, self.keep = [], []
         for c in self.ctxs:
             t, keep = self._begin(c, kinds)
@@ -224,6 +233,8 @@ class RowsFromHostWorkload:
         job.version = b"1.5.0"
         job.set_public_args(None)
         job.dense_rands_per_row = self.per_row.ctypes.data      # the synthetic stream's dense coefficient rows: sampled on the device
+        if self.widths is not None:
+            job.elem_bytes = self.widths.ctypes.data
         t = C.c_void_p()
         c.check(c.L.lig_rows_begin(c.h, C.byref(job), C.byref(t)))
         return t, (kinds, job)
@@ -487,6 +498,7 @@ def main():
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the stub workload uses gloo)")
     ap.add_argument("--sharded-log2", type=int, default=26, help="N > 1: size of the ONE trace sharded over the ranks (configs[3]: 2^26)")
     ap.add_argument("--sharded-steps", type=int, default=5)
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds after which a hung sharded leg is given up (the line is still printed)")
     ap.add_argument("--sharded-leg", action="store_true", help="run the configs[3] leg with one rank as well")
     ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--log2-constraints", type=int, default=None)
@@ -496,6 +508,8 @@ def main():
     ap.add_argument("--h2d-inflight", type=int, default=2, help="contexts alternating in the PCIe-inclusive measurement: each pipelines "
                     "upload i+1 under proof i, the uploads of all contexts go through one uploader thread (one at a time), so two "
                     "contexts keep the link busy: commit / prove of one under the upload of the other")
+    ap.add_argument("--h2d-narrow", type=int, default=8, choices=[0, 4, 8], help="also time a small-witness trace shipped in the narrow row "
+                    "format with this many bytes per witness slot (0: skip)")
     ap.add_argument("--inflight", type=int, default=2, help="full workload: proofs (traces) proved concurrently per GPU in one step")
     a = ap.parse_args()
     global NO_VERIFY
@@ -598,6 +612,23 @@ def main():
                     "how": "lig_rows_restart/commit/prove: witness rows uploaded from pinned host memory inside the timed region "
                            "(chunk by chunk by the library's uploader thread, each chunk encoded as it arrives; upload i+1 under proof i), "
                            "%d contexts alternating" % hw.inflight}
+            if a.h2d_narrow:
+                try:
+                    hw.close()
+                    hw = RowsFromHostWorkload(ctx, 1 << log2c, pkg, max(1, a.h2d_inflight), local_rank, narrow_bytes=a.h2d_narrow)
+                    hw.run(3)
+                    fence()
+                    t0 = time.perf_counter()
+                    hw.run(a.steps)
+                    fence()
+                    dtn = group.max_over_ranks(time.perf_counter() - t0)
+                    incl["narrow_format"] = {
+                        "value": hw.constraints * a.steps * world / dtn, "ms_per_step": 1e3 * dtn / a.steps, "elem_bytes": a.h2d_narrow,
+                        "witness_bytes_per_trace": int(hw.host.numel() * 4),
+                        "note": "a small-witness trace (every witness < 2^%d) shipped in the narrow row format (lig_rows_job.elem_bytes): 4x less on "
+                                "the link; another trace than the dense one, hence another proof" % (8 * a.h2d_narrow)}
+                except (RuntimeError, MemoryError, pkg.LigError) as e:
+                    sys.stderr.write("narrow H2D leg skipped: %r\n" % (e,))
             hw.close()
         except (RuntimeError, MemoryError, pkg.LigError) as e:      # e.g. no pinned memory left: the resident figure below stands on its own
             incl = None
@@ -671,9 +702,31 @@ def main():
     else:
         out = None
     if a.workload == "full" and not a.no_sharded_leg and (world > 1 or a.sharded_leg):
-        sh = sharded_leg(ctx, group, pkg, a.sharded_log2, a.sharded_steps, 2, fence)       # collective: all ranks
+        # The sharded leg is the one part of this script that needs real peers (RCCL over xGMI).  If it fails or hangs on some
+        # node, the weak-scaling figure measured above must not be lost with it: exceptions are recorded in the line, and a
+        # watchdog on EVERY rank ends the process after --sharded-timeout seconds -- rank 0 prints the line it has first.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(a.sharded_timeout):
+                return
+            if out is not None:
+                out.setdefault("sharded", {"error": "the sharded leg did not finish within %d s (hung collective?); the weak-scaling figures above are unaffected" % a.sharded_timeout})
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            sh = sharded_leg(ctx, group, pkg, a.sharded_log2, a.sharded_steps, 2, fence)       # collective: all ranks
+        except (RuntimeError, MemoryError, pkg.LigError) as e:
+            sh = {"error": repr(e)[:500]}
+            sys.stderr.write("sharded leg failed on rank %d: %r\n" % (rank, e))
         if out is not None:
             out["sharded"] = sh
+        if "error" not in sh:
+            done.set()              # (after a failure the watchdog stays armed: the teardown below may wait for peers that are gone)
     if out is not None:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl.name)

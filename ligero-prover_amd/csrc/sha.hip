@@ -72,8 +72,7 @@ __global__ void k_sha_init(uint32_t* __restrict__ st, size_t n_inst) {
 __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, const fr* __restrict__ rows, size_t row_stride,
                                   size_t nrows, uint64_t rows_before, uint32_t pk, const fr* __restrict__ msgs) {
     // The column chain is sequential in rows: this kernel is latency-bound with only n_inst/64 waves and usually runs
-    // next to an encode kernel on the side stream.  Highest wave priority lets it issue whenever it is ready, so its
-    // critical path stays close to the stand-alone one while the encode waves fill the remaining issue slots.
+    // next to an encode kernel on the side stream.
     // (s_setprio(3) measured: no gain stand-alone, slower when co-resident with the encode kernels.  A two-wave variant --
     // one wave expanding the message schedule of block b+1 into LDS while the other runs the rounds of block b -- was
     // measured too: same stand-alone time, 2 % slower proofs; the per-block barrier and LDS round trip eat the shorter chain.)

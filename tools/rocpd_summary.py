@@ -21,7 +21,9 @@ def main(path, by_grid=None):
     print("|---|---|---|---|---|---|---|")
     for name, n, avg, mn, mx, tot in rows:
         print("| `%s` | %d | %.2f | %.2f | %.2f | %.3f | %.1f |" % (short(name), n, avg / 1e3, mn / 1e3, mx / 1e3, tot / 1e6, 100.0 * tot / total))
-    if by_grid:
+    for by_grid in (by_grid or "").split(";"):
+        if not by_grid:
+            continue
         print()
         print("`%s` by launch size (workgroups):" % by_grid)
         print()
