@@ -690,9 +690,11 @@ def main():
             out["roofline"]["hbm_frac_end_to_end"] = e2e / 8000.0
             out["roofline"]["end_to_end_GBps"] = e2e
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_valu_lds.json")) as f:
-                out["roofline"]["valu_busy_pct"] = {kname: v.get("VALUBusy") for kname, v in json.load(f).get("kernels", {}).items()}
-                out["roofline"]["valu_busy_source"] = "profiles/pmc_valu_lds.json (rocprofv3 --pmc VALUBusy, stand-alone encode launches)"
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_valu_lds_full_proof.json")) as f:
+                out["roofline"]["valu_busy_pct"] = {kname: v.get("VALUBusy") for kname, v in json.load(f).get("kernels", {}).items()
+                                                    if v.get("VALUBusy", 0) >= 20}
+                out["roofline"]["valu_busy_source"] = ("profiles/r03_pmc_valu_lds_full_proof.json (rocprofv3 --pmc VALUBusy over full proofs, one in flight; "
+                                                       "a committed measurement of this build, not taken in this run)")
         except (OSError, ValueError):
             pass
         if incl is not None:
