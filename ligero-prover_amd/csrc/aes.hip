@@ -10,6 +10,7 @@
 // instruction on gfx950), three-input xors (v_bitop3_b32), and the last round masks S-box bytes out of the same tables.
 #include "fr29.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace lig {
 
@@ -162,16 +163,21 @@ __global__ void __launch_bounds__(256) k_rng_fill_rows_dense(const uint32_t* __r
 // (VALU-bound: the two halves of k_rng_fill_rows_dense + k_rlc_partial fill each other's idle slots, and the randomness row
 // is read once less).  Partials have k_rlc_partial's contract: code_part = running lazy sums (< 2p), lin_part plain values
 // (< 2p), both ADDED to (zeroed by the caller before the first chunk).  Persistent workgroups over (group, 256 positions) tiles.
+#ifndef LIG_RLC_THREADS
+#define LIG_RLC_THREADS 256
+#endif
 template <int LOGR>
-__global__ void __launch_bounds__(256) k_rand_rlc(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ rand_out,
+__global__ void __launch_bounds__(LIG_RLC_THREADS) k_rand_rlc(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ rand_out,
                                                   const fr* __restrict__ msgs, size_t rows, uint32_t per_row, uint32_t k,
                                                   const f29s* __restrict__ rc, uint32_t group_rows, fr* __restrict__ code_part,
                                                   fr* __restrict__ lin_part) {
     __shared__ uint32_t te[1024 << LOGR];
     const uint32_t* tl = te_stage<LOGR>(te);
-    const uint32_t jblocks = k >> 8, groups = (uint32_t)((rows + group_rows - 1) / group_rows), tiles = jblocks * groups;
+    // (-DLIG_RLC_THREADS=512: 512 threads share one 64 KiB set of replicated tables = four waves per SIMD instead of two to hide the LDS
+    // latency of the 448 lookups per element behind the products; measured equal, profiles/r03_fused_rand_rlc_ab.md)
+    const uint32_t jblocks = k / blockDim.x, groups = (uint32_t)((rows + group_rows - 1) / group_rows), tiles = jblocks * groups;
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t g = tile / jblocks, j = ((tile - g * jblocks) << 8) + threadIdx.x;
+        const uint32_t g = tile / jblocks, j = (tile - g * jblocks) * blockDim.x + threadIdx.x;
         const size_t r0 = (size_t)g * group_rows, r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
         const bool live = j < per_row;                         // positions >= per_row of a dense row are zero
         f29 ac = unpack29(fr_load(code_part + (size_t)g * k + j)), al = f29_zero();
@@ -214,12 +220,13 @@ void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_
 void launch_rand_rlc(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, const fr* msgs, size_t rows, uint32_t per_row, uint32_t k,
                      const f29s* rc_dev, uint32_t group_rows, fr* code_part, fr* lin_part) {
     if (!rows) return;
-    const size_t tiles = (size_t)(k >> 8) * ((rows + group_rows - 1) / group_rows);
+    const uint32_t th = (k % LIG_RLC_THREADS == 0) ? LIG_RLC_THREADS : 256;      // k is a multiple of 256 (checked by the callers)
+    const size_t tiles = (size_t)(k / th) * ((rows + group_rows - 1) / group_rows);
     if (rows * k >= BIG_FILL)
-        hipLaunchKernelGGL(k_rand_rlc<REP>, dim3((uint32_t)(tiles < BIG_BLOCKS ? tiles : BIG_BLOCKS)), dim3(256), 0, s, rk60_dev, first, out, msgs, rows, per_row, k,
+        hipLaunchKernelGGL(k_rand_rlc<REP>, dim3((uint32_t)(tiles < BIG_BLOCKS ? tiles : BIG_BLOCKS)), dim3(th), 0, s, rk60_dev, first, out, msgs, rows, per_row, k,
                            rc_dev, group_rows, code_part, lin_part);
     else
-        hipLaunchKernelGGL(k_rand_rlc<0>, dim3((uint32_t)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, s, rk60_dev, first, out, msgs, rows, per_row, k, rc_dev,
+        hipLaunchKernelGGL(k_rand_rlc<0>, dim3((uint32_t)(tiles < 8192 ? tiles : 8192)), dim3(th), 0, s, rk60_dev, first, out, msgs, rows, per_row, k, rc_dev,
                            group_rows, code_part, lin_part);
 }
 
