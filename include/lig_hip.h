@@ -200,6 +200,9 @@ typedef struct {
 } lig_verify_info;
 int lig_synth_verify(lig_ctx *ctx, const lig_synth_job *job, const uint8_t *const_sum /* NULL: derived */, const uint8_t *proof, size_t proof_len,
                      lig_verify_info *out);
+/* the verifiers keep their device workspace on the context between calls (~2.5 GB after a 2^24-constraint verification: allocating it
+ * per call costs milliseconds); this gives it back (it is also freed by lig_ctx_destroy) */
+int lig_verify_release(lig_ctx *ctx);
 
 /* ==== transcript helpers (host only, no GPU work): what a driver needs to stay byte-compatible with the reference ==== */
 enum { LIG_ARG_I64 = 0, LIG_ARG_STR = 1, LIG_ARG_HEX = 2 };

@@ -28,7 +28,7 @@ EXPORTS = [
     "lig_sample_gather", "lig_encode_rows", "lig_sha_update_rows", "lig_merkle_nodes", "lig_merkle_build",
     "lig_rlc_rows", "lig_gather_rows", "lig_rng_fill", "lig_profile_enable", "lig_profile_read",
     "lig_synth_prepare", "lig_synth_prove", "lig_trace_rows", "lig_trace_destroy",
-    "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify",
+    "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify", "lig_verify_release",
     "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
     "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
     "lig_rows_verify_begin", "lig_rows_verify_finish",
@@ -167,6 +167,7 @@ def load_library():
     L.lig_proof_gunzip_size.argtypes = [vp, sz]
     L.lig_proof_gunzip.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
     L.lig_synth_verify.argtypes = [vp, C.POINTER(SynthJob), vp, vp, sz, C.POINTER(VerifyInfo)]
+    L.lig_verify_release.argtypes = [vp]
     L.lig_shard_prepare.argtypes = [vp, C.POINTER(SynthJob), u32, u32, C.POINTER(Comm), C.POINTER(vp)]
     L.lig_shard_prove.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_shard_destroy.argtypes = [vp]
@@ -550,6 +551,9 @@ class Context:
         pb = np.frombuffer(bytes(proof), dtype=np.uint8).copy()
         self.check(self.L.lig_synth_verify(self.h, C.byref(job), _hptr(cs), _hptr(pb), len(pb), C.byref(info)))
         return info
+
+    def verify_release(self):
+        self.check(self.L.lig_verify_release(self.h))
 
     # ---- the same prover over rows supplied by the caller (lig_rows_*)
     def rows_begin(self, kinds, msgs, on_device=False, encoding_seed=None, generated_at=0, public_args=None, program_hash=None,

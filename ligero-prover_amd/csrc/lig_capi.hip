@@ -363,6 +363,16 @@ void lig_ctx_destroy(lig_ctx* c) {
     delete c;
 }
 
+// the verifier's device workspace (~2.5 GB after a 2^24-constraint verification) is kept between calls; a service that is done
+// verifying for a while gives it back with this
+int lig_verify_release(lig_ctx* c) {
+    CHECK_CTX(c);
+    for (hipStream_t st : {c->stream, c->stream2, c->stream3}) if (st) HIP_TRY(c, hipStreamSynchronize(st));
+    for (auto& w : c->vws) if (w.first) (void)hipFree(w.first);
+    c->vws.clear();
+    return LIG_OK;
+}
+
 int lig_sync(lig_ctx* c) { CHECK_CTX(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return LIG_OK; }
 const char* lig_last_error(const lig_ctx* c) { return c ? c->err.c_str() : "null context"; }
 uint32_t lig_message_size(const lig_ctx* c) { return c ? c->l : 0; }

@@ -144,6 +144,9 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     size_t ws_slot = 0;
     auto dm0 = [&](void** p, size_t bytes, bool zero) -> int {
         const size_t need = bytes ? bytes : 16;
+        // slot = the ordinal of the request in this call.  The request sequence is the same for every call mode up to the
+        // derive-only buffers, which are requested LAST (below): a derive call after a non-derive call (or the other way round)
+        // re-uses every common slot instead of shifting them all by one and re-allocating 2.5 GB
         if (ws_slot == c->vws.size()) c->vws.push_back({nullptr, 0});
         auto& w = c->vws[ws_slot++];
         if (w.second < need) {

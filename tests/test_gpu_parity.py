@@ -456,6 +456,11 @@ def test_hip_verifier_agrees_with_restated_verifier(amd, l, k, n, n_linear, n_qu
         # a different statement (one more linear constraint) does not verify
         job2 = amd.Context.make_job(n_linear + l, n_quad, generated_at=99)
         assert c.synth_verify(job2, cs, proof).accept == 0
+        # the verifier's device workspace can be given back and comes back on demand; derive / given-constant calls share it
+        c.verify_release()
+        assert c.synth_verify(job, None, proof).accept == 1
+        assert c.synth_verify(job, cs, proof).accept == 1
+        c.verify_release()
     finally:
         c.close()
 
