@@ -684,6 +684,17 @@ def main():
                                  "arithmetic; v_mad_u64_u32 issues at half the simple-ALU rate); the HBM fraction is small by "
                                  "construction, see DESIGN.md"},
         }
+        # the roof this kernel actually runs against: issue slots of v_mad_u64_u32.  Work per encoded row: 8 tiles x 1024 elements, an
+        # inverse + three forward tile transforms with their twists and seams = ~185k windowed products of 117 v_mad_u64_u32 + 4
+        # v_mul_lo_u32 (DESIGN.md sections 2 and 4); peak: one wave64 multiply per SIMD per 5.4 cycles (measured issue rate,
+        # profiles/r01_ubench_valu_issue_rates.txt), 1024 SIMDs, 2.4 GHz.  Informational: the contract's roofline object above is the HBM one.
+        mads_per_row = 185000.0 * 121
+        peak_mads = 1024 * 64 / 5.4 * 2.4e9
+        if launches:
+            out["roofline"]["valu_multiplier"] = {"achieved_mads_per_s": rows_per_launch * mads_per_row / max(avg_launch_s, 1e-12), "peak_mads_per_s": peak_mads,
+                                                  "frac": rows_per_launch * mads_per_row / max(avg_launch_s, 1e-12) / peak_mads,
+                                                  "how": "185k products/row x 121 multiplies / in-run average launch time of k_encode_tiles, against 1024 SIMDs x 64 lanes / "
+                                                         "5.4 cycles x 2.4 GHz; the other ~45 % of the kernel's instructions (limb adds, masks, shifts, LDS exchanges) share the same issue slots"}
         if a.workload != "encode":
             # whole-proof algorithmic bytes (4*k*32 + 192*32 = 1,054,720 B per committed row) over the wall time
             e2e = 1054720.0 * (wl.rows + 3) * (total_constraints / wl.constraints_per_trace if hasattr(wl, "constraints_per_trace") else a.steps) / dt / 1e9
