@@ -17,6 +17,14 @@
 // The host side only waits for the peers' HOSTS to reach the same call (a few microseconds of skew), never for a GPU.
 // Verified on the target box by tools/ipc_probe.hip (memory handles: an interior pointer exports its allocation's BASE,
 // hence the explicit offset; stream memory operations on registered shared memory; profiles/r03_ipc_probe.txt).
+//
+// What tools/soak_sharded.py taught this file (profiles/r03_soak_sharded_ipc.md):
+//   * exports are cached per epoch -- every hipIpcGetMemHandle exports the allocation anew and fails after a few dozen;
+//   * forget() is a host collective -- a peer must close its mapping BEFORE the owner frees the buffer;
+//   * a send out of an allocation smaller than 2 MiB goes through a window exported once -- such allocations are fragments
+//     of shared blocks and the importer is handed the block's base.
+// Failure model: this is a test communicator.  A rank that fails in the middle of a collective leaves its peers' streams
+// waiting on flags that never come (their hosts give up after 120 s in the next collective; a stream wait has no timeout).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
