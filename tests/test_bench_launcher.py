@@ -54,3 +54,16 @@ def test_a_dying_rank_ends_the_launcher():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                        env=_env(HIP_VISIBLE_DEVICES=""), capture_output=True, timeout=300)
     assert p.returncode != 0
+
+
+def test_under_torch_distributed_run_as_the_driver_launches_it():
+    """the driver's N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... (stub workload, gloo)"""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29961", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "2", "--warmup", "1"],
+                       env=_env(), capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["spawned_by_bench"] is False and out["steps"] == 2

@@ -100,6 +100,7 @@ def test_sharded_proof_with_batch_rows_equals_single_gpu_proof(tmp_path, world):
     (4, 320, 512, 2048, 320 * 4300 + 1, 0),       # three rounds on 4 ranks: buffer REUSE gated by ev_comm / ev_hash with real peers
     (2, 320, 512, 2048, 320 * 5200 + 3, 960),     # six rounds on 2 ranks
     (2, 8000, 8192, 32768, 5 * 8000 + 17, 8000),
+    (8, 320, 512, 2048, 320 * 9000 + 11, 330),   # the node's shape: 8 ranks (8 processes on the one GPU), three rounds, 256 columns per rank
 ])
 def test_sharded_over_stream_ordered_ipc_comm_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, n_quad):
     """W processes on the one GPU, collectives = comm_ipc.hip: peers pull from each other's send buffers, ordering on the
