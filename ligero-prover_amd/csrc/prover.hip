@@ -756,6 +756,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         return LIG_OK;
     }
     T->host_msgs = (const uint8_t*)msgs;
+    if (T->narrow && !T->packed_dev) HIP_TRY(c, hipMalloc((void**)&T->packed_dev, T->src_off[R] ? T->src_off[R] : 16));   // (the job began with device rows)
     // byte range of a stage-1 chunk in the caller's matrix / the destination of its copy
     auto chunk_src = [&](size_t b) -> size_t { return T->narrow ? (size_t)T->src_off[b] : b * (size_t)k * 32; };
     uint8_t* up_dst = T->narrow ? T->packed_dev : (uint8_t*)dst;
