@@ -307,6 +307,15 @@ def test_rows_entry_narrow_row_format_equals_oracle(amd, bits, n_linear, n_quad,
         assert c.rows_commit(tr) == (root, seed1)
         proof2, _ = c.rows_prove(tr, rands, None)
         assert proof2 == proof
+        # the same job fed from the other side (device rows after host rows and vice versa)
+        if where == "device":
+            c.rows_restart(tr, packed.ctypes.data, on_device=False)
+        else:
+            d_alt = c.upload(packed)
+            c.rows_restart(tr, d_alt, on_device=True)
+        assert c.rows_commit(tr) == (root, seed1)
+        proof3, _ = c.rows_prove(tr, rands, const_sum)
+        assert proof3 == proof
         c.trace_destroy(tr)
         # a narrow row without LIG_ROW_DRAW_PAD, a width that does not exist
         bad = kk.copy(); bad[0] &= 0x7f
