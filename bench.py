@@ -708,6 +708,8 @@ def main():
                                                        "a committed measurement of this build, not taken in this run)")
         except (OSError, ValueError):
             pass
+        out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the bench contract of this repo: the PCIe-inclusive rate "
+                                   "is never `value`); SURVEY 8(d)'s H2D-inclusive figure is value_incl_h2d, measured in the same run")
         if incl is not None:
             out["value_incl_h2d"] = incl["value"]
             out["incl_h2d"] = incl
