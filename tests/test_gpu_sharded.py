@@ -271,11 +271,15 @@ ROWS_WORKER = textwrap.dedent('''
         if len(mine):
             local[draws[mine], l:] = 0xDEADBEEF
     comm = g.make_comm(pkg, ctx)
+    dense = None
+    if mode == "dense_rands":                        # the synthetic stream's dense coefficient rows are generated by the library
+        per = [l] * (n_lin // l) + [l] * (3 * (n_quad // l)) + ([n_lin % l] if n_lin % l else []) + ([n_quad % l] * 3 if n_quad % l else [])
+        dense = np.array([0] * (len(kinds) - len(per)) + per, dtype=np.uint32)       # batch rows (in front) carry no randomness
     if mode == "device_rows":
         d_local = ctx.upload(local) if len(mine) else ctx.malloc(32)
         sh = ctx.shard_rows_begin(kk, d_local, g.rank, g.world, comm, on_device=True, generated_at=55)
     else:
-        sh = ctx.shard_rows_begin(kk, local, g.rank, g.world, comm, generated_at=55)
+        sh = ctx.shard_rows_begin(kk, local, g.rank, g.world, comm, generated_at=55, dense_rands_per_row=dense)
     out = []
     for rep in range(2):                             # the second pass: lig_shard_rows_restart with the same rows
         if rep:
@@ -286,6 +290,8 @@ ROWS_WORKER = textwrap.dedent('''
         if mode == "device_rows":
             d_r = ctx.upload(lr) if len(mine) else ctx.malloc(32)
             proof, info = ctx.shard_rows_prove(sh, d_r, const_sum if rep == 0 else None, on_device=True)
+        elif mode == "dense_rands":
+            proof, info = ctx.shard_rows_prove(sh, None, const_sum if rep == 0 else None)
         else:
             proof, info = ctx.shard_rows_prove(sh, lr, const_sum if rep == 0 else None)
         out.append((proof, bytes(info.const_sum) == const_sum, [info.valid_code, info.valid_linear, info.valid_quad]))
@@ -332,6 +338,8 @@ def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch, mode, c
     (4, 900, 330, True, "library_pads", None),
     (2, 320 * 1500 + 7, 330, False, "device_rows", "ipc"),      # two exchange rounds, local rows and randomness rows on the device
     (4, 320 * 4300 + 1, 0, False, "library_pads", "ipc"),       # three rounds on 4 ranks
+    (2, 320 * 700 + 9, 330 + 5, False, "dense_rands", "ipc"),  # the dense coefficient rows generated (and accumulated) by the library on every rank
+    (4, 900, 330, True, "dense_rands", None),
 ])
 def test_sharded_rows_entry_equals_rows_prove_and_oracle(tmp_path, world, n_lin, n_quad, batch, mode, comm):
     """lig_shard_rows_*: one trace whose rows come from the caller, sharded over W ranks (each rank passes all kinds + its own
