@@ -36,6 +36,11 @@ struct hip_proof_meta {
     int64_t generated_at = 0;                 // :422-427
     std::string version = "1.5.0";
     std::vector<std::vector<uint8_t>> public_args;   // input_args entries of the PUBLIC arguments after arg0 (:110-168)
+    // Ship narrow rows (lig_rows_job.elem_bytes): a linear / x / y / z row all of whose data slots fit 8 bytes is uploaded as
+    // l x 8 bytes instead of k x 32, and its k - l pad slots are drawn by the library.  Sound only because those pads ARE the
+    // encoding stream at the row's position (witness_manager::pad_encoding_random, witness_manager.hpp:323-336, keyed by
+    // encoding_seed): the library draws the same elements the row arrived with.
+    bool narrow_rows = false;
 };
 
 class hip_row_batcher {
@@ -88,6 +93,33 @@ public:
         job.kinds = kinds_.data();
         job.msgs = rows_.data();
         job.msgs_on_device = 0;
+        std::vector<uint8_t> widths, packed;
+        if (meta_.narrow_rows) {
+            const size_t R = kinds_.size(), words = (size_t)k_ * 4;
+            widths.assign(R ? R : 1, 32);
+            bool any = false;
+            for (size_t r = 0; r < R; r++) {
+                if (kinds_[r] > LIG_ROW_QZ) continue;                       // batch rows are device rows of full width
+                const uint64_t* row = rows_.data() + r * words;
+                bool fits = true;
+                for (uint32_t i = 0; i < l_ && fits; i++) fits = !(row[4 * i + 1] | row[4 * i + 2] | row[4 * i + 3]);
+                if (fits) { widths[r] = 8; any = true; }
+            }
+            if (any) {
+                for (size_t r = 0; r < R; r++) {
+                    const uint64_t* row = rows_.data() + r * words;
+                    if (widths[r] == 8) {
+                        kinds_[r] |= LIG_ROW_DRAW_PAD;
+                        for (uint32_t i = 0; i < l_; i++) { const uint8_t* b = reinterpret_cast<const uint8_t*>(row + 4 * i); packed.insert(packed.end(), b, b + 8); }
+                    } else {
+                        const uint8_t* b = reinterpret_cast<const uint8_t*>(row);
+                        packed.insert(packed.end(), b, b + words * 8);
+                    }
+                }
+                job.msgs = packed.data();
+                job.elem_bytes = widths.data();
+            }
+        }
         std::memcpy(job.encoding_seed, meta_.encoding_seed, 32);
         std::memcpy(job.program_hash, meta_.program_hash, 32);
         job.generated_at = meta_.generated_at;
@@ -97,6 +129,7 @@ public:
         job.n_public_args = lens.size();
         check(lig_rows_begin(ctx_, &job, &trace_), "lig_rows_begin");
         check(lig_rows_commit(trace_, root, stage1_seed), "lig_rows_commit");
+        for (auto& kd : kinds_) kd &= 0x7f;               // (pass 2 compares plain kinds)
         rows_.clear(); rows_.shrink_to_fit();            // the message rows are resident on the device now
         rands_.assign(kinds_.size() * (size_t)k_ * 4, 0);
         pass_ = 2; next_ = 0; enc_pos_ = 0;              // the guest's second run starts the encoding stream over

@@ -13,7 +13,7 @@
 #include "../../oracle/lig_oracle.h"
 
 int main(int argc, char** argv) {
-    if (argc < 6) { std::fprintf(stderr, "usage: %s l k n n_linear n_quad\n", argv[0]); return 2; }
+    if (argc < 6) { std::fprintf(stderr, "usage: %s l k n n_linear n_quad [witness_bits: 64 = small witnesses, shipped as narrow rows]\n", argv[0]); return 2; }
     const uint32_t l = std::atoi(argv[1]), k = std::atoi(argv[2]), n = std::atoi(argv[3]);
     lo_job j;
     std::memset(&j, 0, sizeof j);
@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     lo_synth_key(1, j.witness_key);
     j.generated_at = 4242;
     j.threads = 8;
+    j.witness_bits = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 0;
     const int64_t arg_i64 = -7;                                  // one public i64 argument and one string (with its NUL)
     std::vector<uint8_t> args((const uint8_t*)&arg_i64, (const uint8_t*)&arg_i64 + 8);
     const char* str = "row-batcher";
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
         std::memcpy(meta.encoding_seed, j.encoding_seed, 32);
         meta.generated_at = j.generated_at;
         meta.public_args = {std::vector<uint8_t>(args.begin(), args.begin() + 8), std::vector<uint8_t>(args.begin() + 8, args.end())};
+        meta.narrow_rows = j.witness_bits != 0;                   // x, y and linear rows fit 8 bytes per slot; the z rows (products) stay wide
         ligero::hip_row_batcher b(ctx, meta);
         auto at = [&](const std::vector<lo_fr>& v, size_t r) { return reinterpret_cast<const uint64_t*>(v.data() + r * (size_t)k); };
         auto replay = [&](const std::vector<lo_fr>* rands) {

@@ -94,6 +94,14 @@ def test_row_batcher_shim_compiles_and_links():
 
 
 @pytest.mark.gpu
+def test_row_batcher_shim_ships_narrow_rows():
+    """hip_proof_meta::narrow_rows: a small-witness trace (lo_job.witness_bits = 64) goes through the shim's callbacks as full rows;
+    the shim uploads every row that fits as l x 8 bytes and lets the library draw its pads -- same envelope as the oracle's"""
+    out = subprocess.check_output([build_batcher_exe(), "320", "512", "2048", str(320 * 40 + 7), "700", "64"]).decode()
+    assert out.startswith("equal 1 "), out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("l,k,n,n_lin,n_quad", [(320, 512, 2048, 2000, 700), (320, 512, 2048, 320 * 530 + 1, 0), (8000, 8192, 32768, 20000, 8001)])
 def test_row_batcher_shim_gives_the_oracle_envelope(l, k, n, n_lin, n_quad):
     """include/lig_hip_row_batcher.hpp driven like the reference's stage contexts (two passes of per-row callbacks) produces
