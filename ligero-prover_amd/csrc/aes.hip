@@ -180,11 +180,11 @@ __global__ void __launch_bounds__(LIG_RLC_THREADS) k_rand_rlc(const uint32_t* __
         const uint32_t g = tile / jblocks, j = (tile - g * jblocks) * blockDim.x + threadIdx.x;
         const size_t r0 = (size_t)g * group_rows, r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
         const bool live = j < per_row;                         // positions >= per_row of a dense row are zero
-        f29 ac = unpack29(fr_load(code_part + (size_t)g * k + j)), al = f29_zero();
+        f29 ac = rc != nullptr ? unpack29(fr_load(code_part + (size_t)g * k + j)) : f29_zero(), al = f29_zero();
         int since = 0;
         for (size_t r = r0; r < r1; r++) {
             const f29 u = unpack29(fr_load(msgs + r * k + j));
-            ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));
+            if (rc != nullptr) ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));      // (rc == nullptr: the code test was accumulated up front)
             fr v = fr_zero();
             if (live) {
                 v = aes_field_elem<LOGR>(rk, tl, first + r * (uint64_t)per_row + j);
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(LIG_RLC_THREADS) k_rand_rlc(const uint32_t* __
             fr_store(rand_out + r * k + j, v);
             if (++since == 6) { ac = f29_qnorm(ac); al = f29_qnorm(al); since = 0; }
         }
-        fr_store(code_part + (size_t)g * k + j, pack29(f29_reduce_2p(ac)));
+        if (rc != nullptr) fr_store(code_part + (size_t)g * k + j, pack29(f29_reduce_2p(ac)));
         f29 w = f29_montmul(f29_qnorm(al), f29_const_r2());                                   // plain value, < 1.2p
         w = f29_reduce_2p(f29_add(w, unpack29(fr_load(lin_part + (size_t)g * k + j))));
         fr_store(lin_part + (size_t)g * k + j, pack29(w));

@@ -410,6 +410,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // Generated (dense) randomness rows: the sampler also accumulates the message-domain halves of the code and linear tests
     // while the elements are in registers (aes.hip: k_rand_rlc) -- all of it on the side stream; the main stream only encodes.
     const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
+    static const bool early_code = [] { const char* e = std::getenv("LIG_EARLY_CODE"); return !e || std::atoi(e) != 0; }();      // (see below)
+    const lig::f29s* rc_loop = early_code ? nullptr : T->coef_dev;      // code coefficients of the row loop (null: accumulated up front)
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
@@ -423,7 +425,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
                 size_t run = 1;
                 const uint32_t d = T->rows[b + r].data;
                 while (r + run < nb && T->rows[b + r + run].data == d) run++;
-                if (fused_rlc) lig::launch_rand_rlc(s2, c->rk_dev, lpos, rb + r * k, T->msgs + (b + r) * k, run, d, k, T->coef_dev + b + r, lig_tune::GROUP / 4, p_code, p_linH);
+                if (fused_rlc) lig::launch_rand_rlc(s2, c->rk_dev, lpos, rb + r * k, T->msgs + (b + r) * k, run, d, k, rc_loop ? rc_loop + b + r : nullptr, lig_tune::GROUP / 4, p_code, p_linH);
                 else lig::launch_rng_fill_rows_dense(s2, c->rk_dev, lpos, rb + r * k, run, d, k);
                 lpos += (uint64_t)run * d; r += run;
             }
@@ -448,6 +450,25 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));            // the side stream starts after the key / coefficient uploads and the memsets above
     HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
     if (n_chunks) TRY(form_rand_chunk(0));
+    // (the side stream is already sampling the first randomness rows while the main stream does this)
+    // The code-test accumulator does not depend on the randomness rows: it is formed FIRST (one pass over the message rows, one
+    // encode, mask, download), so that the host can absorb it into the stage-2 seed hash -- 1 MiB of the 3 MiB sequential
+    // SHA-256 that is the longest host step of a proof -- while the GPU is still busy with the row loop below.
+    // LIG_EARLY_CODE=0: accumulate it inside the row loop as before (profiles/r03_early_code_ab.md).
+    fr* mask = T->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
+    uint8_t* enc = T->h_enc;
+    const size_t vec_bytes = (size_t)n * 32;
+    if (early_code) {
+        for (size_t b = 0; b < R; b += lig_tune::CHUNK) {
+            const size_t nb = std::min<size_t>(lig_tune::CHUNK, R - b);
+            lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, nullptr, 0, nb, k, T->coef_dev + b, p_code, nullptr, lig_tune::GROUP / 4);
+        }
+        lig::launch_rlc_combine(s, tmp, p_code, (uint32_t)((lig_tune::CHUNK + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4)), k);
+        TRY(lig_internal_encode_rows(c, tmp, code, 1, false));      // out of place: no device-to-device staging copy
+        lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
+        TRY(lig_internal_download(c, enc, code, vec_bytes, s));
+        HIP_TRY(c, hipEventRecord(T->ev_acc[0], s));
+    }
     for (size_t ci = 0; ci < n_chunks; ci++) {
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
@@ -462,12 +483,12 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
             lig::launch_rlc_accumulate29(s, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::DOT_GROUP);
         }
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
-        if (!fused_rlc) lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, T->coef_dev + b, p_code, p_linH, lig_tune::GROUP / 4);
+        if (!fused_rlc) lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, rc_loop ? rc_loop + b : nullptr, p_code, p_linH, lig_tune::GROUP / 4);
         HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
     {   // one combine per accumulator and proof
         const uint32_t pg = (uint32_t)((lig_tune::CHUNK + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4));
-        lig::launch_rlc_combine(s, tmp, p_code, pg, k);         // the code test's k message values (tmp was zeroed with acc)
+        if (!early_code) lig::launch_rlc_combine(s, tmp, p_code, pg, k);         // the code test's k message values (tmp was zeroed with acc)
         lig::launch_rlc_combine(s, linH, p_linH, pg, k);
         lig::launch_rlc_combine(s, linC, p_linC, (uint32_t)dot_groups, k);
     }
@@ -480,15 +501,14 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // Each accumulator is extended to the n evaluation points, masked (nonbatch_context.hpp:739-753) and sent to the host
     // as soon as it is final; the host absorbs it into the stage-2 seed hash (a sequential SHA-256 over 3 MiB, the longest
     // host step of the proof) while the GPU extends the next one.
-    fr* mask = T->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;
-    uint8_t* enc = T->h_enc;
-    const size_t vec_bytes = (size_t)n * 32;
     const H::Fr* dots = reinterpret_cast<const H::Fr*>(T->h_small);
     TRY(lig_internal_download(c, T->h_small, T->dots, 32, s));
-    TRY(lig_internal_encode_rows(c, tmp, code, 1, false));      // out of place: no device-to-device staging copy
-    lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
-    TRY(lig_internal_download(c, enc, code, vec_bytes, s));
-    HIP_TRY(c, hipEventRecord(T->ev_acc[0], s));
+    if (!early_code) {
+        TRY(lig_internal_encode_rows(c, tmp, code, 1, false));      // out of place: no device-to-device staging copy
+        lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mask, nullptr, code, n, fr{}, 0);
+        TRY(lig_internal_download(c, enc, code, vec_bytes, s));
+        HIP_TRY(c, hipEventRecord(T->ev_acc[0], s));
+    }
     TRY(lig_internal_extend_2k(c, lin));
     lig::launch_eltwise(s, LIG_OP_ADD_ASSIGN, mlin, nullptr, lin, n, fr{}, 0);
     TRY(lig_internal_download(c, enc + vec_bytes, lin, vec_bytes, s));
