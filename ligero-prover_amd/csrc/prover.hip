@@ -347,11 +347,13 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     HIP_TRY(c, hipEventRecord(c->ev_join, s_sha));
     HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
     mark("encode mask rows + column sha tail");
-    lig::launch_sha_final(s, T->sha_state, n, absorbed, T->leaves, k);       // plane-major instances -> leaves in column order
-    TRY(lig_merkle_build(c, T->leaves, n, T->nodes));
-    TRY(lig_internal_download(c, T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, s));      // root now, the rest for the decommitment (stage 3)
+    uint32_t* leaf_level = T->nodes + 8 * ((size_t)n - 1);                    // n = 4k is a power of two: the leaves ARE the last level of the heap
+    lig::launch_sha_final(s, T->sha_state, n, absorbed, leaf_level, k);      // plane-major instances -> leaves in column order, written in place
+    TRY(lig_merkle_build(c, leaf_level, n, T->nodes));
+    TRY(lig_internal_download(c, T->h_nodes, T->nodes, 32, s));              // the root now ...
     HIP_TRY(c, hipStreamSynchronize(s));
     std::memcpy(info->root, T->h_nodes, 32);
+    TRY(lig_internal_download(c, T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, s));      // ... the tree for the decommitment (stage 3) under stage 2
     Sha256().add("LigetronStage1", 15).add(info->root, 32).add(T->ih, 32).finish(info->stage1_seed);
     mark("merkle + seed");
     return LIG_OK;
@@ -556,9 +558,10 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);
     const size_t smp_bytes = (R + 3) * (size_t)t * 32;
     const EnvelopeLayout lay = write_envelope(T->h_proof, T->h_proof_cap, T->version, T->program_hash, T->generated_at, k, n, t,
-                                              info->root, sib, idx, enc, smp_bytes);
+                                              info->root, sib, idx, nullptr, smp_bytes);       // framing only: the layout is known now
     if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
-    TRY(lig_internal_download(c, T->h_proof + lay.samples_off, T->samples, smp_bytes, s));   // opened columns land in place (16-byte aligned, else the DMA path)
+    TRY(lig_internal_download(c, T->h_proof + lay.samples_off, T->samples, smp_bytes, s));   // opened columns land in place (any byte offset)
+    for (int a3 = 0; a3 < 3; a3++) std::memcpy(T->h_proof + lay.vec_off[a3], enc + (size_t)a3 * vec_bytes, vec_bytes);     // 3 MiB, under the 13 MB download
     HIP_TRY(c, hipEventSynchronize(c->ev_join));          // decoded accumulators are on the host
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
     info->valid_code = 1;

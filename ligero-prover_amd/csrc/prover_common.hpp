@@ -182,7 +182,9 @@ size_t varlen(uint64_t v) { size_t n = 1; while (v > 0x7f) { v >>= 7; n++; } ret
 // straight into a caller-provided (pinned) buffer.  The four FixedU32Vector payloads are raw little-endian limb
 // bytes: the three accumulators are copied in, the position of the sample payload is returned so that the
 // device->host copy of the opened columns lands directly inside the envelope.
-struct EnvelopeLayout { size_t total = 0, samples_off = 0; };
+// (enc3 == nullptr: the framing is written, the three accumulators are NOT copied -- vec_off says where they belong, so that
+// the caller can start the download of the opened columns first and copy them while it runs)
+struct EnvelopeLayout { size_t total = 0, samples_off = 0, vec_off[3] = {0, 0, 0}; };
 EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, const uint8_t program_hash[32], int64_t generated_at,
                               uint32_t k, uint32_t n, uint32_t t, const uint8_t root[32], const std::vector<uint8_t>& siblings,
                               const std::vector<uint32_t>& idx, const uint8_t* enc3, size_t sample_bytes) {
@@ -216,7 +218,7 @@ EnvelopeLayout write_envelope(uint8_t* dst, size_t cap, const char* version, con
         h.tag(f, 2); h.var(fixed_len(nb));
         if (nb) { h.tag(1, 2); h.var(nb); }
         put(h.b.data(), h.b.size());
-        if (f < 5) put(enc3 + (size_t)(f - 2) * vec, nb);
+        if (f < 5) { L.vec_off[f - 2] = pos; if (enc3) put(enc3 + (size_t)(f - 2) * vec, nb); else pos += nb; }
         else { L.samples_off = pos; pos += nb; }
     }
     L.total = pos;

@@ -193,15 +193,49 @@ __global__ void k_merkle_level(uint32_t* __restrict__ nodes, size_t first, size_
     out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
 }
 
+// the levels of at most 256 nodes in ONE launch: a single workgroup walks up the tree, a barrier between levels (the nodes go
+// through global memory: the writes of a level are made visible to the whole workgroup by the fence + barrier)
+__global__ void __launch_bounds__(256) k_merkle_top(uint32_t* __restrict__ nodes, uint32_t top_width) {
+    for (uint32_t width = top_width; width >= 1; width >>= 1) {
+        if (threadIdx.x < width) {
+            const size_t i = (size_t)(width - 1) + threadIdx.x;
+            const uint4* ch = reinterpret_cast<const uint4*>(nodes + 8 * (2 * i + 1));
+            uint4 q[4] = {ch[0], ch[1], ch[2], ch[3]};
+            uint32_t w[16] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+                              q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) w[k] = __builtin_bswap32(w[k]);
+            uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+            sha256_compress(h, w);
+#pragma unroll
+            for (int k = 0; k < 16; k++) w[k] = 0;
+            w[0] = 0x80000000u;
+            w[15] = 512;
+            sha256_compress(h, w);
+            uint4* out = reinterpret_cast<uint4*>(nodes + 8 * i);
+            out[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+            out[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+// `leaves` may already BE the leaf level of `nodes` (nodes + 8 * (P - 1), P = bit_ceil(n_leaves)): then nothing is copied
 void launch_merkle_build(hipStream_t s, const uint32_t* leaves, size_t n_leaves, uint32_t* nodes) {
     size_t P = 1;
     while (P < n_leaves) P <<= 1;
-    (void)hipMemsetAsync(nodes, 0, 32 * (2 * P - 1), s);
-    (void)hipMemcpyAsync(nodes + 8 * (P - 1), leaves, 32 * n_leaves, hipMemcpyDeviceToDevice, s);
-    for (size_t width = P / 2; width >= 1; width /= 2) {
+    const bool in_place = leaves == nodes + 8 * (P - 1);
+    if (!in_place || n_leaves < P) {
+        if (n_leaves < P) (void)hipMemsetAsync(nodes + 8 * (P - 1 + n_leaves), 0, 32 * (P - n_leaves), s);      // missing leaves = zero digests
+        if (!in_place) (void)hipMemcpyAsync(nodes + 8 * (P - 1), leaves, 32 * n_leaves, hipMemcpyDeviceToDevice, s);
+    }
+    size_t width = P / 2;
+    for (; width > 256; width /= 2) {
         const size_t first = width - 1;
         hipLaunchKernelGGL(k_merkle_level, dim3((uint32_t)((width + 63) / 64)), dim3(64), 0, s, nodes, first, width);
     }
+    if (width >= 1) hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, s, nodes, (uint32_t)width);
 }
 
 }  // namespace lig
