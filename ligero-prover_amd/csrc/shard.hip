@@ -379,8 +379,9 @@ static int shard_stage1(lig_shard* S, lig_proof_info* info) {
         HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     }
     lig::launch_sha_final(s, S->sha_state, ncol, absorbed, S->leaves_slice, (uint32_t)kq);      // plane-major instances -> the rank's leaves in column order
-    TRY(all_gather(S->leaves_slice, S->leaves, ncol * 32, s, "all_gather(leaves)"));
-    TRY(lig_merkle_build(c, S->leaves, n, S->nodes));
+    uint32_t* leaf_level = S->nodes + 8 * ((size_t)n - 1);         // the gathered leaves ARE the last level of the node heap (n is a power of two)
+    TRY(all_gather(S->leaves_slice, leaf_level, ncol * 32, s, "all_gather(leaves)"));
+    TRY(lig_merkle_build(c, leaf_level, n, S->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     Sha256().add("LigetronStage1", 15).add(info->root, 32).add(S->ih, 32).finish(info->stage1_seed);
