@@ -51,7 +51,16 @@ public:
     }
     hip_row_batcher(const hip_row_batcher&) = delete;
     hip_row_batcher& operator=(const hip_row_batcher&) = delete;
-    ~hip_row_batcher() { if (trace_) lig_trace_destroy(trace_); }
+    ~hip_row_batcher() { if (trace_) lig_trace_destroy(trace_); if (shard_) lig_shard_destroy(shard_); }
+
+    // ONE trace over the GPUs of a node (configs[4]: the guest's rows on 8 GPUs): every rank runs the same guest, so every rank's
+    // callbacks see all rows; after pass 1 the batcher keeps the rows of its own chunks (lig_shard_rows_plan), in pass 2 the
+    // randomness rows of those.  Call before commit(); `comm` from lig_rccl_comm_create (or lig_ipc_comm_create) must outlive
+    // the batcher.  Every rank's prove() returns the same envelope as an unsharded batcher would.
+    void shard_over(uint32_t rank, uint32_t world, const lig_comm* comm) {
+        if (pass_ != 1 || !comm || !world || rank >= world) throw std::invalid_argument("hip_row_batcher::shard_over");
+        sharded_ = true; rank_ = rank; world_ = world; comm_ = *comm;
+    }
 
     // ---- the callbacks of nonbatch_context_base (nonbatch_context.hpp:78-86).  `rand` rows are null in pass 1.
     void linear_callback(const uint64_t* val, const uint64_t* rand = nullptr) { row(LIG_ROW_LINEAR, val, rand); }
@@ -93,6 +102,7 @@ public:
         job.kinds = kinds_.data();
         job.msgs = rows_.data();
         job.msgs_on_device = 0;
+        if (sharded_) { commit_sharded(job, args, lens, root, stage1_seed); return; }
         std::vector<uint8_t> widths, packed;
         if (meta_.narrow_rows) {
             const size_t R = kinds_.size(), words = (size_t)k_ * 4;
@@ -143,13 +153,42 @@ public:
         if (next_ != kinds_.size()) throw std::logic_error("hip_row_batcher::prove: pass 2 replayed " + std::to_string(next_) + " of " + std::to_string(kinds_.size()) + " rows");
         const uint8_t* proof = nullptr;
         lig_proof_info local;
-        check(lig_rows_prove(trace_, rands_.data(), 0, const_sum, &proof, proof_len, info ? info : &local), "lig_rows_prove");
+        if (sharded_) check(lig_shard_rows_prove(shard_, rands_.data(), 0, const_sum, &proof, proof_len, info ? info : &local), "lig_shard_rows_prove");
+        else check(lig_rows_prove(trace_, rands_.data(), 0, const_sum, &proof, proof_len, info ? info : &local), "lig_rows_prove");
         pass_ = 3;
         return proof;
     }
     size_t rows() const { return kinds_.size(); }
+    size_t local_rows() const { return sharded_ ? n_local_ : kinds_.size(); }
 
 private:
+    void commit_sharded(lig_rows_job& job, const std::vector<uint8_t>& args, const std::vector<uint64_t>& lens, uint8_t root[32], uint8_t stage1_seed[32]) {
+        const size_t R = kinds_.size(), words = (size_t)k_ * 4;
+        uint64_t rounds = 0;
+        std::vector<uint64_t> b((size_t)world_ * ((R + 511) / 512 + 2) + 2);
+        if (lig_shard_rows_plan(kinds_.data(), R, world_, &rounds, b.data(), b.size()) != LIG_OK) throw std::runtime_error("lig_shard_rows_plan failed");
+        local_of_.assign(R, (size_t)-1);
+        std::vector<uint64_t> local;
+        n_local_ = 0;
+        for (uint64_t g = rank_; g < rounds * world_; g += world_)
+            for (uint64_t r = b[g]; r < b[g + 1]; r++) {
+                local_of_[r] = n_local_++;
+                local.insert(local.end(), rows_.begin() + r * words, rows_.begin() + (r + 1) * words);
+            }
+        job.msgs = local.empty() ? nullptr : local.data();
+        std::memcpy(job.encoding_seed, meta_.encoding_seed, 32);
+        std::memcpy(job.program_hash, meta_.program_hash, 32);
+        job.generated_at = meta_.generated_at;
+        std::strncpy(job.version, meta_.version.c_str(), sizeof job.version - 1);
+        job.public_args = args.empty() ? nullptr : args.data();
+        job.public_arg_lens = lens.empty() ? nullptr : lens.data();
+        job.n_public_args = lens.size();
+        check(lig_shard_rows_begin(ctx_, &job, rank_, world_, &comm_, &shard_), "lig_shard_rows_begin");
+        check(lig_shard_rows_commit(shard_, root, stage1_seed), "lig_shard_rows_commit");
+        rows_.clear(); rows_.shrink_to_fit();
+        rands_.assign((n_local_ ? n_local_ : 1) * words, 0);
+        pass_ = 2; next_ = 0; enc_pos_ = 0;
+    }
     void check(int rc, const char* what) const {
         if (rc != LIG_OK) throw std::runtime_error(std::string(what) + ": " + lig_last_error(ctx_));
     }
@@ -165,7 +204,8 @@ private:
         } else if (pass_ == 2) {
             // the guest is deterministic: pass 2 must replay the callbacks of pass 1 in the same order
             if (next_ >= kinds_.size() || kinds_[next_] != kind) throw std::logic_error("hip_row_batcher: pass 2 diverges from pass 1");
-            if (rand) std::memcpy(rands_.data() + next_ * words, rand, words * 8);
+            const size_t slot = sharded_ ? local_of_[next_] : next_;                 // sharded: only the randomness rows of this rank's rows are kept
+            if (rand && slot != (size_t)-1) std::memcpy(rands_.data() + slot * words, rand, words * 8);
             next_++;
         } else throw std::logic_error("hip_row_batcher: callback after prove");
     }
@@ -188,6 +228,12 @@ private:
     std::vector<uint8_t> kinds_;
     std::vector<uint64_t> rows_, rands_;
     lig_trace* trace_ = nullptr;
+    bool sharded_ = false;
+    uint32_t rank_ = 0, world_ = 1;
+    lig_comm comm_{};
+    lig_shard* shard_ = nullptr;
+    std::vector<size_t> local_of_;
+    size_t n_local_ = 0;
 };
 
 // The verifier's counterpart (src/webgpu_verifier.cpp:263-452 with nonbatch_verifier_context, nonbatch_context.hpp:1081-1388):

@@ -138,3 +138,37 @@ def test_row_batcher_batch_hooks_give_the_oracle_envelope(n_lin, n_quad, with_bi
     (the shim used to commit init rows without their pads)"""
     out = subprocess.check_output([build_batch_batcher_exe(), str(n_lin), str(n_quad), str(with_bits), str(k)]).decode()
     assert out.startswith("equal 1 "), out
+
+
+SBSRC = os.path.join(ROOT, "tests", "cpp", "sharded_batcher_prog.cpp")
+SBEXE = os.path.join(ROOT, "tests", "cpp", "sharded_batcher_prog")
+
+
+def build_sharded_batcher_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    odir = os.path.join(ROOT, "oracle")
+    ol.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", SBSRC, "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip", "-L" + odir, "-llig_oracle",
+                           "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-Wl,-rpath," + odir, "-o", SBEXE])
+    return SBEXE
+
+
+def test_sharded_row_batcher_compiles_and_links():
+    assert os.path.exists(build_sharded_batcher_exe())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_lin,n_quad", [(2, 2000, 900), (4, 320 * 1100 + 3, 330)])
+def test_sharded_row_batcher_gives_the_oracle_envelope_on_every_rank(world, n_lin, n_quad):
+    """hip_row_batcher::shard_over: the same guest on `world` ranks (processes on the one GPU, comm_ipc), each keeping the rows of its
+    chunks; every rank's envelope is the oracle's -- the backend side of configs[4] (one guest trace on the GPUs of a node)"""
+    exe = build_sharded_batcher_exe()
+    name = "/lig_sb_%d_%d" % (os.getpid(), world)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(r), str(world), name, str(n_lin), str(n_quad)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(world)]
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0 and ("rank %d: equal 1 " % r) in o.decode(), (o.decode(), e.decode()[-2000:])
