@@ -81,3 +81,19 @@ def test_proof_file_gzip_framing_roundtrip_with_python_gzip():
     assert lib.lig_proof_gunzip(tsrc, len(theirs), small, 10, C.byref(n)) != 0
     assert lib.lig_proof_gunzip(src, len(env), back, len(env), C.byref(n)) != 0
     assert lib.lig_proof_gunzip_size(src, len(env)) == 0
+
+
+def test_rccl_is_resolved_lazily_and_only_once():
+    """liblig_hip.so has no link-time dependency on librccl: the host-only helpers work in a process that never touches
+    RCCL, and lig_rccl_available reports which copy the first lig_rccl_* call would use -- the one already mapped into the
+    process if there is one (torch brings its own), so that one process never holds two different RCCL builds"""
+    import subprocess, sys
+    lib = os.path.join(ROOT, "ligero-prover_amd", "liblig_hip.so")
+    needed = subprocess.check_output(["readelf", "-d", lib]).decode()
+    assert "librccl" not in needed, "librccl must not be a DT_NEEDED entry"
+    code = ("import sys; sys.path.insert(0, %r); import hip_lib; m = hip_lib.load(); ok, path, ver = m.rccl_available(); print(ok, path, ver)"
+            % os.path.join(ROOT, "tests"))
+    plain = subprocess.check_output([sys.executable, "-c", code]).decode().split()
+    with_torch = subprocess.check_output([sys.executable, "-c", "import torch; " + code]).decode().split()
+    assert plain[0] == "True" and with_torch[0] == "True"
+    assert "torch" in with_torch[1], "inside a torch process the copy torch mapped must win: %r" % (with_torch,)
