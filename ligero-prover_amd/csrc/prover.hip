@@ -65,6 +65,7 @@ struct lig_trace {
     uint32_t up_seq = 0;
     bool up_by_thread = false;
     std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
+    std::atomic<int> up_failed{0};      // hipError_t of a chunk copy that failed (the chunk is published all the same: no stream may hang)
     // narrow row format (lig_rows_job.elem_bytes): packed byte offset of every row (+1 entry), the widths, the device staging
     // area the packed rows are uploaded to (expanded into `msgs` chunk by chunk in stage 1)
     bool narrow = false;
@@ -352,6 +353,10 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     TRY(lig_merkle_build(c, leaf_level, n, T->nodes));
     TRY(lig_internal_download(c, T->h_nodes, T->nodes, 32, s));              // the root now ...
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (streamed && T->up_by_thread) {
+        // every chunk has been waited for by now; a copy the uploader thread could not make leaves garbage rows behind
+        if (const int e = T->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("rows upload failed: ") + hipGetErrorString((hipError_t)e));
+    }
     std::memcpy(info->root, T->h_nodes, 32);
     TRY(lig_internal_download(c, T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, s));      // ... the tree for the decommitment (stage 3) under stage 2
     Sha256().add("LigetronStage1", 15).add(info->root, 32).add(T->ih, 32).finish(info->stage1_seed);
@@ -693,7 +698,7 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
 // trace waits for that word with a stream memory operation (hipStreamWaitValue32 -- a wait in ITS OWN queue, where it has to
 // wait anyway).  Uploads of all contexts go through the one thread: one at a time, in the order of the calls -- two contexts
 // that alternate keep the link busy without ever sharing it.
-struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; };
+struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed; };
 namespace {
 struct Uploader {
     std::mutex mu;
@@ -715,8 +720,8 @@ struct Uploader {
             }
             const hipError_t e = j.first.bytes ? hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st) : hipSuccess;
             const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
-            // (a failed copy publishes too: the prover must not hang; the rows are then wrong and the self-check / verifier says so)
-            (void)e2;
+            // (a failed copy publishes too: no stream may hang on the flag; lig_rows_commit reports the error once stage 1 has drained)
+            if (e2 != hipSuccess) { (void)hipGetLastError(); j.first.failed->store((int)e2, std::memory_order_release); }
             __atomic_store_n(j.first.flag, j.first.seq, __ATOMIC_RELEASE);
             j.second->fetch_sub(1, std::memory_order_acq_rel);
         }
@@ -800,7 +805,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         for (size_t ci = 0; ci < T->sched1.size(); ci++) {
             const size_t b = T->sched1[ci].first, e = T->sched1[ci].second;
             const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
-            jobs.push_back(UploadJob{up_dst + off, T->host_msgs + off, bytes, T->up_flag + ci, T->up_seq});
+            jobs.push_back(UploadJob{up_dst + off, T->host_msgs + off, bytes, T->up_flag + ci, T->up_seq, &T->up_failed});
         }
         uploader_submit(c->device, jobs, &T->up_pending);
         T->up_by_thread = true;
