@@ -283,6 +283,8 @@ typedef struct lig_vtrace lig_vtrace;
 int lig_rows_verify_begin(lig_ctx *ctx, const lig_rows_job *job, const uint8_t *proof, size_t proof_len, lig_vtrace **trace,
                           uint8_t stage1_seed[32], lig_verify_info *out);
 int lig_rows_verify_finish(lig_vtrace *trace, const void *rands, int rands_on_device, const uint8_t const_sum[32], lig_verify_info *out);
+/* a verifier that gives up between begin and finish (its constraint generator threw) frees the trace here; NULL is a no-op */
+void lig_vtrace_destroy(lig_vtrace *trace);
 /* rows x k dense randomness rows on the device: row r = per_row[r] successive elements of the AES-256-CTR field stream
  * keyed by key32 (row r starts where row r-1 ended, the first at first_elem), zeros up to k -- the linear-test
  * coefficient rows of the synthetic stream, for callers that feed lig_rows_prove from the device. */

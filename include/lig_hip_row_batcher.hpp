@@ -247,6 +247,7 @@ public:
     }
     hip_row_verifier(const hip_row_verifier&) = delete;
     hip_row_verifier& operator=(const hip_row_verifier&) = delete;
+    ~hip_row_verifier() { lig_vtrace_destroy(vt_); }          // begin without finish (the guest threw)
 
     // the row kinds of the public constraint stream, in commit order (a dry run of the guest, or the prover's kinds)
     void expect_rows(const std::vector<uint8_t>& kinds) { kinds_ = kinds; }

@@ -31,7 +31,7 @@ EXPORTS = [
     "lig_shard_prepare", "lig_shard_prove", "lig_shard_destroy", "lig_synth_verify", "lig_verify_release",
     "lig_proof_gzip_bound", "lig_proof_gzip", "lig_proof_gunzip_size", "lig_proof_gunzip",
     "lig_rows_begin", "lig_rows_commit", "lig_rows_prove", "lig_rows_restart", "lig_rng_fill_rows",
-    "lig_rows_verify_begin", "lig_rows_verify_finish",
+    "lig_rows_verify_begin", "lig_rows_verify_finish", "lig_vtrace_destroy",
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
@@ -177,6 +177,8 @@ def load_library():
     L.lig_rows_restart.argtypes = [vp, vp, C.c_int]
     L.lig_rows_verify_begin.argtypes = [vp, C.POINTER(RowsJob), vp, sz, C.POINTER(vp), vp, C.POINTER(VerifyInfo)]
     L.lig_rows_verify_finish.argtypes = [vp, vp, C.c_int, vp, C.POINTER(VerifyInfo)]
+    L.lig_vtrace_destroy.argtypes = [vp]
+    L.lig_vtrace_destroy.restype = None
     L.lig_rows_prove.argtypes = [vp, vp, C.c_int, vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(sz), C.POINTER(ProofInfo)]
     L.lig_rng_fill_rows.argtypes = [vp, vp, u64, vp, sz, vp]
     L.lig_public_arg_bytes.argtypes = [C.c_int, C.c_char_p, vp, sz, C.POINTER(sz)]
@@ -639,6 +641,10 @@ class Context:
             rp = C.c_void_p(rands.ctypes.data if rands.size else None)
         self.check(self.L.lig_rows_verify_finish(vtrace, rp, int(bool(on_device)), _hptr(cs), C.byref(info)))
         return info
+
+    def vtrace_destroy(self, vtrace):
+        """give up a verification between begin and finish (finish frees the trace itself)"""
+        self.L.lig_vtrace_destroy(vtrace)
 
     def rng_fill_rows(self, key, first_elem, per_row, out):
         k = np.frombuffer(bytes(key), dtype=np.uint8).copy()

@@ -403,4 +403,6 @@ int lig_rows_verify_finish(lig_vtrace* V, const void* rands, int rands_on_device
     return rc;
 }
 
+void lig_vtrace_destroy(lig_vtrace* V) { delete V; }
+
 }  // extern "C"

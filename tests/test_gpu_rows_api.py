@@ -112,6 +112,9 @@ def test_rows_entry_equals_oracle(amd, l, k, n, n_linear, n_quad, prog, pub, mod
             other_rands[0, 0, 0] ^= 1                            # another public constraint stream
             vt, _, _ = c.rows_verify_begin(ol.row_kinds(job), proof, public_args=pub)
             assert c.rows_verify_finish(vt, other_rands, const_sum).accept == 0
+            vt, _, _ = c.rows_verify_begin(ol.row_kinds(job), proof, public_args=pub)
+            c.vtrace_destroy(vt)                                 # a verifier that gives up between begin and finish
+            c.vtrace_destroy(None)
         # both verifiers accept it, deriving the constant from the public statement themselves
         hjob = amd.Context.make_job(n_linear, n_quad, generated_at=77, public_args=pub)
         if prog:
