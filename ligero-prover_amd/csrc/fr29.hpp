@@ -150,11 +150,46 @@ __device__ __forceinline__ f29 f29_mulw(const f29& a, const f29wv& W) {
 #include "fr29_mulw_gen.hpp"         // 12 columns, one chained v_mad_u64_u32 block each (tools/gen_fr29_mulw.py)
     return t;
 }
+// A windowed constant that is the SAME for every lane (the radix-8 constants): held in scalar registers.  The entry index must
+// be uniform; the words come through scalar loads (uniform address, read-only table) and enter the multiplies as SGPR operands
+// -- no vector registers, no vector memory instruction, no wait on the vector memory counter in front of the product.
+struct f29ws {
+    uint32_t v[28];
+};
+__device__ __forceinline__ f29ws f29_load_ws(const f29wt p) {
+    // constant address space + uniform address = s_load_dwordx4 (the tables are never written while a kernel runs)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef const v4u __attribute__((address_space(4))) * cptr;
+    f29ws r;
+    const cptr b = (cptr)(uintptr_t)(p.base + p.idx);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const v4u x = b[(size_t)i * p.stride];
+        r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
+    }
+    return r;
+}
+__device__ __forceinline__ f29 f29_mulw(const f29& a, const f29ws& W) {
+    uint32_t m[4];
+    f29 t;
+    uint64_t acc = 0;
+    const uint32_t p0 = f29_p0_opaque();
+#include "fr29_mulw_s_gen.hpp"       // the same 12 columns with the constant's words as scalar operands (gen_fr29_mulw.py --uniform)
+    return t;
+}
 // uniform access to both table formats (tile_dft.hpp is shared by kernels on either)
 __device__ __forceinline__ f29 tab_get(const f29s* p) { return f29_load_tab(p); }
 __device__ __forceinline__ f29wv tab_get(const f29wt p) { return f29_load_w(p); }
 __device__ __forceinline__ f29 tab_mul(const f29& a, const f29& w) { return f29_montmul(a, w); }
 __device__ __forceinline__ f29 tab_mul(const f29& a, const f29wv& w) { return f29_mulw(a, w); }
+__device__ __forceinline__ f29 tab_mul(const f29& a, const f29ws& w) { return f29_mulw(a, w); }
+// a table entry whose index is the same for every lane
+__device__ __forceinline__ f29 tab_get_uniform(const f29s* p) { return f29_load_tab(p); }
+#ifdef LIG_NO_UNIFORM_CONSTS      // A/B: the radix-8 constants through vector loads into vector registers, as before round 3
+__device__ __forceinline__ f29wv tab_get_uniform(const f29wt p) { return f29_load_w(p); }
+#else
+__device__ __forceinline__ f29ws tab_get_uniform(const f29wt p) { return f29_load_ws(p); }
+#endif
 
 // limb-wise lazy add
 __device__ __forceinline__ f29 f29_add(const f29& a, const f29& b) {

@@ -14,7 +14,7 @@ __device__ __forceinline__ constexpr int brev3(int p) { return ((p & 1) << 2) | 
 template <class TW>
 __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const TW w8) {
     f29 t, u;
-    const auto w2 = tab_get(w8 + 2);
+    const auto w2 = tab_get_uniform(w8 + 2);
     // span 2, twiddle 1.  u: limbs < 2^30, < 6p.  v = x - y + 4p: limbs < 2^31, < 7p.
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
@@ -37,9 +37,9 @@ __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const TW w8) {
     for (int i = 0; i < 8; i++) a[i] = f29_qnorm(a[i]);
     // span 8.  pair (0,4): twiddle 1, subtrahend limbs < 2^29+8, < 12p -> + 16p.  others: w, w^2, w^3.
     u = f29_add(a[0], a[4]); a[4] = f29_sub_k16(a[0], a[4]); a[0] = u;                 // < 24p | limbs < 2^31+8, < 28p
-    t = tab_mul(a[5], tab_get(w8 + 1)); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
+    t = tab_mul(a[5], tab_get_uniform(w8 + 1)); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
     t = tab_mul(a[6], w2); u = f29_add(a[2], t); a[6] = f29_sub_k2(a[2], t); a[2] = u;
-    t = tab_mul(a[7], tab_get(w8 + 3)); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
+    t = tab_mul(a[7], tab_get_uniform(w8 + 3)); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
 }
 
 // ---------------------------------------------------------------------------------------------------- tile transform

@@ -12,9 +12,10 @@ def _gen(script, *args):
 
 
 def test_generated_headers_are_current():
-    for script, header in (("gen_fr29_mulw.py", "fr29_mulw_gen.hpp"), ("gen_fr29_montmul.py", "fr29_montmul_gen.hpp")):
+    for script, args, header in (("gen_fr29_mulw.py", (), "fr29_mulw_gen.hpp"), ("gen_fr29_mulw.py", ("--uniform",), "fr29_mulw_s_gen.hpp"),
+                                 ("gen_fr29_montmul.py", (), "fr29_montmul_gen.hpp")):
         with open(os.path.join(ROOT, "ligero-prover_amd", "csrc", header)) as f:
-            assert f.read() == _gen(script), header
+            assert f.read() == _gen(script, *args), header
 
 
 def test_windowed_product_is_exact_and_fits_64_bit_columns():
