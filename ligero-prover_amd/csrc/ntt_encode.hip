@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict_
         f29 a[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
-        radix8_dit(a, w8);                                                 // limbs < 2^31 + 8, value < 28p
+        radix8_dit<false>(a, w8);                                                 // limbs < 2^31 + 8, value < 28p
 #pragma unroll
         for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_add(acc[q1], f29_montmul(a[q1], unpack29(fr_load(u + (size_t)B * q1))));   // each term < 1.2p
         if (++since == 6) {

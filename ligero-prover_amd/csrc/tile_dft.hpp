@@ -11,10 +11,14 @@ __device__ __forceinline__ constexpr int brev3(int p) { return ((p & 1) << 2) | 
 // Radix-8 DIT butterfly in registers.  In: a[p] = input number brev3(p), normalised limbs, value < 3p.
 // Out: a[j] = sum_i in[i] * w^(i*j), lazy (limbs < 2^31 + 8, value < 28p).  w8[1..3] = w, w^2, w^3 (either table format; the
 // entries are uniform, so their loads are broadcasts).
-template <class TW>
+// SCALAR: the three constants as scalar operands (s_load + SGPR source, fr29.hpp: f29ws) -- for straight-line kernels (K1, K3);
+// a kernel that runs the butterfly in a loop keeps them in vector registers instead, loaded once (81 SGPRs do not stay live
+// next to the loop's own, and re-loading them per iteration costs more than it saves: k_encode_out_dot 76 -> 108 us).
+template <bool SCALAR = true, class TW>
 __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const TW w8) {
     f29 t, u;
-    const auto w2 = tab_get_uniform(w8 + 2);
+    auto konst = [](const TW p) { if constexpr (SCALAR) return tab_get_uniform(p); else return tab_get(p); };
+    const auto w2 = konst(w8 + 2);
     // span 2, twiddle 1.  u: limbs < 2^30, < 6p.  v = x - y + 4p: limbs < 2^31, < 7p.
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
@@ -37,9 +41,9 @@ __device__ __forceinline__ void radix8_dit(f29 (&a)[8], const TW w8) {
     for (int i = 0; i < 8; i++) a[i] = f29_qnorm(a[i]);
     // span 8.  pair (0,4): twiddle 1, subtrahend limbs < 2^29+8, < 12p -> + 16p.  others: w, w^2, w^3.
     u = f29_add(a[0], a[4]); a[4] = f29_sub_k16(a[0], a[4]); a[0] = u;                 // < 24p | limbs < 2^31+8, < 28p
-    t = tab_mul(a[5], tab_get_uniform(w8 + 1)); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
+    t = tab_mul(a[5], konst(w8 + 1)); u = f29_add(a[1], t); a[5] = f29_sub_k2(a[1], t); a[1] = u;
     t = tab_mul(a[6], w2); u = f29_add(a[2], t); a[6] = f29_sub_k2(a[2], t); a[2] = u;
-    t = tab_mul(a[7], tab_get_uniform(w8 + 3)); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
+    t = tab_mul(a[7], konst(w8 + 3)); u = f29_add(a[3], t); a[7] = f29_sub_k2(a[3], t); a[3] = u;
 }
 
 // ---------------------------------------------------------------------------------------------------- tile transform
