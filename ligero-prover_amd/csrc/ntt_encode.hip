@@ -223,7 +223,9 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     constexpr uint32_t B = 1u << LOG2B;
     const size_t th1 = rows * B;
     static const int kmask = [] { const char* e = std::getenv("LIG_ENCODE_KMASK"); return e ? std::atoi(e) : 15; }();   // experiments only: 1 = K1, 6 = K2, 8 = K3
-    if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + 255) / 256)), dim3(256), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
+    // K1 / K3 have no LDS and no barrier: their workgroup size is free (LIG_K13_BLOCK, experiments)
+    static const uint32_t bs13 = [] { const char* e = std::getenv("LIG_K13_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128) ? (uint32_t)v : 256u; }();
+    if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + bs13 - 1) / bs13)), dim3(bs13), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     if (ev0) (void)hipEventRecord(ev0, s);
     if (kmask & 6) {
         if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
@@ -238,10 +240,10 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
         return;
     }
     const size_t th3 = rows * B * (mode == 0 ? 4 : mode == 1 ? 1 : 3);
-    const dim3 g3((uint32_t)((th3 + 255) / 256));
-    if (mode == 0) hipLaunchKernelGGL((k_encode_out<LOG2B, 0>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
-    else if (mode == 1) hipLaunchKernelGGL((k_encode_out<LOG2B, 1>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
-    else hipLaunchKernelGGL((k_encode_out<LOG2B, 2>), g3, dim3(256), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    const dim3 g3((uint32_t)((th3 + bs13 - 1) / bs13));
+    if (mode == 0) hipLaunchKernelGGL((k_encode_out<LOG2B, 0>), g3, dim3(bs13), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    else if (mode == 1) hipLaunchKernelGGL((k_encode_out<LOG2B, 1>), g3, dim3(bs13), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+    else hipLaunchKernelGGL((k_encode_out<LOG2B, 2>), g3, dim3(bs13), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
 }
 
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
