@@ -228,8 +228,11 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + bs13 - 1) / bs13)), dim3(bs13), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     if (ev0) (void)hipEventRecord(ev0, s);
     if (kmask & 6) {
-        if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
-        else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), 0, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+        // LIG_K2_DYN_LDS (experiments): unused dynamic LDS per workgroup, to lower the tile kernel's workgroups per CU below what its
+        // registers allow (3) and leave room for the waves of the other stream's kernels
+        static const uint32_t dyn = [] { const char* e = std::getenv("LIG_K2_DYN_LDS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+        if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+        else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
     }
     if (ev1) (void)hipEventRecord(ev1, s);
     if (!(kmask & 8)) return;
