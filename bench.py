@@ -686,15 +686,17 @@ def main():
         }
         # the roof this kernel actually runs against: issue slots of v_mad_u64_u32.  Work per encoded row: 8 tiles x 1024 elements, an
         # inverse + three forward tile transforms with their twists and seams = ~185k windowed products of 117 v_mad_u64_u32 + 4
-        # v_mul_lo_u32 (DESIGN.md sections 2 and 4); peak: one wave64 multiply per SIMD per 5.4 cycles (measured issue rate,
-        # profiles/r01_ubench_valu_issue_rates.txt), 1024 SIMDs, 2.4 GHz.  Informational: the contract's roofline object above is the HBM one.
+        # v_mul_lo_u32 (DESIGN.md sections 2 and 4; the kernel's ISA: 10,796 multiplies per wave x 32 waves per row); peak: the MEASURED
+        # chip-wide rate of independent v_mad_u64_u32 with 4 waves per SIMD (profiles/r01_ubench_valu_issue_rates.txt: 32.4e12 lane-multiplies/s
+        # = one wave64 multiply per SIMD per ~4.6 cycles at the 2.3 GHz the chip holds).  Informational: the contract's roofline object above is the HBM one.
         mads_per_row = 185000.0 * 121
-        peak_mads = 1024 * 64 / 5.4 * 2.4e9
+        peak_mads = 32.4e12
         if launches:
             out["roofline"]["valu_multiplier"] = {"achieved_mads_per_s": rows_per_launch * mads_per_row / max(avg_launch_s, 1e-12), "peak_mads_per_s": peak_mads,
                                                   "frac": rows_per_launch * mads_per_row / max(avg_launch_s, 1e-12) / peak_mads,
-                                                  "how": "185k products/row x 121 multiplies / in-run average launch time of k_encode_tiles, against 1024 SIMDs x 64 lanes / "
-                                                         "5.4 cycles x 2.4 GHz; the other ~45 % of the kernel's instructions (limb adds, masks, shifts, LDS exchanges) share the same issue slots"}
+                                                  "how": "185k products/row x 121 multiplies / in-run average launch time of k_encode_tiles, against the measured chip-wide "
+                                                         "v_mad_u64_u32 rate (32.4e12/s, profiles/r01_ubench_valu_issue_rates.txt); the other 46 % of the kernel's instructions "
+                                                         "(limb adds, masks, shifts, LDS exchanges: a third of its issue time) share the same issue slots"}
         if a.workload != "encode":
             # whole-proof algorithmic bytes (4*k*32 + 192*32 = 1,054,720 B per committed row) over the wall time
             e2e = 1054720.0 * (wl.rows + 3) * (total_constraints / wl.constraints_per_trace if hasattr(wl, "constraints_per_trace") else a.steps) / dt / 1e9
@@ -708,6 +710,18 @@ def main():
                                                        "a committed measurement of this build, not taken in this run)")
         except (OSError, ValueError):
             pass
+        if a.workload == "full":
+            # chip-wide: the VALU issue time ONE proof needs (sum over all its launches of stand-alone duration x VALUBusy, a committed PMC
+            # pass of this build: tools/valu_budget.sh) against the time the bench takes per proof -- the fraction of issue slots in use
+            try:
+                with open(os.path.join(ROOT, "profiles", "r03_valu_budget.json")) as f:
+                    busy_ms = json.load(f)["valu_busy_ms_per_proof"]
+                ms_per_proof = 1e3 * dt / a.steps / max(1, getattr(wl, "inflight", 1))
+                out["roofline"]["valu_issue"] = {"busy_ms_per_proof": busy_ms, "measured_ms_per_proof": ms_per_proof, "frac": busy_ms / ms_per_proof,
+                                                 "source": "profiles/r03_valu_budget.json (rocprofv3 --pmc VALUBusy --kernel-trace over full proofs of this build; "
+                                                           "a committed measurement, not taken in this run), see profiles/r03_valu_budget.md"}
+            except (OSError, ValueError, KeyError):
+                pass
         out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the bench contract of this repo: the PCIe-inclusive rate "
                                    "is never `value`); SURVEY 8(d)'s H2D-inclusive figure is value_incl_h2d, measured in the same run")
         if incl is not None:
