@@ -208,7 +208,11 @@ int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t byt
     return 0;
 }
 
-int a2a_on(void* user, const void* send, void* recv, size_t block, void* stream) { return collective_on(static_cast<IpcComm*>(user), 0, send, recv, block, static_cast<hipStream_t>(stream)); }
+int a2a_on(void* user, const void* send, void* recv, size_t block, void* stream) {
+    IpcComm* r = static_cast<IpcComm*>(user);
+    if (lig_internal_comm_fault(r->ctx, true)) return 1;
+    return collective_on(r, 0, send, recv, block, static_cast<hipStream_t>(stream));
+}
 int ag_on(void* user, const void* send, void* recv, size_t bytes, void* stream) { return collective_on(static_cast<IpcComm*>(user), 1, send, recv, bytes, static_cast<hipStream_t>(stream)); }
 // the caller is about to free device buffers it has used as send buffers
 // Collective on the host (every rank calls it at the same point of the program, lig_shard_destroy): the caller's streams are
@@ -231,7 +235,7 @@ void forget(void* user) {
 }
 int a2a_sync(void* user, const void* send, void* recv, size_t block) {
     IpcComm* r = static_cast<IpcComm*>(user);
-    if (!r->ctx || a2a_on(user, send, recv, block, r->ctx->stream)) return 1;
+    if (!r->ctx || lig_internal_comm_fault(r->ctx, false) || collective_on(r, 0, send, recv, block, r->ctx->stream)) return 1;
     return hipStreamSynchronize(r->ctx->stream) == hipSuccess ? 0 : 1;
 }
 int ag_sync(void* user, const void* send, void* recv, size_t bytes) {

@@ -47,8 +47,8 @@ RcclApi& api() {
     std::call_once(once, [] {
         // 1. LIG_RCCL_LIB (explicit), 2. whatever librccl.so.1 is already mapped (RTLD_NOLOAD matches by SONAME: torch's copy
         // in a torch process), 3. the loader's search path, 4. the ROCm install
-        const char* env = std::getenv("LIG_RCCL_LIB");
-        if (env && *env) a.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        const std::string& env = lig::knobs().rccl_lib;
+        if (!env.empty()) a.handle = dlopen(env.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!a.handle) a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
         if (!a.handle) a.handle = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
         if (!a.handle) a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -71,6 +71,7 @@ struct RcclComm {
     ncclComm_t comm = nullptr;
     lig_ctx* ctx = nullptr;                 // cleared by lig_ctx_destroy (lig_internal_comms_release): the context may die first
     uint32_t rank = 0, world = 1;
+    bool in_sync = false;                   // a2a_sync is running a2a_on (fault injection tells the two forms apart)
 };
 
 int fail(RcclComm* r, const char* what, ncclResult_t e) {
@@ -81,6 +82,7 @@ int fail(RcclComm* r, const char* what, ncclResult_t e) {
 int a2a_on(void* user, const void* send, void* recv, size_t block, void* stream) {
     RcclComm* r = static_cast<RcclComm*>(user);
     if (!r->comm) return 1;
+    if (!r->in_sync && lig_internal_comm_fault(r->ctx, true)) return 1;
     RcclApi& A = api();
     hipStream_t st = static_cast<hipStream_t>(stream);
     ncclResult_t e = A.GroupStart();
@@ -103,7 +105,11 @@ int ag_on(void* user, const void* send, void* recv, size_t bytes, void* stream) 
 // host-synchronous forms: same collectives on the context stream, then wait
 int a2a_sync(void* user, const void* send, void* recv, size_t block) {
     RcclComm* r = static_cast<RcclComm*>(user);
-    if (!r->ctx || a2a_on(user, send, recv, block, r->ctx->stream)) return 1;
+    if (!r->ctx || lig_internal_comm_fault(r->ctx, false)) return 1;
+    r->in_sync = true;
+    const int rc = a2a_on(user, send, recv, block, r->ctx->stream);
+    r->in_sync = false;
+    if (rc) return 1;
     return hipStreamSynchronize(r->ctx->stream) == hipSuccess ? 0 : 1;
 }
 int ag_sync(void* user, const void* send, void* recv, size_t bytes) {

@@ -10,6 +10,7 @@
 
 using lig::fr;
 
+
 struct lig_ctx {
     int device = 0;
     uint32_t l = 0, k = 0, n = 0;
@@ -58,6 +59,11 @@ inline void lig_internal_comms_release(lig_ctx* c) {
 inline void lig_internal_comm_unregister(lig_ctx* c, void* obj) {
     for (size_t i = 0; i < c->comms.size(); i++) if (c->comms[i].first == obj) { c->comms.erase(c->comms.begin() + i); return; }
 }
+
+// tests (LIG_FAULT_COMM): the library's communicators (comm_rccl.hip, comm_ipc.hip) ask this at the top of their all-to-all.
+// 1: the stream-ordered form fails, 2: the host-synchronous form fails too, 3: the stream-ordered form never returns (the caller's
+// watchdog has to end the process).  Used to show that bench.py's transport ladder falls through to the next rung.
+int lig_internal_comm_fault(lig_ctx* c, bool stream_ordered);
 
 // mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes)
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr);

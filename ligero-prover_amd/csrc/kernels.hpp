@@ -3,7 +3,37 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string>
 #include "fr.hpp"
+
+namespace lig {
+// Every run-time knob of the library, read ONCE from the environment by the first lig_ctx_create of the process
+// (lig_capi.hip: lig::knobs()).  None is needed on the product path: the defaults are what was measured best; the
+// table in DESIGN.md (appendix) names the experiment each one belongs to.  No other getenv exists in the library
+// (tests/test_generated_code.py greps for that).
+struct Knobs {
+    int      encode_kmask = 15;        // LIG_ENCODE_KMASK   run only K1 (1) / K2 (6) / K3 (8) of the encoder
+    uint32_t k13_block = 256;          // LIG_K13_BLOCK      workgroup size of K1 / K3 (64 | 128 | 256)
+    uint32_t k2_dyn_lds = 0;           // LIG_K2_DYN_LDS     extra dynamic LDS bytes of the tile kernel (occupancy experiments)
+    size_t   encode_chunk = 512;       // LIG_ENCODE_CHUNK   rows per encode launch group
+    bool     encode_generic = false;   // LIG_ENCODE_GENERIC radix-2 row path even where the tiled encoder exists (tests)
+    uint32_t sha_block = 256;          // LIG_SHA_BLOCK      workgroup size of the column hash
+    int      sha_gate = 1;             // LIG_SHA_GATE       place every chunk's hash before the encode stream goes on
+    size_t   sha_gate_rows = 2;        // LIG_SHA_GATE_ROWS  rows hashed before the encode stream is released
+    int      sha_prio = 0;             // LIG_SHA_PRIO       1: the side stream (column hash, samplers) is a high-priority stream
+    size_t   s1_head = 128, s1_tail = 96, s2_head = 192;   // LIG_S1_HEAD / LIG_S1_TAIL / LIG_S2_HEAD  chunk schedule
+    bool     fused_rlc = true;         // LIG_NO_FUSED_RLC   (set: the two-kernel sampler / accumulate path of round 2)
+    bool     early_code = true;        // LIG_EARLY_CODE=0   accumulate the code test inside the row loop
+    int      upload_mode = 2;          // LIG_UPLOAD_MODE    2: uploader thread, 1: per-context copy stream + events
+    bool     d2h_kernel = true;        // LIG_D2H_KERNEL=0   proof downloads by hipMemcpyAsync instead of copy kernels
+    bool     shard_force_exchange = false;   // LIG_SHARD_FORCE_EXCHANGE  pack + all-to-all with one rank too (tests)
+    bool     trace = false;            // LIG_TRACE          synchronised phase timeline on stderr
+    int      fault_comm = 0;           // LIG_FAULT_COMM     tests: 1 = the stream-ordered all-to-all of the library's communicators
+                                       //                    fails on first use, 2 = the host-synchronous one fails as well
+    std::string rccl_lib;              // LIG_RCCL_LIB       the librccl to load instead of the one already mapped / found
+};
+const Knobs& knobs();
+}  // namespace lig
 
 namespace lig {
 

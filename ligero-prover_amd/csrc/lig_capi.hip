@@ -10,6 +10,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <unistd.h>
 #include "../../include/lig_hip.h"
 #include "host_field.hpp"
 #include "kernels.hpp"
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(256) k_copy_to_unaligned(uint8_t* __restrict__
 }
 int lig_internal_download(lig_ctx* c, void* host_pinned, const void* src, size_t bytes, hipStream_t st) {
     if (!bytes) return LIG_OK;
-    static const bool by_kernel = [] { const char* e = std::getenv("LIG_D2H_KERNEL"); return !e || std::atoi(e) != 0; }();
+    const bool by_kernel = lig::knobs().d2h_kernel;
     if (!by_kernel || (bytes & 3) || ((uintptr_t)src & 15)) {
         HIP_TRY(c, hipMemcpyAsync(host_pinned, src, bytes, hipMemcpyDeviceToHost, st));
         return LIG_OK;
@@ -293,6 +294,46 @@ static int make_tiled_plan(lig_ctx* c, lig::TiledPlan& tp, uint32_t N, const H::
     return upload29(c, mid, &tp.mid);
 }
 
+// the one place the library reads its environment (ctx_internal.hpp: lig::Knobs)
+const lig::Knobs& lig::knobs() {
+    static const lig::Knobs k = [] {
+        lig::Knobs t;
+        auto num = [](const char* name, long dflt) { const char* e = std::getenv(name); return e && *e ? std::atol(e) : dflt; };
+        auto pos = [&](const char* name, long dflt) { const long v = num(name, 0); return v > 0 ? v : dflt; };
+        t.encode_kmask = (int)num("LIG_ENCODE_KMASK", 15);
+        { const long v = num("LIG_K13_BLOCK", 0); t.k13_block = (v == 64 || v == 128) ? (uint32_t)v : 256u; }
+        t.k2_dyn_lds = (uint32_t)num("LIG_K2_DYN_LDS", 0);
+        t.encode_chunk = (size_t)pos("LIG_ENCODE_CHUNK", 512);
+        { const char* e = std::getenv("LIG_ENCODE_GENERIC"); t.encode_generic = e && e[0] == '1'; }
+        t.sha_block = (uint32_t)pos("LIG_SHA_BLOCK", 256);
+        t.sha_gate = (int)num("LIG_SHA_GATE", 1);
+        t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
+        t.sha_prio = (int)num("LIG_SHA_PRIO", 0);
+        t.s1_head = (size_t)num("LIG_S1_HEAD", 128); t.s1_tail = (size_t)num("LIG_S1_TAIL", 96); t.s2_head = (size_t)num("LIG_S2_HEAD", 192);
+        t.fused_rlc = std::getenv("LIG_NO_FUSED_RLC") == nullptr;
+        t.early_code = num("LIG_EARLY_CODE", 1) != 0;
+        t.upload_mode = (int)num("LIG_UPLOAD_MODE", 2);
+        t.d2h_kernel = num("LIG_D2H_KERNEL", 1) != 0;
+        t.shard_force_exchange = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
+        t.trace = std::getenv("LIG_TRACE") != nullptr;
+        t.fault_comm = (int)num("LIG_FAULT_COMM", 0);
+        { const char* e = std::getenv("LIG_RCCL_LIB"); if (e) t.rccl_lib = e; }
+        return t;
+    }();
+    return k;
+}
+
+int lig_internal_comm_fault(lig_ctx* c, bool stream_ordered) {
+    const int f = lig::knobs().fault_comm;
+    if (!f) return 0;
+    if (f == 3 && stream_ordered) for (;;) sleep(3600);
+    if ((stream_ordered && (f == 1 || f == 2)) || (!stream_ordered && f == 2)) {
+        if (c) c->err = std::string("injected fault (LIG_FAULT_COMM) in the ") + (stream_ordered ? "stream-ordered" : "host-synchronous") + " all-to-all";
+        return 1;
+    }
+    return 0;
+}
+
 extern "C" {
 
 const char* lig_version(void) { return "lig_hip 0.1 (gfx950)"; }
@@ -313,12 +354,17 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     if ((rc = make_plan(c, c->plan[LIG_SIZE_2K], 2 * k, w2k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan[LIG_SIZE_N], n, w4k)) != LIG_OK) return rc;
     if ((rc = make_plan(c, c->plan_half, 2 * k, H::mul(w4k, w4k))) != LIG_OK) return rc;     // the subgroup <w_n^2>, order 2k
+    if (lig::knobs().sha_prio) {              // experiment (profiles/r04_sha_priority_ab.md): the hash stream in the high-priority queue class
+        int lo = 0, hi = 0;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+    } else
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));      // side stream: column hash, samplers
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));      // copy stream
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     // LIG_ENCODE_GENERIC=1 (tests): take the generic radix-2 row path even where the tiled encoder exists
-    c->fast = lig::encode_fast_supported(k) && !(std::getenv("LIG_ENCODE_GENERIC") && std::getenv("LIG_ENCODE_GENERIC")[0] == '1');
+    c->fast = lig::encode_fast_supported(k) && !lig::knobs().encode_generic;
     if (c->fast && (rc = make_encode_plan(c, wk, w4k)) != LIG_OK) return rc;
     c->tiled = lig::tiled_supported(ilog2u(k)) && lig::tiled_supported(ilog2u(n));
     if (c->tiled) {
@@ -451,7 +497,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
     if (c->fast) {
         // rows per launch group: the Y/Z scratch (1 MiB/row) should stay inside the 256 MiB L3 so that K3's
         // re-read of Z does not go to HBM.  LIG_ENCODE_CHUNK overrides for experiments.
-        static const size_t chunk = [] { const char* e = std::getenv("LIG_ENCODE_CHUNK"); size_t v = e ? (size_t)std::atoi(e) : 0; return v ? v : (size_t)512; }();
+        const size_t chunk = lig::knobs().encode_chunk;
         int rc = ensure_scratch(c, rows < chunk ? rows : chunk);
         if (rc != LIG_OK) return rc;
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {

@@ -222,15 +222,15 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
                           hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot) {
     constexpr uint32_t B = 1u << LOG2B;
     const size_t th1 = rows * B;
-    static const int kmask = [] { const char* e = std::getenv("LIG_ENCODE_KMASK"); return e ? std::atoi(e) : 15; }();   // experiments only: 1 = K1, 6 = K2, 8 = K3
+    const int kmask = lig::knobs().encode_kmask;       // experiments only: 1 = K1, 6 = K2, 8 = K3
     // K1 / K3 have no LDS and no barrier: their workgroup size is free (LIG_K13_BLOCK, experiments)
-    static const uint32_t bs13 = [] { const char* e = std::getenv("LIG_K13_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128) ? (uint32_t)v : 256u; }();
+    const uint32_t bs13 = lig::knobs().k13_block;
     if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + bs13 - 1) / bs13)), dim3(bs13), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     if (ev0) (void)hipEventRecord(ev0, s);
     if (kmask & 6) {
         // LIG_K2_DYN_LDS (experiments): unused dynamic LDS per workgroup, to lower the tile kernel's workgroups per CU below what its
         // registers allow (3) and leave room for the waves of the other stream's kernels
-        static const uint32_t dyn = [] { const char* e = std::getenv("LIG_K2_DYN_LDS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+        const uint32_t dyn = lig::knobs().k2_dyn_lds;
         if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
         else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
     }

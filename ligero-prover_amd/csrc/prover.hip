@@ -247,8 +247,7 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
         // last one (the hash tail after the last encode); LIG_S1_HEAD / LIG_S1_TAIL override for experiments
         // (profiles/r02_stage1_schedule_ab.md: head 128 is +3 % proofs/s with two proofs in flight; one stage 1 at a time -- a
         // process-wide lock around this stage -- measured 3-5 % slower)
-        const char* eh = std::getenv("LIG_S1_HEAD"); const char* et = std::getenv("LIG_S1_TAIL");
-        T->sched1 = chunk_schedule(R, lig_tune::CHUNK, eh ? (size_t)std::atoi(eh) : 128, et ? (size_t)std::atoi(et) : 96);
+        T->sched1 = chunk_schedule(R, lig_tune::CHUNK, lig::knobs().s1_head, lig::knobs().s1_tail);
     }
     TRY(lig_internal_reserve_scratch(c, R < lig_tune::CHUNK ? (R ? R : 1) : lig_tune::CHUNK));     // sized once: never re-allocated under a running stream
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -325,8 +324,8 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
         TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, lig::ENC_PLANAR, s_enc));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
-        static const int gate = [] { const char* e = std::getenv("LIG_SHA_GATE"); return e ? std::atoi(e) : 1; }();
-        static const size_t g = [] { const char* e = std::getenv("LIG_SHA_GATE_ROWS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (size_t)v : (size_t)2; }();   // experiments
+        const int gate = lig::knobs().sha_gate;
+        const size_t g = lig::knobs().sha_gate_rows;
         if (gate && nb > 2 * g) {
             // the hash waves must be placed while the chip is idle (one per SIMD, evenly): hash the first two rows, let the
             // encode stream wait for that, and queue the rest of the chunk right behind it on the hash stream
@@ -404,7 +403,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // stream, double-buffered, while the main stream encodes / accumulates chunk b (VALU-bound).
     // first chunk 192 rows (the encode stream waits for the first randomness rows); LIG_S2_HEAD overrides for experiments
     // (profiles/r02_stage1_schedule_ab.md: 192-256 rows +3 % proofs/s over 96 with two proofs in flight)
-    static const size_t s2_head = [] { const char* e = std::getenv("LIG_S2_HEAD"); return e ? (size_t)std::atoi(e) : (size_t)192; }();
+    const size_t s2_head = lig::knobs().s2_head;
     const std::vector<std::pair<size_t, size_t>> sched2 = chunk_schedule(R, lig_tune::CHUNK, s2_head, 0);
     const size_t n_chunks = sched2.size();
     std::vector<uint64_t> chunk_pos(n_chunks + 1, 0);
@@ -416,8 +415,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     auto rand_buf = [&](size_t ci) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + sched2[ci].first * (size_t)k : T->randb + (ci & 1) * lig_tune::CHUNK * (size_t)k; };
     // Generated (dense) randomness rows: the sampler also accumulates the message-domain halves of the code and linear tests
     // while the elements are in registers (aes.hip: k_rand_rlc) -- all of it on the side stream; the main stream only encodes.
-    const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
-    static const bool early_code = [] { const char* e = std::getenv("LIG_EARLY_CODE"); return !e || std::atoi(e) != 0; }();      // (see below)
+    const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && lig::knobs().fused_rlc;
+    const bool early_code = lig::knobs().early_code;      // (see below)
     const lig::f29s* rc_loop = early_code ? nullptr : T->coef_dev;      // code coefficients of the row loop (null: accumulated up front)
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
@@ -590,7 +589,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
 
 // LIG_TRACE=1: print a synchronised timeline of the prove call to stderr (debug aid, off by default)
 static std::function<void(const char*)> make_mark(lig_ctx* c) {
-    const bool trace_on = std::getenv("LIG_TRACE") != nullptr;
+    const bool trace_on = lig::knobs().trace;
     auto t_mark = std::make_shared<clk::time_point>(clk::now());
     return [c, trace_on, t_mark](const char* what) {
         if (!trace_on) return;
@@ -792,7 +791,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
     // (A copy kernel reading the pinned rows over PCIe instead of the DMA engine was measured: 37 GB/s against 56 GB/s, and
     // the long-running kernel serialises with the proof's kernels whenever both streams share a hardware queue:
     // stage 2 5.6 -> 13.8 ms.  The DMA engine it is.)
-    static const int mode = [] { const char* e = std::getenv("LIG_UPLOAD_MODE"); return e ? std::atoi(e) : 2; }();   // 2: uploader thread (default), 1: per-context copy stream + events
+    const int mode = lig::knobs().upload_mode;   // 2: uploader thread (default), 1: per-context copy stream + events
     if (mode == 2 && uploader_available(c)) {
         if (!T->up_flag) {
             HIP_TRY(c, hipHostMalloc((void**)&T->up_flag, 4096, hipHostMallocDefault));

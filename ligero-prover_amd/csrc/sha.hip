@@ -161,7 +161,7 @@ void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const
     // and the encode workgroups that share the chip finish with their slowest wave, so the hash load has to be the same
     // on all SIMDs of a CU (measured: encode kernels 2-3x slower next to 64-thread hash workgroups, 1.1-1.8x next to
     // 256-thread ones; tools/corun_bench.py).  LIG_SHA_BLOCK overrides for experiments.
-    static const uint32_t bs = [] { const char* e = std::getenv("LIG_SHA_BLOCK"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t)v : 256u; }();
+    const uint32_t bs = lig::knobs().sha_block;
     hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + bs - 1) / bs)), dim3(bs), 0, s, state, n_inst, rows, row_stride,
                        nrows, rows_before, plane_k, msgs);
 }

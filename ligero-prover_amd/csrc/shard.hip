@@ -193,7 +193,7 @@ static int shard_alloc(lig_ctx* c, uint32_t rank, uint32_t world, lig_shard* S) 
     const uint32_t k = c->k, n = c->n, t = 192, W = world;
     const size_t R = S->R;
     S->ncol = n / world;
-    S->exchange_even_alone = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
+    S->exchange_even_alone = lig::knobs().shard_force_exchange;
     shard_chunks(S->rows, W, S->rounds, S->gb);
     S->G = S->rounds * W;
     for (size_t g = 0; g < S->G; g++) S->ch_cap = std::max(S->ch_cap, S->chunk_rows(g));
@@ -425,7 +425,7 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // key + memsets above
     HIP_TRY(c, hipStreamWaitEvent(s_hash, c->ev_fork, 0));
     // as in lig_synth_prove: the sampler also accumulates the message-domain halves of the code / linear tests (k_rand_rlc)
-    const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && std::getenv("LIG_NO_FUSED_RLC") == nullptr;
+    const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && lig::knobs().fused_rlc;
     // the caller's randomness rows (lig_shard_rows_prove): device rows are used in place, host rows go through the double buffer
     auto rand_buf = [&](size_t cidx) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + S->lrow0[cidx] * (size_t)k : S->randb + (cidx & 1) * CAP * (size_t)k; };
     auto form_rand_chunk = [&](size_t cidx) -> int {           // on the side stream

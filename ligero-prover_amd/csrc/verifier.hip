@@ -62,7 +62,7 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
     hipStream_t s = c->stream;
     const size_t R = rows.size();
     // LIG_TRACE=1: synchronised phase marks on stderr (debug aid)
-    const bool trace_on = std::getenv("LIG_TRACE") != nullptr;
+    const bool trace_on = lig::knobs().trace;
     auto t_mark = clk::now();
     auto mark = [&](const char* what) {
         if (!trace_on) return;
