@@ -182,10 +182,11 @@ class RowsFromHostWorkload:
     (lig_rng_fill_rows), as its public definition allows.  This is the PCIe-inclusive figure (value_incl_h2d)."""
     name = "rows_from_host"
 
-    def __init__(self, ctx, constraints, pkg, inflight, device, narrow_bytes=0):
+    def __init__(self, ctx, constraints, pkg, inflight, device, narrow_bytes=0, caller_rands=False):
         import numpy as np
         import torch
         self.pkg, self.inflight, self.narrow_bytes = pkg, inflight, narrow_bytes
+        self.caller_rands, self.rands = caller_rands, None
         self.constraints_per_trace = constraints
         self.constraints = constraints * inflight
         R = -(-constraints // L_)
@@ -217,6 +218,20 @@ class RowsFromHostWorkload:
             self.keep.append(keep)
         self.loaded = [True] * inflight          # lig_rows_begin started the first upload
         self.last = None
+        if caller_rands:
+            # what a real constraint generator does (nonbatch_context.hpp:654-780): after the commit it derives one dense 256-bit
+            # randomness row per linear row from the stage-1 seed, in HOST memory.  Here: the dense rows of the synthetic stream (so the
+            # proof is the pinned one), generated once -- the trace and therefore the seed are the same in every step -- and kept in
+            # pinned host memory; every lig_rows_prove of the timed region ships them (another 550 MB per 2^24 constraints).
+            c, t = self.ctxs[0], self.traces[0]
+            _, seed = c.rows_commit(t)
+            d = ctx.malloc(R * K_ * 32)
+            ctx.rng_fill_rows(seed, 0, per_row, d)
+            self.rands = torch.empty((R, K_, 8), dtype=torch.int32, pin_memory=True)
+            ctx.check(ctx.L.lig_read(ctx.h, C.c_void_p(self.rands.data_ptr()), d, R * K_ * 32))
+            ctx.free(d)
+            c.rows_prove(t, self.rands.data_ptr(), None, copy=False)
+            self.loaded[0] = False
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=inflight)
 
@@ -232,7 +247,8 @@ class RowsFromHostWorkload:
         job.generated_at = 0
         job.version = b"1.5.0"
         job.set_public_args(None)
-        job.dense_rands_per_row = self.per_row.ctypes.data      # the synthetic stream's dense coefficient rows: sampled on the device
+        if not self.caller_rands:
+            job.dense_rands_per_row = self.per_row.ctypes.data      # the synthetic stream's dense coefficient rows: sampled on the device
         if self.widths is not None:
             job.elem_bytes = self.widths.ctypes.data
         t = C.c_void_p()
@@ -251,7 +267,7 @@ class RowsFromHostWorkload:
             self.loaded[i] = s_ + 1 < steps
             if self.loaded[i]:
                 c.check(c.L.lig_rows_restart(t, host, 0))
-            (addr, length), info = c.rows_prove(t, None, None, copy=False)
+            (addr, length), info = c.rows_prove(t, self.rands.data_ptr() if self.caller_rands else None, None, copy=False)
             if not (info.valid_code and info.valid_linear and info.valid_quad):
                 raise SystemExit("prover self-check failed")
             out = (addr, length)
@@ -276,10 +292,10 @@ class ShardedWorkload:
     after one all-to-all, all-gathered leaves / partial accumulators / opened columns).  Strong scaling."""
     name = "sharded"
 
-    def __init__(self, ctx, constraints, group, pkg):
+    def __init__(self, ctx, constraints, group, pkg, comm=None):
         self.ctx, self.constraints, self.group = ctx, constraints, group
         self.job = pkg.Context.make_job(constraints, 0, synth_seed=1, generated_at=0)
-        self.comm = group.make_comm(pkg, ctx)
+        self.comm = comm if comm is not None else group.make_comm(pkg, ctx)
         self.shard = ctx.shard_prepare(self.job, group.rank, group.world, self.comm)
         self.rows = -(-constraints // L_)
         self.rounds = pkg.shard_plan(self.job, L_, group.world)[0]
@@ -328,6 +344,9 @@ def launch_ranks(n, argv):
     import subprocess
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()),
                LIG_BENCH_SPAWNED="1")
+    # The pool's host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's own P2P set-up (and any
+    # hipIpcGetMemHandle) fails with "invalid argument".  The image exports it already; it is only set here when the caller's
+    # environment lost it, never overridden, and the value the ranks ran with is recorded in the line (preflight).
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
     for r in range(n):
@@ -363,19 +382,34 @@ def run_stub(a, lig_dist):
     group.barrier()
     dt = group.max_over_ranks(time.perf_counter() - t0)
     total = group.sum_over_ranks(wl.constraints * a.steps)
+    extra = {}
+    if a.sharded_leg:
+        results, attempts = sharded_ladder(a, group, group.rank, group.world, group.local_rank, workload="stub")
+        extra = {"sharded": dict(results.get(str(a.sharded_log2).split(",")[-1]) or {"error": "no rung delivered"}, attempts=attempts)}
     if group.rank == 0:
         print(json.dumps({"metric": "prover constraints/sec", "value": total / dt, "unit": "constraints/s", "n_gpus": group.world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
                           "config": {"workload": "stub (launcher test, no GPU work)"},
-                          "spawned_by_bench": bool(os.environ.get("LIG_BENCH_SPAWNED"))}), flush=True)
+                          "spawned_by_bench": bool(os.environ.get("LIG_BENCH_SPAWNED")), **extra}), flush=True)
     group.close()
 
 
-def sharded_leg(ctx, group, pkg, log2c, steps, warmup, fence):
+TRANSPORT_NOTES = {
+    "rccl-stream": "librccl, stream-ordered: grouped ncclSend/ncclRecv per round + ncclAllGather (leaves, partial sums, opened columns) on the context's HIP streams",
+    "rccl-sync": "librccl, host-synchronous forms of the same communicator (collective, then hipStreamSynchronize)",
+    "ipc-stream": "comm_ipc: peers map each other's buffers (hipIpcMemHandle), GPU-ordered on flags in shared memory",
+    "ipc-sync": "comm_ipc, host-synchronous forms",
+    "torch": "torch.distributed's own RCCL communicator (all_to_all_single / all_gather_into_tensor on the library's device buffers), host-synchronous",
+    "host": "host-synchronous callbacks staged through host memory (gloo) / plain copies (one rank)",
+}
+
+
+def sharded_leg(ctx, group, pkg, log2c, steps, warmup, fence, comm=None, transport=None):
     """configs[3]: ONE trace sharded over all ranks, timed like the main region (barrier + synchronize on both sides, MAX over
     ranks).  Collective: every rank calls it."""
-    swl = ShardedWorkload(ctx, 1 << log2c, group, pkg)
+    swl = ShardedWorkload(ctx, 1 << log2c, group, pkg, comm)
+    transport = transport or getattr(group, "transport", None)
     try:
         for _ in range(warmup):
             swl.step()
@@ -389,14 +423,10 @@ def sharded_leg(ctx, group, pkg, log2c, steps, warmup, fence):
         out = {"workload": d["workload"], "log2_constraints": log2c, "rows": d["rows"], "ranks": group.world, "steps": steps, "warmup": warmup,
                "ms_per_proof": 1e3 * dt / steps, "constraints_per_s": (1 << log2c) * steps / dt, "scaling": "strong",
                "stage_ms": d.get("stage_ms"), "proof_bytes": d.get("proof_bytes"), "proof_sha256": d.get("proof_sha256"),
-               "exchange_rounds": swl.rounds,
-               "collectives": "comm_ipc (test mode: peers map each other's buffers, GPU-ordered)" if os.environ.get("LIG_COMM") == "ipc" else
-                              "librccl: grouped ncclSend/ncclRecv per round + ncclAllGather (leaves, partial sums, opened columns)"}
-        try:
-            out["rccl_ranks"] = ctx.rccl_comm_count(swl.comm)          # ncclCommCount of the communicator the proofs ran on
+               "exchange_rounds": swl.rounds, "transport": transport, "collectives": TRANSPORT_NOTES.get(transport)}
+        out["rccl_ranks"] = group.rccl_ranks() if hasattr(group, "rccl_ranks") else None       # ncclCommCount of the communicator the proofs ran on
+        if out["rccl_ranks"] is not None:
             out["rccl_library"] = pkg.rccl_available()[1]
-        except pkg.LigError:
-            out["rccl_ranks"] = None
         pin_path = os.path.join(ROOT, "tests", "golden", "full_pin_2p%d.json" % log2c)
         if os.path.exists(pin_path):
             with open(pin_path) as f:
@@ -407,6 +437,148 @@ def sharded_leg(ctx, group, pkg, log2c, steps, warmup, fence):
         return out
     finally:
         swl.close()
+
+
+RESULT_TAG = "LIG_SHARDED_RESULT "
+
+
+def ladder_transports(world):
+    """the rungs of the sharded leg, first = the product path.  Every rung runs in FRESH processes (one child per rank, its own
+    rendezvous), so a rung that fails or hangs -- on one rank or on all -- is killed and cannot poison the next one."""
+    if os.environ.get("LIG_COMM") == "ipc":           # tests: W ranks share the one GPU of the box
+        return ["ipc-stream", "ipc-sync", "host"]
+    if world == 1:
+        return ["rccl-stream", "rccl-sync", "host"]
+    return ["rccl-stream", "rccl-sync", "torch", "ipc-stream"]
+
+
+def sharded_child(a, lig_dist):
+    """one rank of one rung of the sharded leg (spawned by sharded_ladder): builds the communicator of --transport, proves the
+    sharded trace at every size of --sharded-log2, rank 0 prints one tagged JSON line per size as soon as it is measured"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    sizes = [int(x) for x in str(a.sharded_log2).split(",") if x]
+    if a.transport.startswith("stub"):                # launcher tests on CPU: a rendezvous, a barrier, canned outcomes
+        group = lig_dist.Group("gloo")
+        if a.transport == "stub-fail" and rank == world - 1:
+            raise SystemExit("stub-fail: rank %d gives up" % rank)
+        if a.transport == "stub-hang" and rank == world - 1:
+            time.sleep(3600)
+        group.barrier()
+        for lg in sizes:
+            if rank == 0:
+                print(RESULT_TAG + json.dumps({"log2_constraints": lg, "ranks": world, "transport": a.transport, "ms_per_proof": 1.0}), flush=True)
+        group.close()
+        return
+    import torch
+    if os.environ.get("LIG_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    pkg = load_pkg()
+    group = lig_dist.Group("nccl" if a.transport == "torch" and world > 1 else "gloo")      # rendezvous only, except for the torch rung
+    ctx = pkg.Context(L_, K_, N_, device=local_rank)
+
+    def fence():
+        group.barrier()
+        torch.cuda.synchronize()
+
+    comm = group.make_comm(pkg, ctx, a.transport)
+    for lg in sizes:
+        out = sharded_leg(ctx, group, pkg, lg, a.sharded_steps, 2, fence, comm, a.transport)
+        if rank == 0:
+            print(RESULT_TAG + json.dumps(out), flush=True)
+    group.close()
+    ctx.close()
+
+
+def sharded_ladder(a, group, rank, world, local_rank, workload="sharded"):
+    """The configs[3] leg of `bench.py --gpus N`: rank by rank one CHILD process per rung (a fresh rendezvous on a port rank 0
+    picks), the rungs of ladder_transports() in order until one delivers every size.  All ranks agree on the outcome of a rung
+    through the parent's process group (MIN of the ranks' success flags), a child that does not finish within
+    --sharded-timeout is killed.  Returns (results by log2 size, attempts)."""
+    import subprocess
+    names = [x for x in (a.sharded_transports or "").split(",") if x] or ladder_transports(world)
+    sizes = [int(x) for x in str(a.sharded_log2).split(",") if x]
+    t_begin = time.time()
+    attempts, results = [], {}
+    env0 = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}     # (an agent store would swallow the child's own rendezvous)
+    for name in names:
+        # rank 0 decides whether there is time for another rung and picks the rendezvous port; everybody learns both
+        go = 0
+        if rank == 0 and time.time() - t_begin + 15 < a.sharded_budget:
+            go = free_port()
+        go = group.sum_over_ranks(go)
+        if not go:
+            attempts.append({"transport": name, "ok": False, "skipped": "the leg's time budget (--sharded-budget %d s) is used up" % a.sharded_budget})
+            continue
+        env = dict(env0, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(go),
+                   LIG_BENCH_CHILD="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--transport", name, "--gpus", str(world), "--workload", workload,
+               "--sharded-log2", ",".join(map(str, sizes)), "--sharded-steps", str(a.sharded_steps)]
+        t0 = time.time()
+        timed_out = False
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        try:
+            o, e = p.communicate(timeout=a.sharded_timeout)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            p.kill()
+            o, e = p.communicate()
+        ok = (not timed_out) and p.returncode == 0
+        got = {}
+        for ln in o.decode(errors="replace").splitlines():
+            if ln.startswith(RESULT_TAG):
+                r = json.loads(ln[len(RESULT_TAG):])
+                got[str(r["log2_constraints"])] = r
+        if rank == 0:
+            ok = ok and all(str(lg) in got for lg in sizes)
+        n_ok = group.sum_over_ranks(1 if ok else 0)
+        att = {"transport": name, "ok": n_ok == world, "ranks_ok": n_ok, "seconds": round(time.time() - t0, 1)}
+        if n_ok != world:
+            att["this_rank"] = "timeout after %d s (killed)" % a.sharded_timeout if timed_out else "rc %s" % p.returncode
+            tail = [ln for ln in e.decode(errors="replace").splitlines() if ln.strip()][-6:]
+            att["stderr_tail"] = " | ".join(tail)[-700:]
+            if got:
+                att["sizes_done_before_failure"] = sorted(got)
+        attempts.append(att)
+        for k_, v in got.items():                       # a size measured before a later one failed still counts
+            results.setdefault(k_, v)
+        if n_ok == world:
+            break
+    return results, attempts
+
+
+def rocm_smi_topo():
+    """link types between the GPUs as rocm-smi reports them (rank 0, best effort)"""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        txt = subprocess.run([exe, "--showtopotype"], capture_output=True, timeout=30).stdout.decode(errors="replace")
+    except (OSError, subprocess.SubprocessError) as e:
+        return {"error": repr(e)[:200]}
+    kinds = re.findall(r"\b(XGMI|PCIE)\b", txt)
+    return {"link_types": {k_: kinds.count(k_) for k_ in sorted(set(kinds))}, "raw_tail": " / ".join(ln.strip() for ln in txt.splitlines() if ln.strip().startswith("GPU"))[:1200]}
+
+
+def preflight(group, pkg, torch, local_rank, world):
+    """what the N > 1 run stands on, recorded in the line: which physical device every rank has, peer access, the RCCL the
+    library resolves, the IPC mode the ranks run with, the node's link types"""
+    bus = pkg.device_pci_bus_id(local_rank) or "?"
+    ids = [b.rstrip(b"\0").decode(errors="replace") for b in group.gather_digests(bus.encode()[:32].ljust(32, b"\0"))]
+    ndev = torch.cuda.device_count()
+    peers = [pkg.device_peer_access(local_rank, j) for j in range(ndev) if j != local_rank]
+    all_peers = group.sum_over_ranks(1 if all(peers) else 0) == world
+    ok, lib, ver = pkg.rccl_available()
+    out = {"pci_bus_ids": ids, "distinct_devices": len(set(ids)) == world, "visible_devices_rank0": ndev,
+           "peer_access_between_all_visible_devices": all_peers,
+           "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+           "rccl": {"available": ok, "library": lib, "version": ver}}
+    if group.rank == 0:
+        out["topology"] = rocm_smi_topo()
+    return out
 
 
 def usable_cores():
@@ -496,15 +668,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded", "stub"])
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the stub workload uses gloo)")
-    ap.add_argument("--sharded-log2", type=int, default=26, help="N > 1: size of the ONE trace sharded over the ranks (configs[3]: 2^26)")
+    ap.add_argument("--sharded-log2", default="24,26", help="N > 1: sizes of the ONE trace sharded over the ranks (configs[3] is 2^26; 2^24 is the "
+                    "N = 1 bench size, so strong scaling is visible there too)")
     ap.add_argument("--sharded-steps", type=int, default=5)
-    ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds after which a hung sharded leg is given up (the line is still printed)")
+    ap.add_argument("--sharded-timeout", type=int, default=180, help="seconds after which the child processes of one rung of the sharded leg are killed")
+    ap.add_argument("--sharded-budget", type=int, default=480, help="seconds the whole sharded leg may take: no further rung is started beyond it")
+    ap.add_argument("--sharded-transports", default=None, help="comma-separated rungs instead of the default ladder (ligero-prover_amd/dist.py: TRANSPORTS)")
+    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)       # one rank of one rung (spawned by the ladder)
+    ap.add_argument("--transport", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--sharded-leg", action="store_true", help="run the configs[3] leg with one rank as well")
     ap.add_argument("--no-sharded-leg", action="store_true")
     ap.add_argument("--log2-constraints", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed, informational) HIP verifier run on the last proof")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive second measurement (value_incl_h2d)")
+    ap.add_argument("--no-h2d-rands", action="store_true", help="skip the leg that also ships the caller's randomness rows from host memory")
     ap.add_argument("--h2d-inflight", type=int, default=2, help="contexts alternating in the PCIe-inclusive measurement: each pipelines "
                     "upload i+1 under proof i, the uploads of all contexts go through one uploader thread (one at a time), so two "
                     "contexts keep the link busy: commit / prove of one under the upload of the other")
@@ -527,6 +705,8 @@ def main():
     spec = importlib.util.spec_from_file_location("lig_dist", os.path.join(ROOT, "ligero-prover_amd", "dist.py"))
     lig_dist = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lig_dist)
+    if a.sharded_child:
+        return sharded_child(a, lig_dist)
     if a.workload == "stub":
         return run_stub(a, lig_dist)
 
@@ -612,6 +792,29 @@ def main():
                     "how": "lig_rows_restart/commit/prove: witness rows uploaded from pinned host memory inside the timed region "
                            "(chunk by chunk by the library's uploader thread, each chunk encoded as it arrives; upload i+1 under proof i), "
                            "%d contexts alternating" % hw.inflight}
+            if not a.no_h2d_rands:
+                # the real driver's figure: witness rows AND the caller's dense randomness rows from pinned host memory
+                try:
+                    hw.close()
+                    hw = RowsFromHostWorkload(ctx, 1 << log2c, pkg, max(1, a.h2d_inflight), local_rank, caller_rands=True)
+                    hw.run(3)
+                    fence()
+                    t0 = time.perf_counter()
+                    hw.run(a.steps)
+                    fence()
+                    dtr = group.max_over_ranks(time.perf_counter() - t0)
+                    both = int(hw.host.numel() * 4 + hw.rands.numel() * 4)
+                    bound_ms = None if not incl["link_GBps"] else both / incl["link_GBps"] / 1e6
+                    incl["caller_rands"] = {
+                        "value": hw.constraints * a.steps * world / dtr, "ms_per_step": 1e3 * dtr / a.steps, "ms_per_proof": 1e3 * dtr / (a.steps * hw.inflight),
+                        "h2d_bytes_per_trace": both, "link_bound_ms_per_trace": bound_ms,
+                        "frac_of_link_bound": None if not bound_ms else bound_ms / (1e3 * dtr / (a.steps * hw.inflight)),
+                        "proof_sha256": hw.proof_sha256(),
+                        "how": "as above, and lig_rows_prove takes the caller's dense randomness rows (one 256-bit coefficient per witness, what "
+                               "nonbatch_context.hpp:654-780 ships per linear row) from pinned host memory: the uploader thread fills the double "
+                               "buffer chunk by chunk, the proof's stream waits on words in pinned memory (hipStreamWaitValue32)"}
+                except (RuntimeError, MemoryError, pkg.LigError) as e:
+                    sys.stderr.write("caller-rands H2D leg skipped: %r\n" % (e,))
             if a.h2d_narrow:
                 try:
                     hw.close()
@@ -728,34 +931,46 @@ def main():
             out["value_incl_h2d"] = incl["value"]
             out["incl_h2d"] = incl
             out["incl_h2d"]["same_proof_bytes"] = incl["proof_sha256"] == out["config"].get("proof_sha256")
+            if "caller_rands" in incl:
+                incl["caller_rands"]["same_proof_bytes"] = incl["caller_rands"]["proof_sha256"] == out["config"].get("proof_sha256")
     else:
         out = None
     if a.workload == "full" and not a.no_sharded_leg and (world > 1 or a.sharded_leg):
-        # The sharded leg is the one part of this script that needs real peers (RCCL over xGMI).  If it fails or hangs on some
-        # node, the weak-scaling figure measured above must not be lost with it: exceptions are recorded in the line, and a
-        # watchdog on EVERY rank ends the process after --sharded-timeout seconds -- rank 0 prints the line it has first.
+        # The sharded leg is the one part of this script that needs real peers (RCCL over xGMI).  It runs in child processes, rung
+        # by rung (sharded_ladder): whatever happens there -- an error on one rank, a hung collective, a crash -- the weak-scaling
+        # figure measured above is already in `out` and is printed.
+        ctx.close()                                         # the children use the GPU now (close() again below is a no-op)
         import threading
         done = threading.Event()
 
-        def watchdog():
-            if done.wait(a.sharded_timeout):
+        def watchdog():           # last resort: the PARENTS' own collectives hang (a peer parent died): print what there is and leave
+            if done.wait(a.sharded_budget + a.sharded_timeout + 60):
                 return
             if out is not None:
-                out.setdefault("sharded", {"error": "the sharded leg did not finish within %d s (hung collective?); the weak-scaling figures above are unaffected" % a.sharded_timeout})
+                out.setdefault("sharded", {"error": "the sharded leg's launcher did not return (a rank of the bench itself is gone?); the weak-scaling figures above are unaffected"})
                 sys.stdout.flush()
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(0 if out is not None else 1)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            sh = sharded_leg(ctx, group, pkg, a.sharded_log2, a.sharded_steps, 2, fence)       # collective: all ranks
-        except (RuntimeError, MemoryError, pkg.LigError) as e:
-            sh = {"error": repr(e)[:500]}
-            sys.stderr.write("sharded leg failed on rank %d: %r\n" % (rank, e))
+            pre = preflight(group, pkg, torch, local_rank, world)
+        except (RuntimeError, OSError, pkg.LigError) as e:
+            pre = {"error": repr(e)[:300]}
+        results, attempts = sharded_ladder(a, group, rank, world, local_rank)
+        done.set()
         if out is not None:
+            sizes = [int(x) for x in str(a.sharded_log2).split(",") if x]
+            main_size = 26 if 26 in sizes else sizes[-1]
+            sh = dict(results.get(str(main_size)) or {"error": "no rung of the ladder delivered the 2^%d trace" % main_size})
+            sh["attempts"] = attempts
+            sh["answers"] = ("strong scaling of ONE trace (north_star's '>= 6x further at 8 GPUs' read as latency of one proof); the per-column hash chain does "
+                             "not shorten with W, see DESIGN.md section 7 for the per-W prediction; `value` above (independent traces) is the throughput answer")
             out["sharded"] = sh
-        if "error" not in sh:
-            done.set()              # (after a failure the watchdog stays armed: the teardown below may wait for peers that are gone)
+            for lg in sizes:
+                if lg != main_size:
+                    out["sharded_2p%d" % lg] = results.get(str(lg)) or {"error": "not delivered"}
+            out["preflight"] = pre
     if out is not None:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl.name)

@@ -44,6 +44,10 @@ uint32_t lig_message_size(const lig_ctx *ctx);            /* l  (wgpu.hpp:153) *
 uint32_t lig_padding_size(const lig_ctx *ctx);            /* k  (wgpu.hpp:154) */
 uint32_t lig_encoding_size(const lig_ctx *ctx);           /* n  (wgpu.hpp:155) */
 void *lig_stream(lig_ctx *ctx);                           /* hipStream_t, for callers that enqueue their own work */
+/* which physical device an ordinal is ("0000:c1:00.0") and whether it can map a peer's memory: what a multi-GPU launcher
+ * records before it builds a communicator (bench.py's preflight).  No context needed. */
+int lig_device_pci_bus_id(int device, char *out, size_t cap);
+int lig_device_peer_access(int device, int peer, int *can);
 
 /* ---- buffers: make_device_buffer (zero-initialised like WebGPU), write_buffer, write_buffer_clear,
  * clear_buffer, copy_buffer_to_buffer, copy_to_host (device_context.hpp:79-98, device_context.cpp:364-449) */
@@ -312,6 +316,8 @@ int    lig_proof_gunzip(const uint8_t *gz, size_t len, uint8_t *out, size_t cap,
  * callbacks exist so that tests can run the same sharded logic over gloo on CPU-staged buffers: they are called after
  * the context stream has been drained and must return 0 once the data is in place. ==== */
 typedef struct lig_shard lig_shard;
+/* A caller that fills in a lig_comm itself MUST zero the whole struct first (memset / = {0}): members may be appended (as
+ * `forget` was), a non-NULL optional member is called.  lig_rccl_comm_create / lig_ipc_comm_create zero it themselves. */
 typedef struct {
     void *user;
     /* rank g's `send` holds world blocks of block_bytes; block h goes to rank h; `recv` block g comes from rank g */
@@ -359,7 +365,8 @@ void lig_shard_destroy(lig_shard *shard);
  * the randomness rows of its own rows; lig_shard_rows_prove takes those (local rows x k, zero rows for batch kinds) and the
  * public linear constant (NULL: minus the sum of all inner products, as lig_rows_prove).  Every rank obtains the envelope of
  * lig_rows_prove on the whole trace.  Replaces the per-row callbacks of include/zkp/nonbatch_context.hpp:445-471, :654-780,
- * :924-970 when the rows of one trace live on several GPUs. ==== */
+ * :924-970 when the rows of one trace live on several GPUs.
+ * The sharded entry takes full-width rows only: job->elem_bytes must be NULL (LIG_E_ARG otherwise). ==== */
 int lig_shard_rows_plan(const uint8_t *kinds, size_t n_rows, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
 int lig_shard_rows_begin(lig_ctx *ctx, const lig_rows_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
 int lig_shard_rows_restart(lig_shard *shard, const void *local_msgs, int msgs_on_device);   /* next trace, same shape */

@@ -35,6 +35,7 @@ EXPORTS = [
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
+    "lig_device_pci_bus_id", "lig_device_peer_access",
     "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
 ]
 
@@ -198,6 +199,8 @@ def load_library():
     L.lig_ipc_comm_destroy.restype = None
     L.lig_rccl_available.argtypes = [C.c_char_p, sz, C.POINTER(C.c_int)]
     L.lig_rccl_comm_count.argtypes = [C.POINTER(Comm), C.POINTER(u32)]
+    L.lig_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, sz]
+    L.lig_device_peer_access.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -238,6 +241,19 @@ def rccl_available():
     buf, ver = C.create_string_buffer(512), C.c_int()
     rc = L.lig_rccl_available(buf, 512, C.byref(ver))
     return rc == 0, buf.value.decode(), ver.value
+
+
+def device_pci_bus_id(device):
+    """-> "0000:c1:00.0" of a HIP device ordinal (None if the runtime cannot say)"""
+    L = load_library()
+    buf = C.create_string_buffer(64)
+    return buf.value.decode() if L.lig_device_pci_bus_id(device, buf, 64) == 0 else None
+
+
+def device_peer_access(device, peer):
+    L = load_library()
+    can = C.c_int()
+    return bool(can.value) if L.lig_device_peer_access(device, peer, C.byref(can)) == 0 else None
 
 
 def shard_plan(job, l, world):
@@ -611,6 +627,8 @@ class Context:
             rp = None
         elif on_device:
             rp = rands
+        elif isinstance(rands, int):              # a raw host address (e.g. a pinned torch tensor's data_ptr()): no copy, no conversion
+            rp = C.c_void_p(rands)
         else:
             rands = np.ascontiguousarray(rands, dtype=np.uint32)
             rp = C.c_void_p(rands.ctypes.data if rands.size else None)

@@ -193,6 +193,9 @@ int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t byt
             for (uint32_t i = 1; i < W; i++) IPC_TRY(r, hipStreamWaitValue32(st, pulled + ((me + i) % W) * RS, (uint32_t)(c - SLOTS), hipStreamWaitValueGte, 0xffffffffu));
         if (total) IPC_TRY(r, hipMemcpyAsync(r->window + slot * SLOT_BYTES, send, total, hipMemcpyDeviceToDevice, st));
     }
+    // slot reuse across my own streams: call c - SLOTS (same slot, possibly another stream) must have written its `pulled` --
+    // which follows its `ready` -- before this call writes `ready <- c`, or a late "ready <- c - SLOTS" would overwrite it
+    if (c > SLOTS) IPC_TRY(r, hipStreamWaitValue32(st, pulled + me * RS, (uint32_t)(c - SLOTS), hipStreamWaitValueGte, 0xffffffffu));
     IPC_TRY(r, hipStreamWriteValue32(st, ready + me * RS, v, 0));
     for (uint32_t i = 0; i < W; i++) {
         const uint32_t h = (me + i) % W;                    // own block first, then the peers in a rotated order (no hot spot)
@@ -284,25 +287,46 @@ int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_
     IpcComm* r = new IpcComm();
     r->ctx = c; r->rank = rank; r->world = world; r->name = shm_name;
     auto bail = [&](const std::string& msg, int code) { c->err = "ipc comm: " + msg; if (r->shm) (void)munmap(r->shm, sizeof(Shm)); delete r; return code; };
-    int fd = -1;
+    // Rank 0 builds the segment under a private name, initialises it and only then gives it the agreed name (rename replaces a
+    // stale segment of that name atomically); a peer that still catches a stale one -- every rank of an earlier communicator has
+    // left it (departed != 0) or it is already full (arrived >= world) -- lets go of it and opens the name again.
     if (rank == 0) {
-        (void)shm_unlink(shm_name);
-        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, sizeof(Shm)) != 0) { if (fd >= 0) close(fd); return bail("shm_open(create) failed", LIG_E_STATE); }
-    } else if (!host_wait([&] { fd = shm_open(shm_name, O_RDWR, 0600); if (fd < 0) usleep(1000); return fd >= 0; })) {
-        return bail("the shared segment never appeared", LIG_E_STATE);
-    }
-    // (rank 0 may have created the name but not sized the segment yet: touching pages beyond the end would raise SIGBUS)
-    if (!host_wait([&] { struct stat sb; return fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(Shm); }, 30)) { close(fd); return bail("segment has the wrong size", LIG_E_STATE); }
-    void* m = mmap(nullptr, sizeof(Shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return bail("mmap failed", LIG_E_STATE);
-    r->shm = static_cast<Shm*>(m);
-    if (rank == 0) {                               // a fresh segment is zero-filled: publication counters and flags start at 0
+        const std::string tmp = std::string(shm_name) + ".new" + std::to_string((long)getpid());
+        (void)shm_unlink(tmp.c_str());
+        int fd = shm_open(tmp.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(Shm)) != 0) { if (fd >= 0) close(fd); (void)shm_unlink(tmp.c_str()); return bail("shm_open(create) failed", LIG_E_STATE); }
+        void* m = mmap(nullptr, sizeof(Shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { (void)shm_unlink(tmp.c_str()); return bail("mmap failed", LIG_E_STATE); }
+        r->shm = static_cast<Shm*>(m);                // a fresh segment is zero-filled: publication counters and flags start at 0
         r->shm->world = world;
         r->shm->magic.store(MAGIC, std::memory_order_release);
-    } else if (!host_wait([&] { return r->shm->magic.load(std::memory_order_acquire) == MAGIC; }) || r->shm->world != world) {
-        return bail("segment not initialised by rank 0 (or another world size)", LIG_E_STATE);
+        const std::string from = "/dev/shm" + tmp, to = std::string("/dev/shm") + shm_name;
+        if (rename(from.c_str(), to.c_str()) != 0) {   // (no /dev/shm view of POSIX shared memory here: fall back to unlink + link by name)
+            (void)shm_unlink(shm_name);
+            (void)shm_unlink(tmp.c_str());
+            return bail("cannot publish the shared segment under its name", LIG_E_STATE);
+        }
+    } else {
+        const auto t0 = clk::now();
+        for (;;) {
+            int fd = shm_open(shm_name, O_RDWR, 0600);
+            struct stat sb;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= sizeof(Shm)) {
+                void* m = mmap(nullptr, sizeof(Shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                close(fd);
+                if (m == MAP_FAILED) return bail("mmap failed", LIG_E_STATE);
+                Shm* sh = static_cast<Shm*>(m);
+                if (sh->magic.load(std::memory_order_acquire) == MAGIC && sh->departed.load() == 0 && sh->arrived.load() < sh->world) {
+                    if (sh->world != world) { (void)munmap(m, sizeof(Shm)); return bail("segment made for another world size", LIG_E_STATE); }
+                    r->shm = sh;
+                    break;
+                }
+                (void)munmap(m, sizeof(Shm));         // stale: rank 0 has not replaced it yet
+            } else if (fd >= 0) close(fd);
+            if (clk::now() - t0 > std::chrono::seconds(HOST_TIMEOUT_S)) return bail("the shared segment never appeared", LIG_E_STATE);
+            usleep(1000);
+        }
     }
     if (hipHostRegister(r->shm->ready, FLAG_BYTES, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess ||
         hipHostGetDevicePointer((void**)&r->ready_dev, r->shm->ready, 0) != hipSuccess)

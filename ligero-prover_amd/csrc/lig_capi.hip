@@ -419,6 +419,15 @@ int lig_verify_release(lig_ctx* c) {
     return LIG_OK;
 }
 
+int lig_device_pci_bus_id(int device, char* out, size_t cap) {
+    if (!out || cap < 16) return LIG_E_ARG;
+    return hipDeviceGetPCIBusId(out, (int)cap, device) == hipSuccess ? LIG_OK : LIG_E_HIP;
+}
+int lig_device_peer_access(int device, int peer, int* can) {
+    if (!can) return LIG_E_ARG;
+    return hipDeviceCanAccessPeer(can, device, peer) == hipSuccess ? LIG_OK : LIG_E_HIP;
+}
+
 int lig_sync(lig_ctx* c) { CHECK_CTX(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return LIG_OK; }
 const char* lig_last_error(const lig_ctx* c) { return c ? c->err.c_str() : "null context"; }
 uint32_t lig_message_size(const lig_ctx* c) { return c ? c->l : 0; }

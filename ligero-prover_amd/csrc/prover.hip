@@ -64,6 +64,8 @@ struct lig_trace {
     volatile uint32_t* up_flag = nullptr; uint32_t* up_flag_dev = nullptr;   // pinned: word ci = sequence number of the last upload whose chunk ci has arrived
     uint32_t up_seq = 0;
     bool up_by_thread = false;
+    size_t up_words = 0;                // words in up_flag: [stage-1 chunks | stage-2 chunks: randomness rows arrived | ... consumed]
+    std::atomic<int> up_abort{0};       // a failed lig_rows_prove: the uploader drops the randomness-row copies it still holds
     std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
     std::atomic<int> up_failed{0};      // hipError_t of a chunk copy that failed (the chunk is published all the same: no stream may hang)
     // narrow row format (lig_rows_job.elem_bytes): packed byte offset of every row (+1 entry), the widths, the device staging
@@ -97,6 +99,13 @@ struct lig_trace {
 };
 
 static void uploader_drain(lig_trace* T);      // (below, with the uploader thread)
+// `wait` (optional): the copy may only start once *wait >= wait_val -- a word in pinned host memory that a stream of the proof writes
+// (hipStreamWriteValue32) when it is done with the destination buffer (the double-buffered randomness rows of stage 2)
+struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed;
+                   const volatile uint32_t* wait = nullptr; uint32_t wait_val = 0; const std::atomic<int>* abort = nullptr; };
+static bool uploader_available(lig_ctx* c);
+static void uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending);
+static int ensure_up_flags(lig_ctx* c, lig_trace* T);
 
 // The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
 // kernel into a temporary + a copy (as vbn254fr_module does), every hook a device-to-device copy of the rows it names
@@ -418,10 +427,36 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && lig::knobs().fused_rlc;
     const bool early_code = lig::knobs().early_code;      // (see below)
     const lig::f29s* rc_loop = early_code ? nullptr : T->coef_dev;      // code coefficients of the row loop (null: accumulated up front)
+    // Caller rows in HOST memory (what a constraint generator delivers, nonbatch_context.hpp:654-780 / mpz_vector.hpp:108-127) take
+    // the road of the witness rows (rows_load): the uploader thread copies chunk after chunk into the double buffer and
+    // publishes each arrival in pinned host memory, the main stream waits for that word in its own queue and writes a second word
+    // when it has consumed a chunk -- which is what the uploader waits for before it overwrites that half of the buffer.  No copy,
+    // event or barrier packet of this transfer ever sits in a queue of the proof (the event-chained copy
+    // on the side stream that this replaces is LIG_UPLOAD_MODE=1, profiles/r04_caller_rands_ab.md).
+    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && uploader_available(c) && n_chunks;
+    uint32_t rseq = 0;
+    size_t rflag0 = 0, uflag0 = 0;
+    if (rands_by_thread) {
+        TRY(ensure_up_flags(c, T));
+        rflag0 = T->sched1.size(); uflag0 = rflag0 + n_chunks;
+        if (uflag0 + n_chunks > T->up_words) FAIL(c, LIG_E_STATE, "rows job: flag page too small for the stage-2 schedule");
+        rseq = ++T->up_seq;
+        T->up_abort.store(0, std::memory_order_release);
+        std::vector<UploadJob> jobs;
+        for (size_t ci = 0; ci < n_chunks; ci++) {
+            const size_t b = sched2[ci].first, nb = sched2[ci].second - b;
+            UploadJob j{(uint8_t*)rand_buf(ci), rs.host + b * (size_t)k * 32, nb * (size_t)k * 32, T->up_flag + rflag0 + ci, rseq, &T->up_failed};
+            if (ci >= 2) { j.wait = T->up_flag + uflag0 + ci - 2; j.wait_val = rseq; }
+            j.abort = &T->up_abort;
+            jobs.push_back(j);
+        }
+        uploader_submit(c->device, jobs, &T->up_pending);
+    }
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
         if (rs.dev) { HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2)); return LIG_OK; }     // used in place
+        if (rands_by_thread) return LIG_OK;                                                     // the uploader thread brings them
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
         if (rs.host) {
             HIP_TRY(c, hipMemcpyAsync(rb, rs.host + b * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, s2));
@@ -479,7 +514,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
-        HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
+        if (rands_by_thread) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + rflag0 + ci, rseq, hipStreamWaitValueGte, 0xffffffffu));
+        else HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         if (c->fast) {
             // coset-2 values of the randomness rows times the coset-2 plane of the codewords, summed per group of rows inside the
             // encoder's output kernel: the values themselves are never written
@@ -490,7 +526,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         }
         // k columns per pass: groups of 16 rows (4x more workgroups than the n-column grouping; same partial-sum space)
         if (!fused_rlc) lig::launch_rlc_accumulate29(s, T->msgs + b * k, k, 1, rb, k, nb, k, rc_loop ? rc_loop + b : nullptr, p_code, p_linH, lig_tune::GROUP / 4);
-        HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
+        if (rands_by_thread) HIP_TRY(c, hipStreamWriteValue32(s, T->up_flag_dev + uflag0 + ci, rseq, 0));      // chunk consumed: its half of the buffer is free
+        else HIP_TRY(c, hipEventRecord(T->ev_used[ci & 1], s));
     }
     {   // one combine per accumulator and proof
         const uint32_t pg = (uint32_t)((lig_tune::CHUNK + lig_tune::GROUP / 4 - 1) / (lig_tune::GROUP / 4));
@@ -649,6 +686,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream);
     (void)hipStreamSynchronize(T->c->stream2);
     (void)hipStreamSynchronize(T->c->stream3);
+    T->up_abort.store(1, std::memory_order_release);      // (copies that wait for a buffer of a proof that never ran)
     uploader_drain(T);                                    // an upload still in flight
     T->c->sha.erase(T->sha_state);
     for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
@@ -697,7 +735,6 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
 // trace waits for that word with a stream memory operation (hipStreamWaitValue32 -- a wait in ITS OWN queue, where it has to
 // wait anyway).  Uploads of all contexts go through the one thread: one at a time, in the order of the calls -- two contexts
 // that alternate keep the link busy without ever sharing it.
-struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed; };
 namespace {
 struct Uploader {
     std::mutex mu;
@@ -712,12 +749,22 @@ struct Uploader {
         for (;;) {
             std::pair<UploadJob, std::atomic<int>*> j;
             {
+                // the first job whose destination is free: a job that waits for its buffer must not hold up the other contexts'
+                // uploads queued behind it (jobs of one trace stay in order: their wait words become true in order)
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !q.empty(); });
-                j = q.front();
-                q.pop_front();
+                for (;;) {
+                    auto it = q.begin();
+                    for (; it != q.end(); ++it) {
+                        const UploadJob& u = it->first;
+                        if (!u.wait || (int32_t)(__atomic_load_n(u.wait, __ATOMIC_ACQUIRE) - u.wait_val) >= 0 || (u.abort && u.abort->load(std::memory_order_acquire))) break;
+                    }
+                    if (it != q.end()) { j = *it; q.erase(it); break; }
+                    if (q.empty()) cv.wait(lk, [&] { return !q.empty(); });
+                    else cv.wait_for(lk, std::chrono::microseconds(20));       // every queued job waits for the GPU: poll
+                }
             }
-            const hipError_t e = j.first.bytes ? hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+            const bool skip = j.first.abort && j.first.abort->load(std::memory_order_acquire);
+            const hipError_t e = (j.first.bytes && !skip) ? hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st) : hipSuccess;
             const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
             // (a failed copy publishes too: no stream may hang on the flag; lig_rows_commit reports the error once stage 1 has drained)
             if (e2 != hipSuccess) { (void)hipGetLastError(); j.first.failed->store((int)e2, std::memory_order_release); }
@@ -756,6 +803,16 @@ static void uploader_submit(int device, const std::vector<UploadJob>& jobs, std:
 static void uploader_drain(lig_trace* T) {
     while (T->up_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
 }
+// pinned flag words of a trace: one per stage-1 chunk (rows arrived), two per stage-2 chunk (caller randomness rows arrived / consumed)
+static int ensure_up_flags(lig_ctx* c, lig_trace* T) {
+    if (T->up_flag) return LIG_OK;
+    T->up_words = T->sched1.size() + 2 * (T->R / lig_tune::CHUNK + 3) + 8;
+    const size_t bytes = (T->up_words * 4 + 4095) & ~(size_t)4095;
+    HIP_TRY(c, hipHostMalloc((void**)&T->up_flag, bytes, hipHostMallocDefault));
+    std::memset((void*)T->up_flag, 0, bytes);
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&T->up_flag_dev, (void*)T->up_flag, 0));
+    return LIG_OK;
+}
 // message rows of a rows job -> T->msgs.  Device rows: one copy on the main stream.  Host rows: the upload starts now, on
 // the copy stream, one event per stage-1 chunk: lig_rows_commit encodes chunk b while chunk b+1 is still on the bus.
 static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device) {
@@ -793,12 +850,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
     // stage 2 5.6 -> 13.8 ms.  The DMA engine it is.)
     const int mode = lig::knobs().upload_mode;   // 2: uploader thread (default), 1: per-context copy stream + events
     if (mode == 2 && uploader_available(c)) {
-        if (!T->up_flag) {
-            HIP_TRY(c, hipHostMalloc((void**)&T->up_flag, 4096, hipHostMallocDefault));
-            std::memset((void*)T->up_flag, 0, 4096);
-            HIP_TRY(c, hipHostGetDevicePointer((void**)&T->up_flag_dev, (void*)T->up_flag, 0));
-            if (T->sched1.size() > 1024) FAIL(c, LIG_E_ARG, "rows job: too many stage-1 chunks");
-        }
+        TRY(ensure_up_flags(c, T));
         T->up_seq++;
         std::vector<UploadJob> jobs;
         for (size_t ci = 0; ci < T->sched1.size(); ci++) {
@@ -928,7 +980,17 @@ int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
     std::memset(&T->info1, 0, sizeof T->info1);
     T->info1.rows = T->R + 3;
     const auto t_begin = clk::now();
-    TRY(prove_stage1(T, &T->info1, make_mark(c)));
+    {
+        const int rc = prove_stage1(T, &T->info1, make_mark(c));
+        if (rc != LIG_OK) {           // the caller is told it may free its rows: nothing of ours may still read them
+            const std::string why = c->err;
+            uploader_drain(T);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            T->loaded = false; T->host_msgs = nullptr;
+            c->err = why;
+            return rc;
+        }
+    }
     T->info1.ms_stage1 = ms_since(t_begin);
     T->committed = true;
     T->loaded = false;
@@ -953,7 +1015,21 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     const auto t_begin = clk::now();
     RandSource rs;                                        // default: generated from the dense counts of the job
     if (rands && rands_on_device) rs.dev = (const fr*)rands; else if (rands) rs.host = (const uint8_t*)rands;
-    TRY(prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c)));
+    {
+        int rc = prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c));
+        const std::string why = c->err;
+        if (rc != LIG_OK) {           // randomness-row copies the uploader thread still holds read the caller's memory: drop them, wait
+            T->up_abort.store(1, std::memory_order_release);
+            uploader_drain(T);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            c->err = why;
+            return rc;
+        }
+        if (rs.host) {
+            uploader_drain(T);
+            if (const int e = T->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
+        }
+    }
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
     T->committed = false;
     return LIG_OK;

@@ -52,6 +52,7 @@ struct lig_shard {
     size_t h_proof_cap = 0;
     uint8_t ih[32] = {0};
     hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr}, ev_hash[2] = {nullptr, nullptr};
+    bool used_comm = false;                    // a collective has been issued with buffers of this shard as send buffers
     bool exchange_even_alone = false;          // LIG_SHARD_FORCE_EXCHANGE: run pack + all-to-all with world == 1 too (tests)
     size_t chunk_rows(size_t g) const { return g < G ? gb[g + 1] - gb[g] : 0; }
 };
@@ -269,7 +270,9 @@ void lig_shard_destroy(lig_shard* S) {
     (void)hipStreamSynchronize(S->c->stream);
     (void)hipStreamSynchronize(S->c->stream2);
     (void)hipStreamSynchronize(S->c->stream3);
-    if (S->comm.forget) S->comm.forget(S->comm.user);       // the send buffers below are about to be freed
+    // the send buffers below are about to be freed.  forget() may be a host collective (comm_ipc): a shard that fails before its
+    // first collective (a local error in *_begin / *_prepare) has exported nothing and must not wait for peers that are not there
+    if (S->comm.forget && S->used_comm) S->comm.forget(S->comm.user);
     S->c->sha.erase(S->sha_state);
     for (void* p : {(void*)S->msgs, (void*)S->cw, (void*)S->maskcw, (void*)S->send, (void*)S->recv, (void*)S->randb, (void*)S->rhalf, (void*)S->acc,
                     (void*)S->parts, (void*)S->accp, (void*)S->accg, (void*)S->dots, (void*)S->smp, (void*)S->smpg, (void*)S->sha_state,
@@ -289,8 +292,9 @@ struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
     const size_t R = S->R, Rl = S->Rl, RM = S->rows_max, ncol = S->ncol, CAP = S->ch_cap; \
     hipStream_t s = c->stream, s_hash = c->stream2, s_comm = c->stream3; \
     const bool ordered = S->comm.all_to_all_on != nullptr && S->comm.all_gather_on != nullptr; \
-    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos && c->err.find("ipc comm") == std::string::npos) c->err = std::string("collective failed: ") + what; else c->err = std::string(what) + ": " + c->err; return (int)LIG_E_STATE; }; \
+    auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos && c->err.find("ipc comm") == std::string::npos && c->err.find("injected fault") == std::string::npos) c->err = std::string("collective failed: ") + what; else c->err = std::string(what) + ": " + c->err; return (int)LIG_E_STATE; }; \
     auto all_gather = [&](const void* src, void* dst, size_t bytes, hipStream_t st, const char* what) -> int { \
+        S->used_comm = true; \
         if (ordered) { if (S->comm.all_gather_on(S->comm.user, src, dst, bytes, st)) return comm_fail(what); return LIG_OK; } \
         HIP_TRY(c, hipStreamSynchronize(st)); \
         if (S->comm.all_gather(S->comm.user, src, dst, bytes)) return comm_fail(what); \
@@ -345,6 +349,7 @@ static int shard_stage1(lig_shard* S, lig_proof_info* info) {
         }
         HIP_TRY(c, hipEventRecord(S->ev_enc[pb], s));
         if (exchange) {
+            S->used_comm = true;
             if (ordered) {
                 HIP_TRY(c, hipStreamWaitEvent(s_comm, S->ev_enc[pb], 0));
                 if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s_comm, S->ev_hash[pb], 0));   // receive buffer free again (hash c-2 done)
@@ -651,6 +656,7 @@ int lig_shard_rows_begin(lig_ctx* c, const lig_rows_job* job, uint32_t rank, uin
     if (!job || !out || !comm || world == 0 || rank >= world) return LIG_E_ARG;
     if (!comm->all_to_all || !comm->all_gather) return LIG_E_ARG;
     if (job->rows && !job->kinds) FAIL(c, LIG_E_ARG, "sharded rows job: null kinds");
+    if (job->elem_bytes) FAIL(c, LIG_E_ARG, "sharded rows job: the narrow row format (elem_bytes) is not supported here, pass full-width rows");
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     if (l >= k || l < 2 || t > n || k - l < t || k % world) FAIL(c, LIG_E_ARG, "sharded trace: need 2 <= l <= k - 192 and world | k");
     *out = nullptr;

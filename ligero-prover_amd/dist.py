@@ -62,44 +62,88 @@ class Group:
         self.dist.all_gather(out, mine)
         return [bytes(o.cpu().tolist()) for o in out]
 
-    # ---- collectives for the sharded prover (include/lig_hip.h: lig_comm).  The C side hands over raw pointers after
-    # synchronising its stream; the callbacks return once the received data is in place.
-    def make_comm(self, pkg, ctx):
-        """pkg = the ligero_prover_amd module, ctx = its Context on this rank's GPU.
-        nccl: the product path -- the library's own RCCL communicator (csrc/comm_rccl.hip: grouped ncclSend/ncclRecv and
-        ncclAllGather enqueued on the context's HIP streams); torch.distributed only carries the 128-byte unique id from
-        rank 0 to the others.  gloo (tests) / no process group: host-synchronous callbacks staged through host memory."""
+    # ---- collectives for the sharded prover (include/lig_hip.h: lig_comm)
+    TRANSPORTS = ("rccl-stream", "rccl-sync", "ipc-stream", "ipc-sync", "torch", "host")
+
+    def default_transport(self):
+        if os.environ.get("LIG_COMM") == "ipc":
+            return "ipc-stream"
+        return "rccl-stream" if self.backend == "nccl" else "host"
+
+    def make_comm(self, pkg, ctx, transport=None):
+        """pkg = the ligero_prover_amd module, ctx = its Context on this rank's GPU.  Transports (bench.py tries them in order):
+          rccl-stream  the product path -- the library's own RCCL communicator (csrc/comm_rccl.hip: grouped ncclSend/ncclRecv
+                       and ncclAllGather enqueued on the context's HIP streams); the process group only carries the
+                       128-byte unique id from rank 0 to the others
+          rccl-sync    the same communicator through its host-synchronous forms (collective, then hipStreamSynchronize):
+                       no stream-ordered overlap, no cross-stream events around RCCL kernels
+          ipc-stream   process-to-process over mapped device memory (csrc/comm_ipc.hip), GPU-ordered on flags in shared memory:
+                       one device shared by all ranks (tests) or one device per rank with peer access
+          ipc-sync     its host-synchronous forms
+          torch        host-synchronous callbacks over torch.distributed's OWN communicator on device memory, zero-copy
+                       (all_to_all_single / all_gather_into_tensor of the backend "nccl" = RCCL inside torch)
+          host         host-synchronous callbacks staged through host memory (gloo; the CPU-side tests) or plain copies (1 rank)
+        Every communicator made here is ended by close(), newest first."""
         import ctypes as C
         import numpy as np
         import torch
         g = self
-        if os.environ.get("LIG_COMM") == "ipc":
-            # the process-to-process communicator (csrc/comm_ipc.hip): peers map each other's send buffers, the GPU orders the
-            # copies on flags in a POSIX shared-memory segment; torch.distributed (any backend) is only the launcher's rendezvous.
-            # Every communicator needs a fresh segment name, the same on all ranks: launcher tag + a per-group counter.
+        transport = transport or self.default_transport()
+        if transport not in self.TRANSPORTS:
+            raise ValueError("unknown transport %r" % (transport,))
+        self.transport = transport
+        if not hasattr(self, "_comms"):
+            self._comms = []
+
+        def sync_only(comm):
+            """a copy of `comm` without the stream-ordered forms: lig_shard_* then takes its host-synchronous branch.  The
+            original stays the handle the library's *_comm_destroy recognises."""
+            c2 = pkg.Comm()
+            C.memmove(C.byref(c2), C.byref(comm), C.sizeof(pkg.Comm))
+            c2.all_to_all_on = pkg.A2A_ON_FN()
+            c2.all_gather_on = pkg.A2A_ON_FN()
+            return c2
+
+        if transport in ("ipc-stream", "ipc-sync"):
+            # torch.distributed (any backend) is only the launcher's rendezvous.  Every communicator needs a fresh segment
+            # name, the same on all ranks: launcher tag + rendezvous port + a per-group counter
             self._ipc_n = getattr(self, "_ipc_n", 0) + 1
             name = "/lig_ipc_%s_%s_%d" % (os.environ.get("LIG_COMM_TAG", "0"), os.environ.get("MASTER_PORT", "0"), self._ipc_n)
             comm = ctx.ipc_comm(name, g.rank, g.world)
-            self._ipc = getattr(self, "_ipc", []) + [(ctx, comm)]
-            return comm
-        if g.backend == "nccl":
+            self._comms.append(("ipc", ctx, comm))
+            return comm if transport == "ipc-stream" else sync_only(comm)
+        if transport in ("rccl-stream", "rccl-sync"):
             uid = ctx.rccl_unique_id() if g.rank == 0 else bytes(128)
             if g.dist is not None:
-                t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+                t = self._tensor(list(uid), torch.uint8)
                 g.dist.broadcast(t, src=0)
                 uid = bytes(t.cpu().tolist())
             comm = ctx.rccl_comm(uid, g.rank, g.world)
-            self._rccl = (ctx, comm)
-            return comm
+            self._comms.append(("rccl", ctx, comm))
+            return comm if transport == "rccl-stream" else sync_only(comm)
 
         def host_of(ptr, nbytes):        # device -> host numpy copy through the library's own stream
             return ctx.download(C.c_void_p(ptr), (nbytes,), dtype=np.uint8)
+
+        class DevBytes:                  # a raw device range as a zero-copy torch tensor (__cuda_array_interface__)
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+        def dev_tensor(ptr, nbytes):
+            return torch.as_tensor(DevBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
+
+        on_device = transport == "torch"
+        if on_device and (g.dist is None or g.backend != "nccl") and g.world > 1:
+            raise ValueError("transport 'torch' needs the nccl (= RCCL) process group")
 
         def all_to_all(user, send, recv, block):
             try:
                 total = block * g.world
                 if g.dist is None:
                     ctx.check(ctx.L.lig_copy(ctx.h, C.c_void_p(recv), C.c_void_p(send), total)); ctx.sync()
+                elif on_device:              # the library drained its stream before the call; torch's stream is drained before we return
+                    g.dist.all_to_all_single(dev_tensor(recv, total), dev_tensor(send, total))
+                    torch.cuda.synchronize()
                 else:                      # gloo has no all_to_all: gather everything, keep the blocks addressed to me
                     mine = torch.from_numpy(host_of(send, total))
                     parts = [torch.empty_like(mine) for _ in range(g.world)]
@@ -115,6 +159,9 @@ class Group:
             try:
                 if g.dist is None:
                     ctx.check(ctx.L.lig_copy(ctx.h, C.c_void_p(recv), C.c_void_p(send), nbytes)); ctx.sync()
+                elif on_device:
+                    g.dist.all_gather_into_tensor(dev_tensor(recv, nbytes * g.world), dev_tensor(send, nbytes))
+                    torch.cuda.synchronize()
                 else:
                     mine = torch.from_numpy(host_of(send, nbytes))
                     parts = [torch.empty_like(mine) for _ in range(g.world)]
@@ -129,17 +176,24 @@ class Group:
         comm.user = None
         comm.all_to_all = pkg.A2A_FN(all_to_all)
         comm.all_gather = pkg.A2A_FN(all_gather)
-        self._keepalive = (all_to_all, all_gather, comm)
+        self._comms.append(("callbacks", ctx, (all_to_all, all_gather, comm)))     # keeps the ctypes thunks alive
         return comm
 
+    def rccl_ranks(self):
+        """ncclCommCount of the newest RCCL communicator made here (None: the transport in use is not RCCL)"""
+        for kind, ctx, comm in reversed(getattr(self, "_comms", [])):
+            if kind == "rccl":
+                return ctx.rccl_comm_count(comm)
+            break
+        return None
+
     def close(self):
-        for ctx, comm in getattr(self, "_ipc", []):
-            ctx.ipc_comm_destroy(comm)
-        self._ipc = []
-        if getattr(self, "_rccl", None):
-            ctx, comm = self._rccl
-            ctx.rccl_comm_destroy(comm)
-            self._rccl = None
+        for kind, ctx, comm in reversed(getattr(self, "_comms", [])):
+            if kind == "ipc":
+                ctx.ipc_comm_destroy(comm)
+            elif kind == "rccl":
+                ctx.rccl_comm_destroy(comm)
+        self._comms = []
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()

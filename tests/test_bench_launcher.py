@@ -67,3 +67,47 @@ def test_under_torch_distributed_run_as_the_driver_launches_it():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["spawned_by_bench"] is False and out["steps"] == 2
+
+
+def _ladder(extra, launcher=None, timeout=300):
+    cmd = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "2", "--warmup", "0", "--sharded-leg",
+           "--sharded-timeout", "10", "--sharded-log2", "24,26"] + extra
+    cmd = (launcher or [sys.executable]) + cmd
+    p = subprocess.run(cmd, env=_env(), capture_output=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_transport_ladder_falls_through_a_dead_rank_and_a_hung_rank():
+    """the sharded leg of `bench.py --gpus N` runs every rung in fresh child processes with their own rendezvous:
+    a rung whose LAST rank exits (the others then fail in their barrier) and a rung whose last rank hangs (every child is killed
+    after --sharded-timeout) are recorded as failed attempts, the third rung delivers, rc stays 0 and the weak figure is intact"""
+    out = _ladder(["--sharded-transports", "stub-fail,stub-hang,stub-ok"])
+    sh = out["sharded"]
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert [a["transport"] for a in sh["attempts"]] == ["stub-fail", "stub-hang", "stub-ok"]
+    assert [a["ok"] for a in sh["attempts"]] == [False, False, True]
+    assert "timeout" in sh["attempts"][1]["this_rank"] and sh["attempts"][0]["stderr_tail"]
+    assert sh["transport"] == "stub-ok" and sh["log2_constraints"] == 26 and sh["ranks"] == 2
+
+
+def test_transport_ladder_with_every_rung_failing_still_prints_the_weak_line():
+    out = _ladder(["--sharded-transports", "stub-fail,stub-fail"])
+    assert out["value"] > 0 and "error" in out["sharded"] and len(out["sharded"]["attempts"]) == 2
+
+
+def test_transport_ladder_time_budget_stops_further_rungs():
+    out = _ladder(["--sharded-transports", "stub-hang,stub-ok", "--sharded-budget", "20"])
+    att = out["sharded"]["attempts"]
+    assert att[0]["ok"] is False and "skipped" in att[1] and "error" in out["sharded"]
+
+
+def test_transport_ladder_under_torch_distributed_run():
+    """the children must not inherit the elastic agent's store (TORCHELASTIC_USE_AGENT_STORE): they rendezvous on their own port"""
+    out = _ladder(["--sharded-transports", "stub-fail,stub-ok"],
+                  launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29963"])
+    assert out["spawned_by_bench"] is False and out["sharded"]["transport"] == "stub-ok"
+    assert [a["ok"] for a in out["sharded"]["attempts"]] == [False, True]

@@ -220,23 +220,101 @@ def test_sharded_configs3_trace_full_size_over_ipc_comm_equals_oracle_pin(tmp_pa
         assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
 
 
-def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_path):
-    """`python bench.py --gpus 2` (its own launcher) with both ranks on the one GPU (LIG_BENCH_SHARE_GPU, collectives =
-    comm_ipc over a gloo rendezvous): the N > 1 code path of the bench -- weak leg on every rank, then ONE trace sharded over
-    the ranks -- prints one JSON line with n_gpus = 2 and a `sharded` object whose envelope equals the oracle pin"""
+def _bench(args, timeout=1200, **envkw):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    env.update(LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-                        "--log2-constraints", "22", "--sharded-log2", "24", "--sharded-steps", "2", "--no-cpu-baseline", "--no-verify"],
-                       env=env, capture_output=True, timeout=900)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **envkw)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, timeout=timeout)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+TWO_ON_ONE = ["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--log2-constraints", "22", "--sharded-steps", "2",
+              "--no-cpu-baseline", "--no-verify"]
+
+
+def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_path):
+    """`python bench.py --gpus 2` (its own launcher) with both ranks on the one GPU (LIG_BENCH_SHARE_GPU, collectives =
+    comm_ipc over a gloo rendezvous): the N > 1 code path of the bench -- weak leg on every rank, preflight, then ONE trace
+    sharded over the ranks in child processes, at two sizes -- prints one JSON line with n_gpus = 2 and a `sharded` object whose
+    envelope equals the oracle pin, delivered by the first rung of the ladder"""
+    out = _bench(TWO_ON_ONE + ["--sharded-log2", "22,24"], LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()))
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     sh = out["sharded"]
     assert sh["ranks"] == 2 and sh["log2_constraints"] == 24 and sh["scaling"] == "strong"
     assert sh["proof_equals_oracle_pin"] is True and sh["all_ranks_same_envelope"] is True
+    assert sh["transport"] == "ipc-stream" and [a["ok"] for a in sh["attempts"]] == [True]
+    assert out["sharded_2p22"]["all_ranks_same_envelope"] is True and out["sharded_2p22"]["ranks"] == 2
+    pre = out["preflight"]
+    assert len(pre["pci_bus_ids"]) == 2 and pre["distinct_devices"] is False         # (both ranks share the one device here, and the line says so)
+    assert pre["hsa_enable_ipc_mode_legacy"] == "0" and pre["rccl"]["available"] is True
+
+
+@pytest.mark.parametrize("fault,delivered_by,failed", [
+    ("1", "ipc-sync", ["ipc-stream"]),                  # the stream-ordered all-to-all errors out on every rank
+    ("2", "host", ["ipc-stream", "ipc-sync"]),          # ... and so does the host-synchronous form of the same communicator
+    ("3", "ipc-sync", ["ipc-stream"]),                  # the first rung HANGS (host side): its children are killed at the timeout
+])
+def test_bench_ladder_falls_through_an_injected_transport_failure_with_two_real_ranks(tmp_path, fault, delivered_by, failed):
+    """a failure of the first rung (LIG_FAULT_COMM: injected in the library's communicators) must not cost the
+    measurement -- the ladder falls through to the next rung, which still produces the oracle pin's envelope on both ranks"""
+    out = _bench(TWO_ON_ONE + ["--sharded-log2", "24", "--sharded-timeout", "60" if fault == "3" else "180"],
+                 LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()), LIG_FAULT_COMM=fault)
+    sh = out["sharded"]
+    assert out["value"] > 0 and sh["transport"] == delivered_by
+    assert [a["transport"] for a in sh["attempts"] if not a["ok"]] == failed
+    assert sh["proof_equals_oracle_pin"] is True and sh["all_ranks_same_envelope"] is True
+    if fault == "3":
+        assert "timeout" in sh["attempts"][0]["this_rank"]
+    else:
+        assert "injected fault" in sh["attempts"][0]["stderr_tail"]
+
+
+def test_bench_ladder_on_the_real_rccl_library_with_one_rank(tmp_path):
+    """the product's first two rungs on librccl itself (all a one-GPU box can run: one rank, exchange forced on): with the
+    stream-ordered all-to-all failing, the host-synchronous forms of the same RCCL communicator deliver the pin"""
+    out = _bench(["--steps", "2", "--warmup", "1", "--log2-constraints", "22", "--sharded-leg", "--sharded-log2", "24", "--sharded-steps", "2",
+                  "--no-cpu-baseline", "--no-verify", "--no-h2d"], LIG_SHARD_FORCE_EXCHANGE="1", LIG_FAULT_COMM="1")
+    sh = out["sharded"]
+    assert [(a["transport"], a["ok"]) for a in sh["attempts"]] == [("rccl-stream", False), ("rccl-sync", True)]
+    assert sh["transport"] == "rccl-sync" and sh["rccl_ranks"] == 1 and sh["proof_equals_oracle_pin"] is True
+    assert out["preflight"]["distinct_devices"] is True
+
+
+def test_torch_transport_zero_copy_on_device_buffers_one_rank(tmp_path):
+    """the third rung (`torch`: torch.distributed's own RCCL communicator on the library's device buffers, zero-copy through
+    __cuda_array_interface__) with one rank: all_to_all_single / all_gather_into_tensor on raw device pointers"""
+    script = tmp_path / "torch_rung.py"
+    script.write_text(textwrap.dedent('''
+        import hashlib, importlib.util, json, os, sys
+        root = sys.argv[1]
+        def load(name, rel):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
+            m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+        pkg = load("ligero_prover_amd", "__init__.py")
+        dist = load("lig_dist", "dist.py")
+        import torch
+        torch.cuda.set_device(0)
+        g = dist.Group("nccl", force_init=True)
+        ctx = pkg.Context(320, 512, 2048, device=0)
+        job = pkg.Context.make_job(320 * 1500 + 7, 330, generated_at=77)
+        comm = g.make_comm(pkg, ctx, "torch")
+        sh = ctx.shard_prepare(job, 0, 1, comm)
+        proof, info = ctx.shard_prove(sh)
+        ctx.shard_destroy(sh)
+        tr = ctx.synth_prepare_job(job)
+        ref, _ = ctx.synth_prove(tr)
+        ctx.trace_destroy(tr)
+        print(json.dumps({"same": proof == ref, "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
+        ctx.close(); g.close()
+    '''))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               LIG_SHARD_FORCE_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert out == {"same": True, "valid": [1, 1, 1]}
 
 
 ROWS_WORKER = textwrap.dedent('''
