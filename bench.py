@@ -83,14 +83,20 @@ class FullWorkload:
     envelope) are covered by the other proof's GPU work.  Default 1: a step is one proof, start to finish."""
     name = "full"
 
-    def __init__(self, ctx, constraints, pkg=None, inflight=1, device=0):
+    def __init__(self, ctx, constraints, pkg=None, inflight=1, device=0, quad_percent=0):
         self.ctx = ctx
         self.constraints_per_trace = constraints
         self.inflight = inflight
         self.constraints = constraints * inflight
+        # quad_percent > 0: that share of the constraints are quadratic slots x*y = z (three committed rows x, y, z per l of them,
+        # each with its dense randomness row in this synthetic stream, plus the quadratic test: nonbatch_context.hpp:771-780),
+        # the rest linear -- SURVEY.md 8(d)'s optional mix
+        self.quad_percent = quad_percent
+        self.n_quad = (constraints * quad_percent) // 100
+        self.n_lin = constraints - self.n_quad
         self.ctxs = [ctx] + [pkg.Context(L_, K_, N_, device=device) for _ in range(inflight - 1)]
-        self.traces = [c.synth_prepare(constraints, 0, synth_seed=1, generated_at=0) for c in self.ctxs]
-        self.rows = -(-constraints // L_)
+        self.traces = [c.synth_prepare(self.n_lin, self.n_quad, synth_seed=1, generated_at=0) for c in self.ctxs]
+        self.rows = -(-self.n_lin // L_) + 3 * -(-self.n_quad // L_)
         self.last = None
         self.pool = None
         if inflight > 1:
@@ -138,6 +144,9 @@ class FullWorkload:
                          "sampling + envelope), witness matrix resident in HBM"
                          % ("configs[2]: " if lg == 24 else "configs[3] trace on one GPU: " if lg == 26 else "", lg),
              "rows": self.rows + 3, "l": L_, "k": K_, "n": N_, "sample_size": T_, "proofs_in_flight": self.inflight}
+        if self.quad_percent:
+            d.update(n_linear=self.n_lin, n_quad=self.n_quad,
+                     workload=d["workload"].replace("full proof", "%d %% quadratic constraints (x*y = z slots, 3 committed rows per %d), full proof" % (self.quad_percent, L_)))
         if self.last:
             proof = C.string_at(self.last[0], self.last[1])               # after the timed region
             d.update(proof_bytes=len(proof), proof_sha256=hashlib.sha256(proof).hexdigest(),
@@ -146,7 +155,7 @@ class FullWorkload:
             # outside the timed region: the HIP verifier on that proof (informational; --no-verify skips it so that a
             # profiler run of this command sees the prover's kernel launches only)
             pkg = sys.modules["ligero_prover_amd"]
-            job = pkg.Context.make_job(self.constraints_per_trace, 0, synth_seed=1, generated_at=0)
+            job = pkg.Context.make_job(self.n_lin, self.n_quad, synth_seed=1, generated_at=0)
             info = self.last_info
             if not NO_VERIFY:
                 self.ctx.synth_verify(job, None, proof)            # first call: its buffers are allocated right after the workloads freed theirs
@@ -158,7 +167,7 @@ class FullWorkload:
                     if best is None or v.ms_total < best[0]:
                         best = (v.ms_total, wall, bool(v.accept))
                 d.update(verifier_accepts=best[2], verify_ms=best[0], verify_ms_with_python_copies=best[1])
-            pin_path = os.path.join(ROOT, "tests", "golden", "full_pin_2p%d.json" % lg)
+            pin_path = os.path.join(ROOT, "tests", "golden", "full_pin_2p%d%s.json" % (lg, "_q%d" % self.quad_percent if self.quad_percent else ""))
             if os.path.exists(pin_path):                      # the oracle's reference-structured prover on this exact job
                 with open(pin_path) as f:
                     pin = json.load(f)
@@ -645,20 +654,32 @@ def cpu_baseline(workload_name, budget_s=20.0):
             raise SystemExit("CPU baseline prover failed its self-check")
         return rows * L_ / sum(stages), stages, wall
     import resource
-    v1, st1, wall1 = run(8, 1)
-    est_row_s = sum(st1) / 8
+    # per-proof constants (3 mask encodes per stage, 3 decodes, the Merkle tree, the seed hashes): an empty statement is exactly that
+    _, st0_1, _ = run(0, 1)
+    _, st0_a, _ = run(0, cores)
+    rows1 = 64                            # >= 64 rows on ONE thread: the constants are < 5 % of the sample (8 rows made the per-core rate look 15 % low)
+    v1_raw, st1, wall1 = run(rows1, 1)
+    v1 = rows1 * L_ / max(sum(st1) - sum(st0_1), 1e-9)
+    est_row_s = (sum(st1) - sum(st0_1)) / rows1
     rows = int(min(2098, max(64, 8 * cores, 0.5 * budget_s * cores / max(est_row_s, 1e-6))))      # >= 8 rows per thread, ~budget_s / 2 of wall time
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
-    va, sta, walla = run(rows, cores)
+    va_raw, sta, walla = run(rows, cores)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(walla, 1e-9)
-    return {"value": va, "unit": "constraints/s", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
+    va = rows * L_ / max(sum(sta) - sum(st0_a), 1e-9)          # marginal rate: rows per second beyond the per-proof constants
+    # what a full 2^24-constraint proof would take at these rates: constants + 2098 rows at the marginal rate
+    full = (1 << 24) / (sum(st0_a) + 2098 * (sum(sta) - sum(st0_a)) / rows)
+    return {"value": full, "unit": "constraints/s", "cores": cores, "kind": "port", "logical_cpus": os.cpu_count(),
             "cpu_seconds_per_wall_second": busy,
-            "value_allcores": va, "value_1thread": v1, "value_1thread_x_cores": v1 * cores, "parallel_efficiency": va / (v1 * cores),
+            "value_allcores": full, "value_allcores_sample_raw": va_raw, "marginal_allcores": va, "marginal_1thread": v1, "value_1thread": v1,
+            "value_1thread_sample_raw": v1_raw, "value_1thread_x_cores": v1 * cores, "parallel_efficiency": va / (v1 * cores),
+            "per_proof_constants_s": {"1thread": sum(st0_1), "allcores": sum(st0_a)},
             "sample": "full 3-stage proof of %d rows (%d constraints) of k=8192 on %d threads: %.2f s in the stages (%.2f/%.2f/%.2f; %.2f s "
                       "wall incl. synthetic row forming), reference structure (every row re-encoded per stage, per-row hash / accumulator "
-                      "passes), OpenMP over rows / column blocks; 1-thread run: 8 rows in %.2f s; 1-thread encode %.1f ms/row"
-                      % (rows, rows * L_, cores, sum(sta), sta[0], sta[1], sta[2], walla, sum(st1), 1e3 * t_row)}
+                      "passes), OpenMP over rows / column blocks; 1-thread run: %d rows in %.2f s; per-proof constants (an empty statement: masks, "
+                      "decodes, Merkle) %.2f s on one thread / %.2f s on all, subtracted for the marginal rates and the parallel efficiency; "
+                      "`value` = 2^24 constraints / (constants + 2098 rows at the all-thread marginal rate); 1-thread encode %.1f ms/row"
+                      % (rows, rows * L_, cores, sum(sta), sta[0], sta[1], sta[2], walla, rows1, sum(st1), sum(st0_1), sum(st0_a), 1e3 * t_row)}
 
 
 def main():
@@ -682,6 +703,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed, informational) HIP verifier run on the last proof")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive second measurement (value_incl_h2d)")
+    ap.add_argument("--quad-percent", type=int, default=0, help="main measurement: this share of the constraints quadratic (default 0: configs[2] is all linear)")
+    ap.add_argument("--quad-mix", type=int, default=50, help="N = 1: a second, shorter measurement with this share of quadratic constraints, "
+                    "reported as `quad_mix` beside `value` (0: skip)")
     ap.add_argument("--no-h2d-rands", action="store_true", help="skip the leg that also ships the caller's randomness rows from host memory")
     ap.add_argument("--h2d-inflight", type=int, default=2, help="contexts alternating in the PCIe-inclusive measurement: each pipelines "
                     "upload i+1 under proof i, the uploads of all contexts go through one uploader thread (one at a time), so two "
@@ -728,7 +752,8 @@ def main():
     if a.workload == "sharded":
         wl = ShardedWorkload(ctx, 1 << log2c, group, pkg)
     else:
-        wl = FullWorkload(ctx, 1 << log2c, pkg, max(1, a.inflight), local_rank) if a.workload == "full" else EncodeWorkload(ctx, 1 << log2c)
+        wl = (FullWorkload(ctx, 1 << log2c, pkg, max(1, a.inflight), local_rank, quad_percent=a.quad_percent) if a.workload == "full"
+              else EncodeWorkload(ctx, 1 << log2c))
 
     def fence():
         group.barrier()
@@ -760,6 +785,28 @@ def main():
     # context holds three HIP streams, and idle streams still occupy slots of the 4 hardware queues the next leg's streams map to
     wl_desc = wl.describe() if rank == 0 else None
     wl.close()
+
+    # the quadratic mix (optional): the same number of constraints, half of them quadratic -- three committed rows
+    # per 8000 quadratic slots instead of one, so constraints/s differs from the all-linear figure by up to 3x
+    quad_mix = None
+    if a.workload == "full" and a.quad_mix and not a.quad_percent and world == 1:
+        try:
+            qw = FullWorkload(ctx, 1 << log2c, pkg, max(1, a.inflight), local_rank, quad_percent=a.quad_mix)
+            qw.run(2)
+            fence()
+            t0 = time.perf_counter()
+            qw.run(a.steps)
+            fence()
+            dtq = time.perf_counter() - t0
+            qd = qw.describe()
+            quad_mix = {"value": qw.constraints * a.steps / dtq, "unit": "constraints/s", "ms_per_step": 1e3 * dtq / a.steps, "quad_percent": a.quad_mix,
+                        "n_linear": qw.n_lin, "n_quad": qw.n_quad, "rows": qd["rows"], "proofs_in_flight": qw.inflight,
+                        "rows_per_s": (qw.rows + 3) * qw.inflight * a.steps / dtq,
+                        "proof_sha256": qd.get("proof_sha256"), "proof_equals_oracle_pin": qd.get("proof_equals_oracle_pin"),
+                        "verifier_accepts": qd.get("verifier_accepts"), "stage_ms": qd.get("stage_ms")}
+            qw.close()
+        except (RuntimeError, MemoryError, pkg.LigError) as e:
+            sys.stderr.write("quadratic-mix leg skipped: %r\n" % (e,))
 
     # PCIe-inclusive figure: the same proofs with the witness matrix starting in pinned host memory (caller-rows entry)
     incl = None
@@ -927,6 +974,8 @@ def main():
                 pass
         out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the bench contract of this repo: the PCIe-inclusive rate "
                                    "is never `value`); SURVEY 8(d)'s H2D-inclusive figure is value_incl_h2d, measured in the same run")
+        if quad_mix is not None:
+            out["quad_mix"] = quad_mix
         if incl is not None:
             out["value_incl_h2d"] = incl["value"]
             out["incl_h2d"] = incl

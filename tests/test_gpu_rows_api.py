@@ -238,13 +238,14 @@ def test_full_size_600_rows_against_oracle_on_host_cores(amd):
     assert proof == want["proof"]
 
 
-@pytest.mark.parametrize("lg", [24, 26])
+@pytest.mark.parametrize("lg", [24, 26, "24_q50"])
 def test_full_size_proof_equals_oracle_pin(amd, lg):
     """the exact bench.py jobs -- configs[2]: 2^24 linear constraints, and the configs[3] trace of 2^26 constraints on one
     GPU (k = 8192, synthetic seed 1, encoding seed 0..31, generated_at 0): the envelope's SHA-256, root, seeds, constant and
     sample indices equal tests/golden/full_pin_2p<lg>.json, which the oracle's reference-structured prover produced
     (tests/golden/make_full_pin.py: 68 s / 277 s on the build container's cores)"""
-    with open(os.path.join(GOLD, "full_pin_2p%d.json" % lg)) as f:
+    # "24_q50": the quadratic mix of SURVEY.md 8(d) -- 2^23 linear + 2^23 quadratic constraints (bench.py's `quad_mix` leg)
+    with open(os.path.join(GOLD, "full_pin_2p%s.json" % lg)) as f:
         pin = json.load(f)
     c = amd.Context(pin["l"], pin["k"], pin["n"])
     try:
