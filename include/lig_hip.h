@@ -58,6 +58,10 @@ int lig_write_clear(lig_ctx *ctx, void *dst, size_t dst_bytes, const void *host_
 int lig_clear(lig_ctx *ctx, void *dst, size_t bytes);
 int lig_copy(lig_ctx *ctx, void *dst, const void *src, size_t bytes);
 int lig_read(lig_ctx *ctx, void *host_dst, const void *src, size_t bytes);   /* blocking */
+/* page-locked host memory for rows a driver hands to lig_rows_* (uploads from it are true DMA transfers; from pageable memory
+ * the runtime stages every copy).  Replaces the std::vector `limbs_` staging of include/zkp/nonbatch_context.hpp:447. */
+int lig_host_alloc(lig_ctx *ctx, size_t bytes, void **host_ptr);
+int lig_host_free(lig_ctx *ctx, void *host_ptr);
 
 /* ---- Reed-Solomon transforms on ONE n-element buffer, in place
  * (encode_ntt_device / decode_ntt_device / ntt_{forward,inverse}_{k,2k,n}: engine.cpp:755-968) */
@@ -272,6 +276,12 @@ int lig_rows_commit(lig_trace *trace, uint8_t root[32], uint8_t stage1_seed[32])
  * are the rows themselves, like the synthetic stream; the prover's own linear self-check is then vacuous. */
 int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, const uint8_t *const_sum,
                    const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+/* Randomness rows handed over WHILE the constraint generator is still producing them (the reference's stage-2 callbacks deliver
+ * one row at a time, include/zkp/nonbatch_context.hpp:654-712): after lig_rows_commit, rows [first_row, first_row + n_rows) of the
+ * rows x k randomness matrix, in order and without gaps from row 0; host memory (page-locked: lig_host_alloc), valid until
+ * lig_rows_prove returns.  The upload starts at once (the library's uploader thread) into a device-resident matrix.  When all
+ * rows have been pushed, lig_rows_prove(rands = NULL) uses them: stage 2 waits chunk by chunk for what is still on the bus. */
+int lig_rows_push_rands(lig_trace *trace, uint64_t first_row, uint64_t n_rows, const void *host_rows);
 /* the next trace of the same shape (same kinds, seeds, metadata) with new message rows, reusing every buffer of `trace`
  * (no allocation on the proving path of a service); same upload semantics as lig_rows_begin.  It may be called right
  * after lig_rows_commit, BEFORE lig_rows_prove of the committed trace: the new rows then go to a second message matrix

@@ -19,6 +19,12 @@
 // (include/util/mpz_vector.hpp:108-127; nonbatch_context.hpp:447); batch rows are device rows of the vbn254fr slab.
 // The three mask rows arrive through mask_callback upstream; the library forms the identical rows itself from the
 // encoding seed (same stream, same position: after the pads of all rows), so mask_callback only checks sizes.
+//
+// Data path (round 4): rows are written ONCE, into page-locked staging (lig_host_alloc; `next_slot()` lets a driver export a
+// row's limbs straight into it), the staging is kept for the next pass and the next proof (`reset()`), `commit()` uploads
+// from it chunk by chunk under the encodes, and in pass 2 every 256 completed randomness rows are handed to the library at
+// once (lig_rows_push_rands) -- their upload runs while the guest is still producing the next ones, `prove()` only waits for
+// the tail.  tests/cpp/row_batcher_bench.cpp measures it (profiles/r04_row_batcher_bench.md).
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -41,13 +47,47 @@ struct hip_proof_meta {
     // encoding stream at the row's position (witness_manager::pad_encoding_random, witness_manager.hpp:323-336, keyed by
     // encoding_seed): the library draws the same elements the row arrived with.
     bool narrow_rows = false;
+    // Rows the guest is expected to commit (0: unknown).  The staging is page-locked memory that grows geometrically when the
+    // guest outruns it; a driver that proves the same program again (or knows its size) saves the re-allocations.
+    size_t expected_rows = 0;
+};
+
+// Page-locked host staging for rows of k x 4 u64 (lig_host_alloc): the callbacks write rows straight into it -- no pageable
+// std::vector, no second copy at commit() -- and it is kept for the next pass and the next proof (reset()).
+class hip_row_staging {
+public:
+    hip_row_staging(lig_ctx* ctx, size_t row_words) : ctx_(ctx), words_(row_words) {}
+    hip_row_staging(const hip_row_staging&) = delete;
+    hip_row_staging& operator=(const hip_row_staging&) = delete;
+    ~hip_row_staging() { if (base_) (void)lig_host_free(ctx_, base_); }
+    uint64_t* row(size_t r) { return base_ + r * words_; }
+    const uint64_t* data() const { return base_; }
+    size_t capacity() const { return cap_; }
+    // room for `rows` rows; the first `keep` rows survive a re-allocation
+    void reserve(size_t rows, size_t keep) {
+        if (rows <= cap_) return;
+        size_t want = cap_ ? cap_ : 64;
+        while (want < rows) want += want < 4096 ? want : 4096;         // double up to 4096 rows (1 GiB at k = 8192), then 1 GiB steps
+        void* p = nullptr;
+        if (lig_host_alloc(ctx_, want * words_ * 8, &p) != LIG_OK) throw std::runtime_error(std::string("lig_host_alloc: ") + lig_last_error(ctx_));
+        if (keep) std::memcpy(p, base_, keep * words_ * 8);
+        if (base_) (void)lig_host_free(ctx_, base_);
+        base_ = static_cast<uint64_t*>(p);
+        cap_ = want;
+    }
+private:
+    lig_ctx* ctx_;
+    size_t words_, cap_ = 0;
+    uint64_t* base_ = nullptr;
 };
 
 class hip_row_batcher {
 public:
     hip_row_batcher(lig_ctx* ctx, hip_proof_meta meta)
-        : ctx_(ctx), meta_(std::move(meta)), k_(lig_padding_size(ctx)), l_(lig_message_size(ctx)) {
+        : ctx_(ctx), meta_(std::move(meta)), k_(ctx ? lig_padding_size(ctx) : 0), l_(ctx ? lig_message_size(ctx) : 0),
+          rows_(ctx, (size_t)k_ * 4), rands_(ctx, (size_t)k_ * 4) {
         if (!ctx_) throw std::invalid_argument("hip_row_batcher: null context");
+        if (meta_.expected_rows) rows_.reserve(meta_.expected_rows, 0);
     }
     hip_row_batcher(const hip_row_batcher&) = delete;
     hip_row_batcher& operator=(const hip_row_batcher&) = delete;
@@ -68,6 +108,17 @@ public:
                             const uint64_t* y_rand = nullptr, const uint64_t* z_rand = nullptr) {
         row(LIG_ROW_QX, x, x_rand); row(LIG_ROW_QY, y, y_rand); row(LIG_ROW_QZ, z, z_rand);
     }
+    // The same callbacks without the copy: where the reference exports a row's limbs into its `limbs_` vector
+    // (mpz_vector::export_limbs, nonbatch_context.hpp:447 / :657-663) an integrated driver exports them straight into the slot --
+    // k x 4 u64 of page-locked staging -- and then commits the slot.  Pass 1: the slot of the next message row; pass 2: the slot
+    // of the next row's randomness row (nullptr for a row this rank does not own when sharded: nothing to export).
+    uint64_t* next_slot() {
+        if (pass_ == 1) { rows_.reserve(kinds_.size() + 1, kinds_.size()); return rows_.row(kinds_.size()); }
+        if (pass_ != 2 || next_ >= kinds_.size()) throw std::logic_error("hip_row_batcher::next_slot: no row expected");
+        const size_t slot = sharded_ ? local_of_[next_] : next_;
+        return slot == (size_t)-1 ? nullptr : rands_.row(slot);
+    }
+    void commit_slot(uint8_t kind) { row(kind, pass_ == 1 ? rows_.row(kinds_.size()) : nullptr, nullptr, true); }
     void mask_callback(size_t code_size, size_t linear_size, size_t quad_size) const {
         if (code_size != k_ || linear_size != 2 * (size_t)k_ || quad_size != 2 * (size_t)k_) throw std::invalid_argument("mask_callback: unexpected mask sizes");
     }
@@ -76,10 +127,15 @@ public:
     // (pad_encoding_random) and writes them INTO the variable at slot message_size, then commits the row -- the pad is part of
     // the variable from then on and flows into every batch row derived from it.  Every stage re-runs the guest with the
     // encoding engine re-seeded, so pass 2 writes the same 192 elements again.
-    void on_batch_init(void* dev_x) {
+    void on_batch_init(void* dev_x) { on_batch_init(dev_x, static_cast<uint8_t*>(dev_x) + (size_t)l_ * 32); }
+    // `pad_dst`: where the 192 pad elements go.  The declared semantics of buffer_view::slice put them into x's own pad slots
+    // (the overload above); upstream's buffer_view::slice_bytes as DEFINED (src/webgpu/buffer_view.cpp:91-95 swaps its parameters)
+    // puts them at byte l * 32 of the whole variable slab, i.e. into variable 0 -- hip_context's upstream_slice_compat mode hands
+    // that address in.
+    void on_batch_init(void* dev_x, void* pad_dst) {
         if (pass_ != 1 && pass_ != 2) throw std::logic_error("hip_row_batcher: callback after prove");
         if (k_ - l_ != init_pad) throw std::invalid_argument("hip_row_batcher::on_batch_init: k - l must be params::sample_size (192)");
-        check(lig_rng_fill(ctx_, meta_.encoding_seed, enc_pos_, static_cast<uint8_t*>(dev_x) + (size_t)l_ * 32, init_pad), "lig_rng_fill(init pad)");
+        check(lig_rng_fill(ctx_, meta_.encoding_seed, enc_pos_, pad_dst, init_pad), "lig_rng_fill(init pad)");
         enc_pos_ += init_pad;
         dev_row(LIG_ROW_INIT, dev_x);
     }
@@ -102,34 +158,6 @@ public:
         job.kinds = kinds_.data();
         job.msgs = rows_.data();
         job.msgs_on_device = 0;
-        if (sharded_) { commit_sharded(job, args, lens, root, stage1_seed); return; }
-        std::vector<uint8_t> widths, packed;
-        if (meta_.narrow_rows) {
-            const size_t R = kinds_.size(), words = (size_t)k_ * 4;
-            widths.assign(R ? R : 1, 32);
-            bool any = false;
-            for (size_t r = 0; r < R; r++) {
-                if (kinds_[r] > LIG_ROW_QZ) continue;                       // batch rows are device rows of full width
-                const uint64_t* row = rows_.data() + r * words;
-                bool fits = true;
-                for (uint32_t i = 0; i < l_ && fits; i++) fits = !(row[4 * i + 1] | row[4 * i + 2] | row[4 * i + 3]);
-                if (fits) { widths[r] = 8; any = true; }
-            }
-            if (any) {
-                for (size_t r = 0; r < R; r++) {
-                    const uint64_t* row = rows_.data() + r * words;
-                    if (widths[r] == 8) {
-                        kinds_[r] |= LIG_ROW_DRAW_PAD;
-                        for (uint32_t i = 0; i < l_; i++) { const uint8_t* b = reinterpret_cast<const uint8_t*>(row + 4 * i); packed.insert(packed.end(), b, b + 8); }
-                    } else {
-                        const uint8_t* b = reinterpret_cast<const uint8_t*>(row);
-                        packed.insert(packed.end(), b, b + words * 8);
-                    }
-                }
-                job.msgs = packed.data();
-                job.elem_bytes = widths.data();
-            }
-        }
         std::memcpy(job.encoding_seed, meta_.encoding_seed, 32);
         std::memcpy(job.program_hash, meta_.program_hash, 32);
         job.generated_at = meta_.generated_at;
@@ -137,96 +165,157 @@ public:
         job.public_args = args.empty() ? nullptr : args.data();
         job.public_arg_lens = lens.empty() ? nullptr : lens.data();
         job.n_public_args = lens.size();
-        check(lig_rows_begin(ctx_, &job, &trace_), "lig_rows_begin");
+        if (sharded_) { commit_sharded(job, root, stage1_seed); return; }
+        std::vector<uint8_t> widths;
+        if (meta_.narrow_rows) {
+            // packed IN PLACE: a narrow row shrinks to l x 8 bytes, rows only ever move towards the front of the staging
+            const size_t R = kinds_.size(), words = (size_t)k_ * 4;
+            widths.assign(R ? R : 1, 32);
+            bool any = false;
+            for (size_t r = 0; r < R; r++) {
+                if (kinds_[r] > LIG_ROW_QZ) continue;                       // batch rows are device rows of full width
+                const uint64_t* rw = rows_.row(r);
+                bool fits = true;
+                for (uint32_t i = 0; i < l_ && fits; i++) fits = !(rw[4 * i + 1] | rw[4 * i + 2] | rw[4 * i + 3]);
+                if (fits) { widths[r] = 8; any = true; }
+            }
+            if (any) {
+                uint64_t* out = rows_.row(0);
+                for (size_t r = 0; r < R; r++) {
+                    const uint64_t* rw = rows_.row(r);
+                    if (widths[r] == 8) {
+                        kinds_[r] |= LIG_ROW_DRAW_PAD;
+                        for (uint32_t i = 0; i < l_; i++) out[i] = rw[4 * i];
+                        out += l_;
+                    } else {
+                        if (out != rw) std::memmove(out, rw, words * 8);
+                        out += words;
+                    }
+                }
+                job.elem_bytes = widths.data();
+            }
+        }
+        if (trace_) {                                      // the next proof of the same program: every device buffer is reused
+            if (same_shape(job)) check(lig_rows_restart(trace_, job.msgs, 0), "lig_rows_restart");
+            else { lig_trace_destroy(trace_); trace_ = nullptr; }
+        }
+        if (!trace_) check(lig_rows_begin(ctx_, &job, &trace_), "lig_rows_begin");
+        shape_kinds_ = kinds_; shape_widths_ = widths; shape_meta_ = meta_;
         check(lig_rows_commit(trace_, root, stage1_seed), "lig_rows_commit");
         for (auto& kd : kinds_) kd &= 0x7f;               // (pass 2 compares plain kinds)
-        rows_.clear(); rows_.shrink_to_fit();            // the message rows are resident on the device now
-        rands_.assign(kinds_.size() * (size_t)k_ * 4, 0);
-        pass_ = 2; next_ = 0; enc_pos_ = 0;              // the guest's second run starts the encoding stream over
+        begin_pass2(kinds_.size());
     }
 
     // ---- end of pass 2: stages 2 + 3 on the GPU.  const_sum = the public constant of the linear test, 32 bytes little
     // endian (linear_sums(), src/webgpu_prover.cpp:307).  The returned bytes are the serialized LigeroProofEnvelope
-    // (owned by the batcher, valid until it is destroyed); `info` (optional) receives the prover's self-check.
+    // (owned by the batcher, valid until it is destroyed or reset); `info` (optional) receives the prover's self-check.
     const uint8_t* prove(const uint8_t const_sum[32], size_t* proof_len, lig_proof_info* info = nullptr) {
         if (pass_ != 2) throw std::logic_error("hip_row_batcher::prove before commit");
         if (next_ != kinds_.size()) throw std::logic_error("hip_row_batcher::prove: pass 2 replayed " + std::to_string(next_) + " of " + std::to_string(kinds_.size()) + " rows");
         const uint8_t* proof = nullptr;
         lig_proof_info local;
         if (sharded_) check(lig_shard_rows_prove(shard_, rands_.data(), 0, const_sum, &proof, proof_len, info ? info : &local), "lig_shard_rows_prove");
-        else check(lig_rows_prove(trace_, rands_.data(), 0, const_sum, &proof, proof_len, info ? info : &local), "lig_rows_prove");
+        else {
+            push_rands(kinds_.size());                     // the tail; everything else went out while the guest was running
+            check(lig_rows_prove(trace_, nullptr, 0, const_sum, &proof, proof_len, info ? info : &local), "lig_rows_prove");
+        }
         pass_ = 3;
         return proof;
+    }
+    // the next proof with this batcher: staging and (for the same row kinds) every device buffer of the trace are kept
+    void reset(const hip_proof_meta* meta = nullptr) {
+        if (pass_ == 2) throw std::logic_error("hip_row_batcher::reset between commit and prove");
+        if (meta) meta_ = *meta;
+        kinds_.clear();
+        pass_ = 1; next_ = 0; enc_pos_ = 0; pushed_ = 0;
     }
     size_t rows() const { return kinds_.size(); }
     size_t local_rows() const { return sharded_ ? n_local_ : kinds_.size(); }
 
 private:
-    void commit_sharded(lig_rows_job& job, const std::vector<uint8_t>& args, const std::vector<uint64_t>& lens, uint8_t root[32], uint8_t stage1_seed[32]) {
+    static constexpr size_t push_rows = 256;             // randomness rows per lig_rows_push_rands (64 MiB at k = 8192)
+
+    bool same_shape(const lig_rows_job& job) const {           // lig_rows_restart keeps kinds, seeds and metadata of the trace
+        if (kinds_ != shape_kinds_) return false;
+        if (std::memcmp(meta_.encoding_seed, shape_meta_.encoding_seed, 32) || std::memcmp(meta_.program_hash, shape_meta_.program_hash, 32) ||
+            meta_.generated_at != shape_meta_.generated_at || meta_.version != shape_meta_.version || meta_.public_args != shape_meta_.public_args) return false;
+        const std::vector<uint8_t> w = job.elem_bytes ? std::vector<uint8_t>(job.elem_bytes, job.elem_bytes + kinds_.size()) : std::vector<uint8_t>();
+        return w == shape_widths_ || (w.empty() && shape_widths_.empty());
+    }
+    void begin_pass2(size_t local_rows) {
+        rands_.reserve(local_rows ? local_rows : 1, 0);
+        pass_ = 2; next_ = 0; enc_pos_ = 0; pushed_ = 0;  // the guest's second run starts the encoding stream over
+    }
+    // randomness rows [pushed_, upto) are complete: hand them to the library while the guest goes on (lig_rows_push_rands)
+    void push_rands(size_t upto) {
+        if (sharded_ || upto <= pushed_) return;
+        check(lig_rows_push_rands(trace_, pushed_, upto - pushed_, rands_.row(pushed_)), "lig_rows_push_rands");
+        pushed_ = upto;
+    }
+    void commit_sharded(lig_rows_job& job, uint8_t root[32], uint8_t stage1_seed[32]) {
         const size_t R = kinds_.size(), words = (size_t)k_ * 4;
         uint64_t rounds = 0;
         std::vector<uint64_t> b((size_t)world_ * ((R + 511) / 512 + 2) + 2);
         if (lig_shard_rows_plan(kinds_.data(), R, world_, &rounds, b.data(), b.size()) != LIG_OK) throw std::runtime_error("lig_shard_rows_plan failed");
         local_of_.assign(R, (size_t)-1);
-        std::vector<uint64_t> local;
         n_local_ = 0;
+        // this rank's rows, compacted IN PLACE to the front of the staging (commit order is kept, rows only move forward)
         for (uint64_t g = rank_; g < rounds * world_; g += world_)
             for (uint64_t r = b[g]; r < b[g + 1]; r++) {
+                if (n_local_ != r) std::memmove(rows_.row(n_local_), rows_.row(r), words * 8);
                 local_of_[r] = n_local_++;
-                local.insert(local.end(), rows_.begin() + r * words, rows_.begin() + (r + 1) * words);
             }
-        job.msgs = local.empty() ? nullptr : local.data();
-        std::memcpy(job.encoding_seed, meta_.encoding_seed, 32);
-        std::memcpy(job.program_hash, meta_.program_hash, 32);
-        job.generated_at = meta_.generated_at;
-        std::strncpy(job.version, meta_.version.c_str(), sizeof job.version - 1);
-        job.public_args = args.empty() ? nullptr : args.data();
-        job.public_arg_lens = lens.empty() ? nullptr : lens.data();
-        job.n_public_args = lens.size();
+        job.msgs = n_local_ ? rows_.data() : nullptr;
+        if (shard_) { lig_shard_destroy(shard_); shard_ = nullptr; }
         check(lig_shard_rows_begin(ctx_, &job, rank_, world_, &comm_, &shard_), "lig_shard_rows_begin");
         check(lig_shard_rows_commit(shard_, root, stage1_seed), "lig_shard_rows_commit");
-        rows_.clear(); rows_.shrink_to_fit();
-        rands_.assign((n_local_ ? n_local_ : 1) * words, 0);
-        pass_ = 2; next_ = 0; enc_pos_ = 0;
+        begin_pass2(n_local_);
+        std::memset(rands_.row(0), 0, (n_local_ ? n_local_ : 1) * words * 8);       // batch rows and rows without a callback keep zero rows
     }
     void check(int rc, const char* what) const {
         if (rc != LIG_OK) throw std::runtime_error(std::string(what) + ": " + lig_last_error(ctx_));
     }
-    void row(uint8_t kind, const uint64_t* val, const uint64_t* rand) {
+    void row(uint8_t kind, const uint64_t* val, const uint64_t* rand, bool in_slot = false) {
         const size_t words = (size_t)k_ * 4;
         // witness_manager pads every linear row and every row of a quadratic triple with k - l stream elements when it forms
         // it (the rows arrive with their pads): the position of the next on_batch_init pad moves past them
         if (kind <= LIG_ROW_QZ) enc_pos_ += k_ - l_;
         if (pass_ == 1) {
             if (!val) throw std::invalid_argument("hip_row_batcher: null row");
+            const size_t r = kinds_.size();
+            if (!in_slot) { rows_.reserve(r + 1, r); std::memcpy(rows_.row(r), val, words * 8); }
             kinds_.push_back(kind);
-            rows_.insert(rows_.end(), val, val + words);
         } else if (pass_ == 2) {
             // the guest is deterministic: pass 2 must replay the callbacks of pass 1 in the same order
             if (next_ >= kinds_.size() || kinds_[next_] != kind) throw std::logic_error("hip_row_batcher: pass 2 diverges from pass 1");
             const size_t slot = sharded_ ? local_of_[next_] : next_;                 // sharded: only the randomness rows of this rank's rows are kept
-            if (rand && slot != (size_t)-1) std::memcpy(rands_.data() + slot * words, rand, words * 8);
+            if (slot != (size_t)-1 && !in_slot) {
+                if (rand) std::memcpy(rands_.row(slot), rand, words * 8);
+                else if (!sharded_) std::memset(rands_.row(slot), 0, words * 8);     // (the staging is reused: a row without randomness is a zero row)
+            }
             next_++;
+            if (!sharded_ && next_ - pushed_ >= push_rows) push_rands(next_);
         } else throw std::logic_error("hip_row_batcher: callback after prove");
     }
     void dev_row(uint8_t kind, const void* dev) {
         if (pass_ == 1) {
             check(lig_sync(ctx_), "lig_sync");           // (lig_read is ordered on the context stream; kept explicit: the row must be final)
-            std::vector<uint64_t> host((size_t)k_ * 4);
-            check(lig_read(ctx_, host.data(), dev, host.size() * 8), "lig_read(batch row)");
-            row(kind, host.data(), nullptr);
+            const size_t r = kinds_.size();
+            rows_.reserve(r + 1, r);
+            check(lig_read(ctx_, rows_.row(r), dev, (size_t)k_ * 32), "lig_read(batch row)");
+            row(kind, rows_.row(r), nullptr, true);
         } else row(kind, nullptr, nullptr);
     }
 
     static constexpr uint32_t init_pad = 192;            // params::sample_size (include/params.hpp:27)
     lig_ctx* ctx_;
-    hip_proof_meta meta_;
+    hip_proof_meta meta_, shape_meta_;
     uint32_t k_, l_;
     int pass_ = 1;
-    size_t next_ = 0;
+    size_t next_ = 0, pushed_ = 0;
     uint64_t enc_pos_ = 0;                                // encoding-stream position (elements) of the next row's pad
-    std::vector<uint8_t> kinds_;
-    std::vector<uint64_t> rows_, rands_;
+    std::vector<uint8_t> kinds_, shape_kinds_, shape_widths_;
+    hip_row_staging rows_, rands_;
     lig_trace* trace_ = nullptr;
     bool sharded_ = false;
     uint32_t rank_ = 0, world_ = 1;

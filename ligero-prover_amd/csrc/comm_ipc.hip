@@ -23,8 +23,24 @@
 //   * forget() is a host collective -- a peer must close its mapping BEFORE the owner frees the buffer;
 //   * a send out of an allocation smaller than 2 MiB goes through a window exported once -- such allocations are fragments
 //     of shared blocks and the importer is handed the block's base.
+// Build: compiled in with -DLIG_WITH_IPC_COMM (the Makefile's default: the GPU test-suite needs it); `make RELEASE=1` leaves it
+// out -- lig_ipc_comm_create then returns LIG_E_STATE and the library carries no shared-memory / IPC-handle code at all.
 // Failure model: this is a test communicator.  A rank that fails in the middle of a collective leaves its peers' streams
 // waiting on flags that never come (their hosts give up after 120 s in the next collective; a stream wait has no timeout).
+#include <cstring>
+
+#include "ctx_internal.hpp"
+
+#ifndef LIG_WITH_IPC_COMM
+extern "C" {
+int lig_ipc_comm_create(lig_ctx* c, const char*, uint32_t, uint32_t, lig_comm* out) {
+    CHECK_CTX(c);
+    if (out) std::memset(out, 0, sizeof *out);
+    FAIL(c, LIG_E_STATE, "ipc comm: this build of liblig_hip.so has no process-to-process test communicator (make without RELEASE=1)");
+}
+void lig_ipc_comm_destroy(lig_comm*) {}
+}
+#else
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -367,3 +383,4 @@ void lig_ipc_comm_destroy(lig_comm* comm) {
 }
 
 }  // extern "C"
+#endif  // LIG_WITH_IPC_COMM

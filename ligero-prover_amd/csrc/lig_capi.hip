@@ -450,6 +450,17 @@ int lig_free(lig_ctx* c, void* dptr) {
     HIP_TRY(c, hipFree(dptr));
     return LIG_OK;
 }
+int lig_host_alloc(lig_ctx* c, size_t bytes, void** host_ptr) {
+    CHECK_CTX(c);
+    if (!host_ptr) return LIG_E_ARG;
+    HIP_TRY(c, hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return LIG_OK;
+}
+int lig_host_free(lig_ctx* c, void* host_ptr) {
+    CHECK_CTX(c);
+    if (host_ptr) HIP_TRY(c, hipHostFree(host_ptr));
+    return LIG_OK;
+}
 int lig_write(lig_ctx* c, void* dst, const void* src, size_t bytes) {
     CHECK_CTX(c);
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));

@@ -62,8 +62,12 @@ struct lig_trace {
     const uint8_t* host_msgs = nullptr; // lig_rows_begin with host memory: uploaded chunk by chunk under the encodes
     std::vector<hipEvent_t> ev_up;      // one per stage-1 chunk: its rows have arrived (per-context copy stream, LIG_UPLOAD_MODE=1)
     volatile uint32_t* up_flag = nullptr; uint32_t* up_flag_dev = nullptr;   // pinned: word ci = sequence number of the last upload whose chunk ci has arrived
-    uint32_t up_seq = 0;
+    uint32_t up_seq = 0;                // sequence number of the last witness-rows upload (what stage 1 waits for)
+    uint32_t rand_seq = 0;              // ... of the last randomness-rows upload (its own flag words, its own counter: a restart
+                                        // between commit and prove must not move what the next commit waits for)
     bool up_by_thread = false;
+    fr* rands_full = nullptr;           // lig_rows_push_rands: R x k, device resident
+    uint64_t rands_pushed = 0;          // rows handed to the uploader so far (word up_words - 1 counts the rows that have ARRIVED)
     size_t up_words = 0;                // words in up_flag: [stage-1 chunks | stage-2 chunks: randomness rows arrived | ... consumed]
     std::atomic<int> up_abort{0};       // a failed lig_rows_prove: the uploader drops the randomness-row copies it still holds
     std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
@@ -374,7 +378,7 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
 
 // where the stage-2 randomness rows come from: generated (dense rows of the synthetic stream, from the linear stream
 // keyed by the stage-1 seed) or supplied by the caller (device pointer used in place / host rows uploaded chunk-wise)
-struct RandSource { const fr* dev = nullptr; const uint8_t* host = nullptr; };
+struct RandSource { const fr* dev = nullptr; const uint8_t* host = nullptr; bool pushed = false; };
 
 // ================= stage 2 + 3
 static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* const_sum_given, const uint8_t** proof, size_t* proof_len,
@@ -440,7 +444,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         TRY(ensure_up_flags(c, T));
         rflag0 = T->sched1.size(); uflag0 = rflag0 + n_chunks;
         if (uflag0 + n_chunks > T->up_words) FAIL(c, LIG_E_STATE, "rows job: flag page too small for the stage-2 schedule");
-        rseq = ++T->up_seq;
+        rseq = ++T->rand_seq;
         T->up_abort.store(0, std::memory_order_release);
         std::vector<UploadJob> jobs;
         for (size_t ci = 0; ci < n_chunks; ci++) {
@@ -455,6 +459,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
+        if (rs.pushed) return LIG_OK;                                                           // arriving in T->rands_full (lig_rows_push_rands)
         if (rs.dev) { HIP_TRY(c, hipEventRecord(T->ev_ready[ci & 1], s2)); return LIG_OK; }     // used in place
         if (rands_by_thread) return LIG_OK;                                                     // the uploader thread brings them
         if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s2, T->ev_used[ci & 1], 0));      // buffer free again
@@ -514,7 +519,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
-        if (rands_by_thread) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + rflag0 + ci, rseq, hipStreamWaitValueGte, 0xffffffffu));
+        if (rs.pushed) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + T->up_words - 1, (uint32_t)sched2[ci].second, hipStreamWaitValueGte, 0xffffffffu));
+        else if (rands_by_thread) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + rflag0 + ci, rseq, hipStreamWaitValueGte, 0xffffffffu));
         else HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         if (c->fast) {
             // coset-2 values of the randomness rows times the coset-2 plane of the codewords, summed per group of rows inside the
@@ -689,7 +695,7 @@ void lig_trace_destroy(lig_trace* T) {
     T->up_abort.store(1, std::memory_order_release);      // (copies that wait for a buffer of a proof that never ran)
     uploader_drain(T);                                    // an upload still in flight
     T->c->sha.erase(T->sha_state);
-    for (void* p : {(void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
+    for (void* p : {(void*)T->rands_full, (void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->tri_dev,
                     (void*)T->coef_dev})
         (void)hipFree(p);
@@ -806,7 +812,7 @@ static void uploader_drain(lig_trace* T) {
 // pinned flag words of a trace: one per stage-1 chunk (rows arrived), two per stage-2 chunk (caller randomness rows arrived / consumed)
 static int ensure_up_flags(lig_ctx* c, lig_trace* T) {
     if (T->up_flag) return LIG_OK;
-    T->up_words = T->sched1.size() + 2 * (T->R / lig_tune::CHUNK + 3) + 8;
+    T->up_words = T->sched1.size() + 2 * (T->R / lig_tune::CHUNK + 3) + 8;        // (the last word: rows of lig_rows_push_rands that have arrived)
     const size_t bytes = (T->up_words * 4 + 4095) & ~(size_t)4095;
     HIP_TRY(c, hipHostMalloc((void**)&T->up_flag, bytes, hipHostMallocDefault));
     std::memset((void*)T->up_flag, 0, bytes);
@@ -1005,7 +1011,7 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     lig_ctx* c = T->c;
     CHECK_CTX(c);
     if (!T->from_rows || !T->committed) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_commit has not run on this trace");
-    if (T->R && !rands && !T->dense_rands) FAIL(c, LIG_E_ARG, "lig_rows_prove: null randomness rows");
+    if (T->R && !rands && !T->dense_rands && !T->rands_pushed) FAIL(c, LIG_E_ARG, "lig_rows_prove: null randomness rows");
     if (const_sum) {
         H::Fr v;
         std::memcpy(v.v, const_sum, 32);
@@ -1015,23 +1021,50 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     const auto t_begin = clk::now();
     RandSource rs;                                        // default: generated from the dense counts of the job
     if (rands && rands_on_device) rs.dev = (const fr*)rands; else if (rands) rs.host = (const uint8_t*)rands;
+    else if (T->rands_pushed) {
+        if (T->rands_pushed != T->R) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_push_rands has not delivered every row");
+        rs.dev = T->rands_full; rs.pushed = true;
+    }
     {
         int rc = prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c));
         const std::string why = c->err;
         if (rc != LIG_OK) {           // randomness-row copies the uploader thread still holds read the caller's memory: drop them, wait
+            T->rands_pushed = 0;
             T->up_abort.store(1, std::memory_order_release);
             uploader_drain(T);
             for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
             c->err = why;
             return rc;
         }
-        if (rs.host) {
+        if (rs.host || rs.pushed) {
             uploader_drain(T);
+            T->rands_pushed = 0;
             if (const int e = T->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
         }
     }
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
     T->committed = false;
+    return LIG_OK;
+}
+
+int lig_rows_push_rands(lig_trace* T, uint64_t first_row, uint64_t n_rows, const void* host_rows) {
+    if (!T) return LIG_E_ARG;
+    lig_ctx* c = T->c;
+    CHECK_CTX(c);
+    if (!T->from_rows || !T->committed) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: lig_rows_commit has not run on this trace");
+    if (first_row != T->rands_pushed || first_row + n_rows > T->R || (n_rows && !host_rows)) FAIL(c, LIG_E_ARG, "lig_rows_push_rands: rows must arrive in order, without gaps, inside the trace");
+    if (!n_rows) return LIG_OK;
+    if (lig::knobs().upload_mode != 2 || !uploader_available(c)) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: no uploader thread on this device (stream memory operations unavailable)");
+    const size_t row_bytes = (size_t)c->k * 32;
+    if (!T->rands_full) HIP_TRY(c, hipMalloc((void**)&T->rands_full, T->R * row_bytes));
+    TRY(ensure_up_flags(c, T));
+    volatile uint32_t* arrived = T->up_flag + T->up_words - 1;
+    if (first_row == 0) { __atomic_store_n(arrived, 0u, __ATOMIC_RELEASE); T->up_abort.store(0, std::memory_order_release); }
+    // one job per push: the uploader publishes the number of rows that have arrived (jobs of a trace are taken in order)
+    UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->up_failed};
+    j.abort = &T->up_abort;
+    uploader_submit(c->device, {j}, &T->up_pending);
+    T->rands_pushed = first_row + n_rows;
     return LIG_OK;
 }
 

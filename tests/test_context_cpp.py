@@ -1,5 +1,6 @@
 """The C++ mirror of the reference executor (include/lig_hip_context.hpp) compiles against a driver written
 like nonbatch_stage1_context (CPU test: syntax + link), and on the GPU produces the oracle's leaves."""
+import json
 import os
 import subprocess
 
@@ -102,7 +103,8 @@ def test_row_batcher_shim_ships_narrow_rows():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("l,k,n,n_lin,n_quad", [(320, 512, 2048, 2000, 700), (320, 512, 2048, 320 * 530 + 1, 0), (8000, 8192, 32768, 20000, 8001)])
+@pytest.mark.parametrize("l,k,n,n_lin,n_quad", [(320, 512, 2048, 2000, 700), (320, 512, 2048, 320 * 530 + 1, 0), (8000, 8192, 32768, 20000, 8001),
+                                                (8000, 8192, 32768, 1 << 22, 0)])       # 525 rows: the staging grows, pass 2 pushes randomness rows twice before prove
 def test_row_batcher_shim_gives_the_oracle_envelope(l, k, n, n_lin, n_quad):
     """include/lig_hip_row_batcher.hpp driven like the reference's stage contexts (two passes of per-row callbacks) produces
     the envelope of the oracle's reference-structured prover, public arguments included"""
@@ -138,6 +140,34 @@ def test_row_batcher_batch_hooks_give_the_oracle_envelope(n_lin, n_quad, with_bi
     (the shim used to commit init rows without their pads)"""
     out = subprocess.check_output([build_batch_batcher_exe(), str(n_lin), str(n_quad), str(with_bits), str(k)]).decode()
     assert out.startswith("equal 1 "), out
+
+
+RBSRC = os.path.join(ROOT, "tests", "cpp", "row_batcher_bench.cpp")
+RBEXE = os.path.join(ROOT, "tests", "cpp", "row_batcher_bench")
+
+
+def build_batcher_bench_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    odir = os.path.join(ROOT, "oracle")
+    ol.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O2", RBSRC, "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip", "-L" + odir, "-llig_oracle", "-lpthread",
+                           "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-Wl,-rpath," + odir, "-o", RBEXE])
+    return RBEXE
+
+
+def test_row_batcher_bench_compiles_and_links():
+    assert os.path.exists(build_batcher_bench_exe())
+
+
+@pytest.mark.gpu
+def test_row_batcher_bench_at_2p20_matches_the_oracle_on_every_path():
+    """tests/cpp/row_batcher_bench.cpp at 2^20 constraints with the oracle check on: copying callbacks, the zero-copy slots
+    (next_slot / commit_slot), re-use of one batcher for several proofs (reset) and two batchers on two contexts all self-check,
+    and the first envelope equals the oracle's"""
+    out = json.loads(subprocess.check_output([build_batcher_bench_exe(), "20", "2", "1"]).decode().strip().splitlines()[-1])
+    assert out["ok"] == 1 and out["checked_against_oracle"] == 1 and out["rows"] == 135
 
 
 SBSRC = os.path.join(ROOT, "tests", "cpp", "sharded_batcher_prog.cpp")
