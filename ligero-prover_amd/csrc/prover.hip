@@ -106,7 +106,8 @@ static void uploader_drain(lig_trace* T);      // (below, with the uploader thre
 // `wait` (optional): the copy may only start once *wait >= wait_val -- a word in pinned host memory that a stream of the proof writes
 // (hipStreamWriteValue32) when it is done with the destination buffer (the double-buffered randomness rows of stage 2)
 struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed;
-                   const volatile uint32_t* wait = nullptr; uint32_t wait_val = 0; const std::atomic<int>* abort = nullptr; };
+                   const volatile uint32_t* wait = nullptr; uint32_t wait_val = 0; const std::atomic<int>* abort = nullptr;
+                   int prio = 0; };     // 1: a proof is waiting for it NOW (randomness rows) -- ahead of the prefetch of a next trace's witness rows
 static bool uploader_available(lig_ctx* c);
 static void uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending);
 static int ensure_up_flags(lig_ctx* c, lig_trace* T);
@@ -437,7 +438,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // when it has consumed a chunk -- which is what the uploader waits for before it overwrites that half of the buffer.  No copy,
     // event or barrier packet of this transfer ever sits in a queue of the proof (the event-chained copy
     // on the side stream that this replaces is LIG_UPLOAD_MODE=1, profiles/r04_caller_rands_ab.md).
-    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && uploader_available(c) && n_chunks;
+    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && uploader_available(c) && n_chunks;
     uint32_t rseq = 0;
     size_t rflag0 = 0, uflag0 = 0;
     if (rands_by_thread) {
@@ -451,7 +452,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
             const size_t b = sched2[ci].first, nb = sched2[ci].second - b;
             UploadJob j{(uint8_t*)rand_buf(ci), rs.host + b * (size_t)k * 32, nb * (size_t)k * 32, T->up_flag + rflag0 + ci, rseq, &T->up_failed};
             if (ci >= 2) { j.wait = T->up_flag + uflag0 + ci - 2; j.wait_val = rseq; }
-            j.abort = &T->up_abort;
+            j.abort = &T->up_abort; j.prio = 1;
             jobs.push_back(j);
         }
         uploader_submit(c->device, jobs, &T->up_pending);
@@ -759,10 +760,13 @@ struct Uploader {
                 // uploads queued behind it (jobs of one trace stay in order: their wait words become true in order)
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
-                    auto it = q.begin();
-                    for (; it != q.end(); ++it) {
-                        const UploadJob& u = it->first;
-                        if (!u.wait || (int32_t)(__atomic_load_n(u.wait, __ATOMIC_ACQUIRE) - u.wait_val) >= 0 || (u.abort && u.abort->load(std::memory_order_acquire))) break;
+                    auto it = q.end();
+                    for (auto i2 = q.begin(); i2 != q.end(); ++i2) {
+                        const UploadJob& u = i2->first;
+                        const bool ready = !u.wait || (int32_t)(__atomic_load_n(u.wait, __ATOMIC_ACQUIRE) - u.wait_val) >= 0 || (u.abort && u.abort->load(std::memory_order_acquire));
+                        if (!ready) continue;
+                        if (it == q.end()) it = i2;                                  // the oldest ready job ...
+                        if (u.prio > it->first.prio) { it = i2; break; }             // ... unless a ready one is urgent
                     }
                     if (it != q.end()) { j = *it; q.erase(it); break; }
                     if (q.empty()) cv.wait(lk, [&] { return !q.empty(); });
@@ -1062,7 +1066,7 @@ int lig_rows_push_rands(lig_trace* T, uint64_t first_row, uint64_t n_rows, const
     if (first_row == 0) { __atomic_store_n(arrived, 0u, __ATOMIC_RELEASE); T->up_abort.store(0, std::memory_order_release); }
     // one job per push: the uploader publishes the number of rows that have arrived (jobs of a trace are taken in order)
     UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->up_failed};
-    j.abort = &T->up_abort;
+    j.abort = &T->up_abort; j.prio = 1;
     uploader_submit(c->device, {j}, &T->up_pending);
     T->rands_pushed = first_row + n_rows;
     return LIG_OK;
