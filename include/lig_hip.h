@@ -152,13 +152,27 @@ typedef struct lig_trace lig_trace;
  *   FREE           x <- 0
  * Stage 2 treats the rows as the reference does: check_code for init / bit / quadratic rows (not for equal rows),
  * check_quadratic for bit (x*x - x) and quadratic triples, quad += r*(x - y) for equal rows; no linear-test randomness.
- * The reference writes the padding of on_batch_init through a mis-sliced view (it lands in variable 0);
- * here it goes to the variable's own padding slots. */
+ * SET / SET_SCALAR with `reserved` bit 0 set: the variable was written by the write_limbs family (vbn254fr_set_str / _set_bytes
+ * and their _scalar forms, vbn254fr.hpp:200,222,251,271: write_buffer, nothing cleared): slots beyond the written ones keep
+ * their content.  Bit 0 clear: the write_buffer_clear family (vbn254fr_set_ui / _set_ui_scalar, :154,:169).
+ *
+ * Two slicing semantics.  DECLARED (default): buffer_view::slice_bytes(from, n_bytes) as include/ligetron/webgpu/
+ * buffer_view.hpp:52 declares it -- the pad of on_batch_init goes to the variable's own slots [l, k), write_buffer_clear zeroes
+ * the rest of the variable.  UPSTREAM (after a LIG_BOP_UPSTREAM_COMPAT op): the definition src/webgpu/buffer_view.cpp:91-95
+ * swaps the two parameters, so x.slice(B) of a variable x at slab byte offset X is the view {offset = B, size = X + size(x) - B}
+ * of the SLAB: (1) on_batch_init (nonbatch_context.hpp:502-505) writes its 192 pad elements at slab byte l*32 = the pad slots
+ * of VARIABLE 0, whatever x is; (2) write_buffer_clear(x, data, len) (device_context.hpp:95-98) clears slab bytes
+ * [len*32, X + k*32) after the write -- for a variable other than 0 that is variable 0 from slot `len` on, every variable in
+ * between and x itself, the data just written included.  An unmodified v1.5.0 build proves THAT; a proof of a vbn254fr program
+ * matches / cross-verifies with it only in this mode. */
 enum {
     LIG_BOP_SET = 0, LIG_BOP_SET_SCALAR, LIG_BOP_COPY, LIG_BOP_ADD, LIG_BOP_SUB, LIG_BOP_MUL, LIG_BOP_DIV, LIG_BOP_ADD_CONST,
     LIG_BOP_SUB_CONST, LIG_BOP_CONST_SUB, LIG_BOP_MUL_CONST, LIG_BOP_MONTMUL_CONST, LIG_BOP_ASSERT_EQUAL,
-    LIG_BOP_BIT_DECOMPOSE, LIG_BOP_FREE, LIG_BOP_COUNT
+    LIG_BOP_BIT_DECOMPOSE, LIG_BOP_FREE,
+    LIG_BOP_UPSTREAM_COMPAT,         /* no operands, no row: from here on slices behave as upstream DEFINES them (see above) */
+    LIG_BOP_COUNT
 };
+enum { LIG_BOP_F_WRITE_LIMBS = 1 };  /* lig_batch_op.reserved, SET / SET_SCALAR */
 typedef struct { uint32_t op, out, x, y, len, reserved; uint64_t data_off; } lig_batch_op;
 typedef struct {
     uint64_t n_linear, n_quad;

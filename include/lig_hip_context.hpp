@@ -40,7 +40,7 @@ inline void check(lig_ctx* c, int rc, const char* what) {
 class buffer_view {
 public:
     buffer_view() = default;
-    buffer_view(lig_ctx* c, size_t bytes) : size_(bytes) {
+    buffer_view(lig_ctx* c, size_t bytes, bool upstream_slices = false) : size_(bytes), storage_size_(bytes), upstream_(upstream_slices) {
         void* p = nullptr;
         check(c, lig_malloc(c, bytes, &p), "make_device_buffer");
         base_ = std::shared_ptr<void>(p, [c](void* q) { lig_free(c, q); });
@@ -48,13 +48,21 @@ public:
     size_t size() const { return size_; }
     size_t offset() const { return offset_; }
     void* data() const { return static_cast<char*>(base_.get()) + offset_; }
-    // slice by bytes / by element count of T (buffer_view.hpp:52-60)
+    // slice by bytes / by element count of T (buffer_view.hpp:52-60).  Two semantics:
+    //   declared (default)  slice_bytes(from, n_bytes) as buffer_view.hpp:52 declares it: {offset + from, n_bytes};
+    //   upstream            as src/webgpu/buffer_view.cpp:91-95 DEFINES it -- the parameter names are swapped there, so the call
+    //                       slice_bytes(A, B) returns buffer_view(storage, /*offset*/ A, /*size*/ offset + B): correct for a view
+    //                       of a whole buffer (offset 0), an absolute offset into the storage for a nested slice.
     buffer_view slice_bytes(size_t begin, size_t len) const {
-        if (begin + len > size_) throw std::out_of_range("buffer_view::slice");
+        if (begin + len > size_) throw std::out_of_range("buffer_view::slice");      // upstream: assert(from + n_bytes <= size_bytes_), same sum
         buffer_view v(*this);
-        v.offset_ += begin; v.size_ = len;
+        if (upstream_) {
+            v.offset_ = begin; v.size_ = offset_ + len;
+            if (v.offset_ + v.size_ > storage_size_) throw std::out_of_range("buffer_view::slice (upstream semantics): beyond the storage");
+        } else { v.offset_ += begin; v.size_ = len; }
         return v;
     }
+    bool upstream_slices() const { return upstream_; }
     buffer_view slice(size_t begin_bytes) const { return slice_bytes(begin_bytes, size_ - begin_bytes); }
     buffer_view slice(size_t begin_bytes, size_t len_bytes) const { return slice_bytes(begin_bytes, len_bytes); }
     template <typename T> buffer_view slice_n(size_t begin, size_t n) const { return slice_bytes(begin * sizeof(T), n * sizeof(T)); }
@@ -62,7 +70,8 @@ public:
 
 private:
     std::shared_ptr<void> base_;
-    size_t offset_ = 0, size_ = 0;
+    size_t offset_ = 0, size_ = 0, storage_size_ = 0;
+    bool upstream_ = false;
 };
 
 // device_bignum (include/ligetron/webgpu/device_bignum.hpp:30-90): 8 x u32 little-endian limbs
@@ -115,6 +124,12 @@ public:
         }
     }
     void set_device(int d) { device_ = d; }
+    // Buffers made from now on slice as upstream's buffer_view::slice_bytes is DEFINED (parameters swapped against its
+    // declaration, src/webgpu/buffer_view.cpp:91-95 vs include/ligetron/webgpu/buffer_view.hpp:52) instead of as declared.
+    // Needed, and only needed, to produce byte-identical proofs of vbn254fr programs with an UNMODIFIED v1.5.0 build: every
+    // other caller slices views of whole buffers, where the two agree.  INTEGRATION.md section 3 lists what it changes.
+    void set_upstream_slice_compat(bool on) { upstream_slices_ = on; }
+    bool upstream_slice_compat() const { return upstream_slices_; }
     void device_synchronize() { hip::check(ctx_, lig_sync(ctx_), "device_synchronize"); }
     size_t message_size() const { return lig_message_size(ctx_); }
     size_t padding_size() const { return lig_padding_size(ctx_); }
@@ -122,15 +137,19 @@ public:
     lig_ctx* native() const { return ctx_; }
 
     // ---- buffers (wgpu.hpp:159-169, device_context.hpp:79-98)
-    buffer_type make_device_buffer(size_t bytes) { return buffer_type(ctx_, bytes); }
+    buffer_type make_device_buffer(size_t bytes) { return buffer_type(ctx_, bytes, upstream_slices_); }
     buffer_type make_codeword_buffer() { return make_device_buffer(encoding_size() * 32); }
     buffer_type make_message_buffer() { return make_device_buffer(message_size() * 32); }
     buffer_type make_sample_buffer() { return make_device_buffer(192 * 32); }
     template <typename T> void write_buffer(buffer_type buf, const T* data, size_t len) {
         hip::check(ctx_, lig_write(ctx_, buf.data(), data, len * sizeof(T)), "write_buffer");
     }
+    // device_context.hpp:95-98: write_buffer(buf, data, len); clear_buffer(buf.slice(len * sizeof(T))) -- through slice(), so that
+    // the upstream slicing semantics (set_upstream_slice_compat) reach it
     template <typename T> void write_buffer_clear(buffer_type buf, const T* data, size_t len) {
-        hip::check(ctx_, lig_write_clear(ctx_, buf.data(), buf.size(), data, len * sizeof(T)), "write_buffer_clear");
+        if (!buf.upstream_slices()) { hip::check(ctx_, lig_write_clear(ctx_, buf.data(), buf.size(), data, len * sizeof(T)), "write_buffer_clear"); return; }
+        write_buffer(buf, data, len);
+        clear_buffer(buf.slice(len * sizeof(T)));
     }
     // write_limbs (include/wgpu.hpp:171-183): `size` copies of one element / a vector of elements, as device_bignum limbs
     void write_limbs(buffer_type buf, const hip::scalar& val, size_t size) {
@@ -276,6 +295,7 @@ private:
 
     lig_ctx* ctx_ = nullptr;
     int device_ = 0;
+    bool upstream_slices_ = false;
     size_t sha_instances_ = 0;
     size_t powmod_bits_ = 0;
     bool powmod_has_base_ = false;

@@ -8,6 +8,11 @@
  * the reference pops them from the WASM value stack and guest memory (interpreter, out of scope here), this class takes
  * them as C++ values (variable handles = element offsets, exactly what the reference stores in guest memory).
  *
+ * Slicing semantics: the layer slices through hip_context's buffer views, so executor.set_upstream_slice_compat(true) (before
+ * the first variable is allocated) reproduces what an unmodified v1.5.0 build does to vbn254fr variables -- the pad of
+ * on_batch_init lands in variable 0, write_buffer_clear of vbn254fr_set_ui / _set_ui_scalar wipes the slab up to the end of the
+ * variable (include/lig_hip.h, LIG_BOP_UPSTREAM_COMPAT).  A recorded program then starts with that op.
+ *
  * Reference defects that are NOT reproduced: vbn254fr_set_ui writes through an empty vector
  * (:150-153) -- here the values are written as intended; vbn254fr_set_bytes reads every element from bytes + len * count
  * (:266) -- callers of set() pass the decoded elements.
@@ -58,6 +63,7 @@ public:
         bind_compute3_ = executor_.bind_eltwise3(base_view, base_view, tmp_buf_);
         for (size_t i = 0; i < max_variables; i++) free_list_.push_back(i * executor_.padding_size());
         initialized_ = true;
+        if (record_ && buffer_base_.upstream_slices()) ops_.push_back(lig_batch_op{LIG_BOP_UPSTREAM_COMPAT, 0, 0, 0, 0, 0, 0});
     }
     buffer_t get_buffer_from_offset(size_t element_offset) {
         return buffer_base_.slice_bytes(element_offset * bignum_t::num_bytes, num_buf_bytes_);
@@ -93,19 +99,25 @@ public:
         if (record_) log(LIG_BOP_SET_SCALAR, 0, fp, 0, 0, blob(v.limbs, 32));
         set_elements(fp, std::vector<bignum_t>(num_buf_elements_, v));
     }
-    // vbn254fr_set_str / _set_bytes (:185-275) after parsing: one canonical element per slot (write_limbs + on_batch_init)
+    // vbn254fr_set_str / _set_bytes (:185-275) after parsing: one canonical element per slot -- write_limbs (wgpu.hpp:177-183:
+    // write_buffer, NOTHING cleared: slots beyond elems.size() keep their content) + on_batch_init
     void vbn254fr_set(handle_t fp, const std::vector<hip::scalar>& elems) {
         if (elems.size() > num_buf_elements_) throw std::invalid_argument("vbn254fr_set: more than message_size() elements");
-        std::vector<bignum_t> vals;
-        vals.reserve(elems.size());
-        for (const auto& e : elems) vals.emplace_back(e);
-        log_set(fp, vals);
-        set_elements(fp, vals);
+        if (record_) {
+            std::vector<bignum_t> vals;
+            for (const auto& e : elems) vals.emplace_back(e);
+            log(LIG_BOP_SET, 0, fp, 0, (uint32_t)vals.size(), blob(vals.data(), 32 * vals.size()), LIG_BOP_F_WRITE_LIMBS);
+        }
+        buffer_t x = get_buffer_from_offset(fp);
+        executor_.write_limbs(x, elems);
+        ctx_->on_batch_init(x);
     }
-    // vbn254fr_set_str_scalar / _set_bytes_scalar (:219-243,:277-296)
+    // vbn254fr_set_str_scalar / _set_bytes_scalar (:219-243,:277-296): write_limbs(x, value, message_size()) + on_batch_init
     void vbn254fr_set_scalar(handle_t fp, const hip::scalar& e) {
-        if (record_) log(LIG_BOP_SET_SCALAR, 0, fp, 0, 0, blob(e.data(), 32));
-        set_elements(fp, std::vector<bignum_t>(num_buf_elements_, bignum_t(e)));
+        if (record_) log(LIG_BOP_SET_SCALAR, 0, fp, 0, 0, blob(e.data(), 32), LIG_BOP_F_WRITE_LIMBS);
+        buffer_t x = get_buffer_from_offset(fp);
+        executor_.write_limbs(x, e, num_buf_elements_);
+        ctx_->on_batch_init(x);
     }
 
     // vbn254fr_copy (:298-317)
@@ -214,8 +226,8 @@ private:
         data_.insert(data_.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n);
         return off;
     }
-    void log(uint32_t op, handle_t out, handle_t x, handle_t y, uint32_t len = 0, uint64_t off = 0) {
-        if (record_) ops_.push_back(lig_batch_op{op, slot(out), slot(x), slot(y), len, 0, off});
+    void log(uint32_t op, handle_t out, handle_t x, handle_t y, uint32_t len = 0, uint64_t off = 0, uint32_t flags = 0) {
+        if (record_) ops_.push_back(lig_batch_op{op, slot(out), slot(x), slot(y), len, flags, off});
     }
     void log_const(uint32_t op, handle_t out, handle_t x, const hip::scalar& k) { if (record_) log(op, out, x, 0, 0, blob(k.data(), 32)); }
 

@@ -103,13 +103,6 @@ struct lig_trace {
 };
 
 static void uploader_drain(lig_trace* T);      // (below, with the uploader thread)
-// `wait` (optional): the copy may only start once *wait >= wait_val -- a word in pinned host memory that a stream of the proof writes
-// (hipStreamWriteValue32) when it is done with the destination buffer (the double-buffered randomness rows of stage 2)
-struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed;
-                   const volatile uint32_t* wait = nullptr; uint32_t wait_val = 0; const std::atomic<int>* abort = nullptr;
-                   int prio = 0; };     // 1: a proof is waiting for it NOW (randomness rows) -- ahead of the prefetch of a next trace's witness rows
-static bool uploader_available(lig_ctx* c);
-static void uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending);
 static int ensure_up_flags(lig_ctx* c, lig_trace* T);
 
 // The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
@@ -141,17 +134,26 @@ int lig_run_batch_program(lig_ctx* c, const lig_synth_job& job, fr* rows_out) {
     auto commit = [&](const fr* src) -> int { HIP_TRY(c, hipMemcpyAsync(rows_out + (r++) * (size_t)k, src, vb, hipMemcpyDeviceToDevice, s)); return LIG_OK; };
     auto to_out = [&](uint32_t out) -> int { HIP_TRY(c, hipMemcpyAsync(var(out), tmp, vb, hipMemcpyDeviceToDevice, s)); return LIG_OK; };
     std::vector<uint8_t> stage;
+    bool compat = false;                 // LIG_BOP_UPSTREAM_COMPAT seen: slices as upstream defines them (lig_hip.h)
     for (uint64_t i = 0; i < job.n_batch_ops; i++) {
         const lig_batch_op& o = job.batch_ops[i];
         const uint8_t* data = job.batch_data ? job.batch_data + o.data_off : nullptr;
         switch (o.op) {
+            case LIG_BOP_UPSTREAM_COMPAT: compat = true; break;
             case LIG_BOP_SET: case LIG_BOP_SET_SCALAR: {
-                stage.assign(vb, 0);                                                    // write_buffer_clear
+                const bool limbs = (o.reserved & LIG_BOP_F_WRITE_LIMBS) != 0;           // write_limbs family: write_buffer only
+                const uint32_t len = o.op == LIG_BOP_SET ? o.len : l;
+                stage.assign(32ull * len, 0);
                 if (o.op == LIG_BOP_SET) std::memcpy(stage.data(), data, 32ull * o.len);
                 else for (uint32_t e = 0; e < l; e++) std::memcpy(stage.data() + 32ull * e, data, 32);
-                HIP_TRY(c, hipMemcpyAsync(var(o.x), stage.data(), vb, hipMemcpyHostToDevice, s));
+                if (!limbs && !compat) HIP_TRY(c, hipMemsetAsync(var(o.x), 0, vb, s));  // write_buffer_clear, declared slice: the rest of x
+                if (len) HIP_TRY(c, hipMemcpyAsync(var(o.x), stage.data(), 32ull * len, hipMemcpyHostToDevice, s));
                 HIP_TRY(c, hipStreamSynchronize(s));                                    // `stage` is reused
-                lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)(inits++) * pad, var(o.x), 1, pad, k, l, 1, pad);
+                // write_buffer_clear as upstream runs it: clear_buffer(x.slice(len * 32)) after the write, the slice being
+                // {offset len*32, size X + k*32 - len*32} of the slab: elements [len, x*k + k)
+                if (!limbs && compat) HIP_TRY(c, hipMemsetAsync(vars + len, 0, ((size_t)o.x * k + k - len) * sizeof(fr), s));
+                // on_batch_init's pad: x's own pad slots (declared) / slab element l = variable 0's pad slots (upstream)
+                lig::launch_rng_fill_rows(s, c->rk_dev, (uint64_t)(inits++) * pad, compat ? vars : var(o.x), 1, pad, k, l, 1, pad);
                 TRY(commit(var(o.x)));
                 break;
             }
@@ -438,7 +440,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // when it has consumed a chunk -- which is what the uploader waits for before it overwrites that half of the buffer.  No copy,
     // event or barrier packet of this transfer ever sits in a queue of the proof (the event-chained copy
     // on the side stream that this replaces is LIG_UPLOAD_MODE=1, profiles/r04_caller_rands_ab.md).
-    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && uploader_available(c) && n_chunks;
+    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && lig_internal_uploader_available(c) && n_chunks;
     uint32_t rseq = 0;
     size_t rflag0 = 0, uflag0 = 0;
     if (rands_by_thread) {
@@ -455,7 +457,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
             j.abort = &T->up_abort; j.prio = 1;
             jobs.push_back(j);
         }
-        uploader_submit(c->device, jobs, &T->up_pending);
+        lig_internal_uploader_submit(c->device, jobs, &T->up_pending);
     }
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
@@ -786,7 +788,7 @@ struct Uploader {
 Uploader* g_uploader[64] = {nullptr};
 std::mutex g_uploader_mu;
 }  // namespace
-static bool uploader_available(lig_ctx* c) {
+bool lig_internal_uploader_available(lig_ctx* c) {
     if (c->device < 0 || c->device >= 64) return false;
     std::lock_guard<std::mutex> lk(g_uploader_mu);
     Uploader*& u = g_uploader[c->device];
@@ -800,7 +802,7 @@ static bool uploader_available(lig_ctx* c) {
     }
     return u->ok;
 }
-static void uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending) {
+void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending) {
     Uploader* u = g_uploader[device];
     pending->fetch_add((int)jobs.size(), std::memory_order_acq_rel);
     {
@@ -859,7 +861,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
     // the long-running kernel serialises with the proof's kernels whenever both streams share a hardware queue:
     // stage 2 5.6 -> 13.8 ms.  The DMA engine it is.)
     const int mode = lig::knobs().upload_mode;   // 2: uploader thread (default), 1: per-context copy stream + events
-    if (mode == 2 && uploader_available(c)) {
+    if (mode == 2 && lig_internal_uploader_available(c)) {
         TRY(ensure_up_flags(c, T));
         T->up_seq++;
         std::vector<UploadJob> jobs;
@@ -868,7 +870,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
             const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
             jobs.push_back(UploadJob{up_dst + off, T->host_msgs + off, bytes, T->up_flag + ci, T->up_seq, &T->up_failed});
         }
-        uploader_submit(c->device, jobs, &T->up_pending);
+        lig_internal_uploader_submit(c->device, jobs, &T->up_pending);
         T->up_by_thread = true;
         return LIG_OK;
     }
@@ -1058,7 +1060,7 @@ int lig_rows_push_rands(lig_trace* T, uint64_t first_row, uint64_t n_rows, const
     if (!T->from_rows || !T->committed) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: lig_rows_commit has not run on this trace");
     if (first_row != T->rands_pushed || first_row + n_rows > T->R || (n_rows && !host_rows)) FAIL(c, LIG_E_ARG, "lig_rows_push_rands: rows must arrive in order, without gaps, inside the trace");
     if (!n_rows) return LIG_OK;
-    if (lig::knobs().upload_mode != 2 || !uploader_available(c)) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: no uploader thread on this device (stream memory operations unavailable)");
+    if (lig::knobs().upload_mode != 2 || !lig_internal_uploader_available(c)) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: no uploader thread on this device (stream memory operations unavailable)");
     const size_t row_bytes = (size_t)c->k * 32;
     if (!T->rands_full) HIP_TRY(c, hipMalloc((void**)&T->rands_full, T->R * row_bytes));
     TRY(ensure_up_flags(c, T));
@@ -1067,7 +1069,7 @@ int lig_rows_push_rands(lig_trace* T, uint64_t first_row, uint64_t n_rows, const
     // one job per push: the uploader publishes the number of rows that have arrived (jobs of a trace are taken in order)
     UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->up_failed};
     j.abort = &T->up_abort; j.prio = 1;
-    uploader_submit(c->device, {j}, &T->up_pending);
+    lig_internal_uploader_submit(c->device, {j}, &T->up_pending);
     T->rands_pushed = first_row + n_rows;
     return LIG_OK;
 }

@@ -5,6 +5,7 @@
 #include <openssl/evp.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,17 @@ void launch_lin_interleave(hipStream_t s, fr* out, const fr* accH, const fr* acc
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count);
 void launch_copy_from_host(hipStream_t s, uint8_t* dst_dev, const uint8_t* src_mapped, size_t bytes);
 }  // namespace lig
+
+// ---- host rows -> device through the library's uploader thread (prover.hip; one thread per device, shared by every trace and
+// shard): no copy, event or barrier packet of such a transfer sits in a HIP queue of a proof.  A job copies `bytes`, waits for
+// the copy ON THE HOST, then publishes `seq` in *flag (pinned host memory; streams wait for it with hipStreamWaitValue32).
+// `wait` (optional): the copy may only start once *wait >= wait_val -- a word in pinned host memory that a stream of the proof writes
+// (hipStreamWriteValue32) when it is done with the destination buffer (the double-buffered randomness rows of stage 2)
+struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed;
+                   const volatile uint32_t* wait = nullptr; uint32_t wait_val = 0; const std::atomic<int>* abort = nullptr;
+                   int prio = 0; };     // 1: a proof is waiting for it NOW (randomness rows) -- ahead of the prefetch of a next trace's witness rows
+extern "C" bool lig_internal_uploader_available(lig_ctx* c);          // false: no stream memory operations on this device (callers fall back to stream copies)
+extern "C" void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending);   // *pending += jobs, -1 per finished job
 
 // (outside the anonymous namespace: these types appear in functions shared between translation units)
 // kind: 0 linear, 1 x, 2 y, 3 z of the synthetic stream; >= 4: rows committed by the batch program (RK_* below)

@@ -1,5 +1,6 @@
 // shard.hip -- one trace sharded over the GPUs of a node (lig_shard_*).
 #include "prover_common.hpp"
+#include <thread>
 
 // =====================================================================================================================
 // One trace sharded over the GPUs of a node (BASELINE.json configs[3]).
@@ -52,10 +53,19 @@ struct lig_shard {
     size_t h_proof_cap = 0;
     uint8_t ih[32] = {0};
     hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr}, ev_hash[2] = {nullptr, nullptr};
+    // caller rows in host memory (lig_shard_rows_*): uploaded by the library's uploader thread, as in lig_rows_* (prover.hip).  Flag words
+    // in pinned host memory: [round c: local rows of my c-th chunk arrived | round c: randomness rows arrived | ... consumed]
+    volatile uint32_t* up_flag = nullptr; uint32_t* up_flag_dev = nullptr;
+    uint32_t up_seq = 0, rand_seq = 0;
+    bool rows_by_thread = false;               // the local rows of the trace being committed are arriving through the uploader
+    std::atomic<int> up_pending{0}, up_failed{0}, up_abort{0};
     bool used_comm = false;                    // a collective has been issued with buffers of this shard as send buffers
     bool exchange_even_alone = false;          // LIG_SHARD_FORCE_EXCHANGE: run pack + all-to-all with world == 1 too (tests)
     size_t chunk_rows(size_t g) const { return g < G ? gb[g + 1] - gb[g] : 0; }
 };
+
+static int shard_up_flags(lig_shard* S);
+static void shard_up_drain(lig_shard* S);
 
 namespace lig {
 // The column slices of `rows` codewords, one block of cap_rows x ncol per destination rank h.  Inside a row of a block the
@@ -270,6 +280,9 @@ void lig_shard_destroy(lig_shard* S) {
     (void)hipStreamSynchronize(S->c->stream);
     (void)hipStreamSynchronize(S->c->stream2);
     (void)hipStreamSynchronize(S->c->stream3);
+    S->up_abort.store(1, std::memory_order_release);
+    while (S->up_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();       // the uploader thread is done with our buffers
+    if (S->up_flag) (void)hipHostFree((void*)S->up_flag);
     // the send buffers below are about to be freed.  forget() may be a host collective (comm_ipc): a shard that fails before its
     // first collective (a local error in *_begin / *_prepare) has exported nothing and must not wait for peers that are not there
     if (S->comm.forget && S->used_comm) S->comm.forget(S->comm.user);
@@ -310,14 +323,18 @@ static int shard_stage1(lig_shard* S, lig_proof_info* info) {
     TRY(lig_internal_upload_small(c, c->rk_dev, rk, sizeof rk, s));
     // pads of the local rows that draw them at commit time (batch init rows carry theirs from the program): the position
     // of a row's pads = number of pad-drawing rows before it in commit order; runs of consecutive rows = one launch
-    for (size_t lr = 0; lr < Rl;) {
-        const size_t gr = S->grow[lr];
-        if (!S->draw[gr]) { lr++; continue; }
-        size_t run = 1;
-        while (lr + run < Rl && S->grow[lr + run] == gr + run && S->draw[gr + run] && S->enc_pos[gr + run] == S->enc_pos[gr + run - 1] + pad) run++;
-        lig::launch_rng_fill_rows(s, c->rk_dev, S->enc_pos[gr], S->msgs + lr * (size_t)k, run, pad, k, l, 1, pad);
-        lr += run;
-    }
+    // (rows that are still arriving from the host -- rows_by_thread -- get theirs round by round below, behind the arrival of the round)
+    auto draw_pads = [&](size_t lr0, size_t lr1) {
+        for (size_t lr = lr0; lr < lr1;) {
+            const size_t gr = S->grow[lr];
+            if (!S->draw[gr]) { lr++; continue; }
+            size_t run = 1;
+            while (lr + run < lr1 && S->grow[lr + run] == gr + run && S->draw[gr + run] && S->enc_pos[gr + run] == S->enc_pos[gr + run - 1] + pad) run++;
+            lig::launch_rng_fill_rows(s, c->rk_dev, S->enc_pos[gr], S->msgs + lr * (size_t)k, run, pad, k, l, 1, pad);
+            lr += run;
+        }
+    };
+    if (!S->rows_by_thread) draw_pads(0, Rl);
     uint64_t epos = S->enc_pos[R];
     fr* mask = S->maskcw; fr* mlin = mask + n; fr* mquad = mask + 2 * (size_t)n;                        // masks: formed by every rank
     const size_t k3 = 3 * (size_t)k, kq = ncol / 4;                                                      // kq = positions per coset of a rank's columns
@@ -342,6 +359,10 @@ static int shard_stage1(lig_shard* S, lig_proof_info* info) {
         const int pb = (int)(cidx & 1);
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
         fr* sendb = S->send + (size_t)pb * CAP * n; fr* recvb = S->recv + (size_t)pb * CAP * n;
+        if (S->rows_by_thread) {                              // my c-th chunk has arrived from the host
+            HIP_TRY(c, hipStreamWaitValue32(s, S->up_flag_dev + cidx, S->up_seq, hipStreamWaitValueGte, 0xffffffffu));
+            draw_pads(lb, lb + nb);
+        }
         if (nb) TRY(lig_internal_encode_rows(c, S->msgs + lb * (size_t)k, S->cw + lb * k3, nb, lig::ENC_PLANAR, s));
         if (exchange) {
             if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s, S->ev_comm[pb], 0));          // send buffer free again (exchange c-2 done)
@@ -389,6 +410,10 @@ static int shard_stage1(lig_shard* S, lig_proof_info* info) {
     TRY(lig_merkle_build(c, leaf_level, n, S->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (S->rows_by_thread) {                                  // every round has been waited for: the caller's rows are no longer read
+        S->rows_by_thread = false;
+        if (const int e = S->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("rows upload failed: ") + hipGetErrorString((hipError_t)e));
+    }
     Sha256().add("LigetronStage1", 15).add(info->root, 32).add(S->ih, 32).finish(info->stage1_seed);
     return LIG_OK;
 }
@@ -433,10 +458,30 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     const bool fused_rlc = !rs.dev && !rs.host && (k % 256 == 0) && lig::knobs().fused_rlc;
     // the caller's randomness rows (lig_shard_rows_prove): device rows are used in place, host rows go through the double buffer
     auto rand_buf = [&](size_t cidx) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + S->lrow0[cidx] * (size_t)k : S->randb + (cidx & 1) * CAP * (size_t)k; };
+    // host rows: the uploader thread fills the double buffer round by round (prover.hip, prove_stage23: same scheme -- arrival and
+    // consumption are words in pinned host memory, no copy or event of the transfer in a queue of the proof)
+    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && lig_internal_uploader_available(c) && S->rounds;
+    uint32_t rseq = 0;
+    const size_t rflag0 = S->rounds, uflag0 = 2 * S->rounds;
+    if (rands_by_thread) {
+        TRY(shard_up_flags(S));
+        rseq = ++S->rand_seq;
+        S->up_abort.store(0, std::memory_order_release);
+        std::vector<UploadJob> jobs;
+        for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+            const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
+            UploadJob j{(uint8_t*)rand_buf(cidx), rs.host + lb * (size_t)k * 32, nb * (size_t)k * 32, S->up_flag + rflag0 + cidx, rseq, &S->up_failed};
+            if (cidx >= 2) { j.wait = S->up_flag + uflag0 + cidx - 2; j.wait_val = rseq; }
+            j.abort = &S->up_abort; j.prio = 1;
+            jobs.push_back(j);
+        }
+        lig_internal_uploader_submit(c->device, jobs, &S->up_pending);
+    }
     auto form_rand_chunk = [&](size_t cidx) -> int {           // on the side stream
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
         fr* rb = rand_buf(cidx);
         if (rs.dev) { HIP_TRY(c, hipEventRecord(S->ev_enc[cidx & 1], s_hash)); return LIG_OK; }
+        if (rands_by_thread) return LIG_OK;
         if (cidx >= 2) HIP_TRY(c, hipStreamWaitEvent(s_hash, S->ev_comm[cidx & 1], 0));        // buffer consumed (event reused: stage 1 is over)
         if (rs.host) {
             if (nb) HIP_TRY(c, hipMemcpyAsync(rb, rs.host + lb * (size_t)k * 32, nb * (size_t)k * 32, hipMemcpyHostToDevice, s_hash));
@@ -460,7 +505,8 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
         const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
         fr* rb = rand_buf(cidx);
         if (cidx + 1 < S->rounds) TRY(form_rand_chunk(cidx + 1));
-        HIP_TRY(c, hipStreamWaitEvent(s, S->ev_enc[cidx & 1], 0));
+        if (rands_by_thread) HIP_TRY(c, hipStreamWaitValue32(s, S->up_flag_dev + rflag0 + cidx, rseq, hipStreamWaitValueGte, 0xffffffffu));
+        else HIP_TRY(c, hipStreamWaitEvent(s, S->ev_enc[cidx & 1], 0));
         if (nb) {
             if (c->fast) {      // as in lig_synth_prove: coset-2 values times the codewords' coset-2 plane inside the encoder's output kernel
                 TRY(lig_internal_encode_dot(c, rb, nb, S->cw + lb * 3 * (size_t)k + k, 3 * (size_t)k, lig_tune::DOT_GROUP, p_linC));
@@ -470,7 +516,8 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
             }
             if (!fused_rlc) lig::launch_rlc_accumulate29(s, S->msgs + lb * (size_t)k, k, 1, rb, k, nb, k, S->coef_dev + lb, p_code, p_linH, lig_tune::GROUP / 4);
         }
-        HIP_TRY(c, hipEventRecord(S->ev_comm[cidx & 1], s));
+        if (rands_by_thread) HIP_TRY(c, hipStreamWriteValue32(s, S->up_flag_dev + uflag0 + cidx, rseq, 0));      // consumed: its half of the buffer is free
+        else HIP_TRY(c, hipEventRecord(S->ev_comm[cidx & 1], s));
     }
     lig::launch_rlc_combine(s, tmp, p_code, pg, k);
     lig::launch_rlc_combine(s, linH, p_linH, pg, k);
@@ -642,12 +689,42 @@ int lig_shard_rows_plan(const uint8_t* kinds, size_t n_rows, uint32_t world, uin
     return LIG_OK;
 }
 
+static int shard_up_flags(lig_shard* S) {
+    lig_ctx* c = S->c;
+    if (S->up_flag) return LIG_OK;
+    const size_t bytes = ((3 * S->rounds + 8) * 4 + 4095) & ~(size_t)4095;
+    HIP_TRY(c, hipHostMalloc((void**)&S->up_flag, bytes, hipHostMallocDefault));
+    std::memset((void*)S->up_flag, 0, bytes);
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&S->up_flag_dev, (void*)S->up_flag, 0));
+    return LIG_OK;
+}
+static void shard_up_drain(lig_shard* S) { while (S->up_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield(); }
+// local rows of a rows job -> S->msgs.  Device rows: one copy on the main stream.  Host rows: round by round through the uploader
+// thread -- lig_shard_rows_commit encodes my c-th chunk as soon as it has arrived (the caller's memory must stay valid until then).
 static int shard_rows_load(lig_shard* S, const void* local_msgs, bool on_device) {
     lig_ctx* c = S->c;
     if (S->Rl && !local_msgs) FAIL(c, LIG_E_ARG, "sharded rows job: null local rows");
-    if (S->Rl) HIP_TRY(c, hipMemcpyAsync(S->msgs, local_msgs, S->Rl * (size_t)c->k * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the caller's memory is no longer referenced
+    shard_up_drain(S);                                 // an upload nobody committed
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the previous trace is done with S->msgs
     S->committed = false;
+    S->rows_by_thread = false;
+    if (!S->Rl) return LIG_OK;
+    const size_t row_bytes = (size_t)c->k * 32;
+    if (!on_device && lig::knobs().upload_mode == 2 && lig_internal_uploader_available(c)) {
+        TRY(shard_up_flags(S));
+        S->up_seq++;
+        S->up_abort.store(0, std::memory_order_release);
+        std::vector<UploadJob> jobs;
+        for (size_t cidx = 0; cidx < S->rounds; cidx++) {
+            const size_t lb = S->lrow0[cidx], nb = S->lrow0[cidx + 1] - lb;
+            jobs.push_back(UploadJob{(uint8_t*)S->msgs + lb * row_bytes, (const uint8_t*)local_msgs + lb * row_bytes, nb * row_bytes, S->up_flag + cidx, S->up_seq, &S->up_failed});
+        }
+        lig_internal_uploader_submit(c->device, jobs, &S->up_pending);
+        S->rows_by_thread = true;
+        return LIG_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(S->msgs, local_msgs, S->Rl * row_bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the caller's memory is no longer referenced
     return LIG_OK;
 }
 
@@ -709,7 +786,17 @@ int lig_shard_rows_commit(lig_shard* S, uint8_t root[32], uint8_t stage1_seed[32
     std::memset(&S->info1, 0, sizeof S->info1);
     S->info1.rows = S->R + 3;
     const auto t_begin = clk::now();
-    TRY(shard_stage1(S, &S->info1));
+    {
+        const int rc = shard_stage1(S, &S->info1);
+        if (rc != LIG_OK) {               // the caller is told it may free its rows
+            const std::string why = c->err;
+            shard_up_drain(S);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            S->rows_by_thread = false;
+            c->err = why;
+            return rc;
+        }
+    }
     S->info1.ms_stage1 = ms_since(t_begin);
     S->committed = true;
     if (root) std::memcpy(root, S->info1.root, 32);
@@ -732,7 +819,21 @@ int lig_shard_rows_prove(lig_shard* S, const void* local_rands, int rands_on_dev
     const auto t_begin = clk::now();
     ShardRands rs;
     if (local_rands && rands_on_device) rs.dev = (const fr*)local_rands; else if (local_rands) rs.host = (const uint8_t*)local_rands;
-    TRY(shard_stage23(S, rs, const_sum, proof, proof_len, info));
+    {
+        const int rc = shard_stage23(S, rs, const_sum, proof, proof_len, info);
+        if (rc != LIG_OK) {               // randomness-row copies the uploader thread still holds read the caller's memory: drop them, wait
+            const std::string why = c->err;
+            S->up_abort.store(1, std::memory_order_release);
+            shard_up_drain(S);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            c->err = why;
+            return rc;
+        }
+        if (rs.host) {
+            shard_up_drain(S);
+            if (const int e = S->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
+        }
+    }
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
     S->committed = false;
     return LIG_OK;

@@ -154,12 +154,15 @@ size_t lo_serialize_proof(uint8_t *out, size_t cap,
  *   ASSERT_EQUAL                                                     -> on_batch_equal(x, y)
  *   BIT_DECOMPOSE: slot table of `len` (= 254) u32 at data_off; out_i <- bit i of x -> on_batch_bit(out_i) (1 row each)
  *   FREE x <- 0
- * The reference writes the padding of on_batch_init through a mis-sliced view (it lands in variable 0);
- * here, as in the HIP prover, it goes to the variable's own padding slots. */
+ * SET / SET_SCALAR with reserved bit 0: written by the write_limbs family (vbn254fr.hpp:200,222,251,271), nothing cleared.
+ * LO_BOP_UPSTREAM_COMPAT switches to buffer_view::slice_bytes as src/webgpu/buffer_view.cpp:91-95 DEFINES it (parameters
+ * swapped against the declaration buffer_view.hpp:52): x.slice(B) = {offset B, size X + size(x) - B} of the slab, hence
+ * on_batch_init's pad (nonbatch_context.hpp:502-505) lands in variable 0's pad slots and write_buffer_clear
+ * (device_context.hpp:95-98) clears slab bytes [len*32, X + k*32).  Default: the declared semantics. */
 enum {
     LO_BOP_SET = 0, LO_BOP_SET_SCALAR, LO_BOP_COPY, LO_BOP_ADD, LO_BOP_SUB, LO_BOP_MUL, LO_BOP_DIV, LO_BOP_ADD_CONST,
     LO_BOP_SUB_CONST, LO_BOP_CONST_SUB, LO_BOP_MUL_CONST, LO_BOP_MONTMUL_CONST, LO_BOP_ASSERT_EQUAL, LO_BOP_BIT_DECOMPOSE,
-    LO_BOP_FREE, LO_BOP_COUNT
+    LO_BOP_FREE, LO_BOP_UPSTREAM_COMPAT, LO_BOP_COUNT
 };
 typedef struct { uint32_t op, out, x, y, len, reserved; uint64_t data_off; } lo_batch_op;
 

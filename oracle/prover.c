@@ -90,6 +90,7 @@ static void batch_run(const lo_job *j, lo_rng *enc, lo_fr *rows) {
     if (!j->n_batch_ops) return;
     lo_fr *vars = calloc((size_t)512 * k, sizeof(lo_fr)), *tmp = calloc(k, sizeof(lo_fr));
     size_t r = 0;
+    int compat = 0;                       /* LO_BOP_UPSTREAM_COMPAT seen: buffer_view::slice_bytes as DEFINED (buffer_view.cpp:91-95) */
 #define VAR(i) (vars + (size_t)(i) * k)
 #define COMMIT(src) do { memcpy(rows + (r++) * (size_t)k, (src), sizeof(lo_fr) * k); } while (0)
     for (uint64_t i = 0; i < j->n_batch_ops; i++) {
@@ -97,13 +98,22 @@ static void batch_run(const lo_job *j, lo_rng *enc, lo_fr *rows) {
         const uint8_t *data = j->batch_data + o->data_off;
         lo_fr c;
         switch (o->op) {
-        case LO_BOP_SET: case LO_BOP_SET_SCALAR:
-            memset(VAR(o->x), 0, sizeof(lo_fr) * k);                       /* write_buffer_clear */
+        case LO_BOP_UPSTREAM_COMPAT: compat = 1; break;
+        case LO_BOP_SET: case LO_BOP_SET_SCALAR: {
+            const int limbs = o->reserved & 1;                             /* write_limbs family: write_buffer only */
+            const uint32_t len = o->op == LO_BOP_SET ? o->len : l;
+            if (!limbs && !compat) memset(VAR(o->x), 0, sizeof(lo_fr) * k); /* write_buffer_clear, declared slice: the rest of x */
             if (o->op == LO_BOP_SET) memcpy(VAR(o->x), data, 32ull * o->len);
             else for (uint32_t e = 0; e < l; e++) memcpy(&VAR(o->x)[e], data, 32);
-            lo_rng_fill(enc, VAR(o->x) + l, k - l);                        /* on_batch_init: pad_encoding_random */
+            /* write_buffer_clear upstream: clear_buffer(x.slice(len * 32)) AFTER the write, x.slice(B) = {offset B, size X + k*32 - B}
+             * of the slab (device_context.hpp:95-98 over buffer_view.cpp:91-95): slab elements [len, x*k + k) */
+            if (!limbs && compat) memset(vars + len, 0, sizeof(lo_fr) * ((size_t)o->x * k + k - len));
+            /* on_batch_init: pad_encoding_random into x.slice(l * 32) (nonbatch_context.hpp:502-505): x's own pad slots as
+             * declared, slab element l (variable 0's pad slots) as defined */
+            lo_rng_fill(enc, compat ? vars + l : VAR(o->x) + l, k - l);
             COMMIT(VAR(o->x));
             break;
+        }
         case LO_BOP_COPY:
             memmove(VAR(o->out), VAR(o->x), sizeof(lo_fr) * k);
             COMMIT(VAR(o->out)); COMMIT(VAR(o->x));                        /* on_batch_equal(out, in) */

@@ -5,7 +5,8 @@ import ctypes as C
 import numpy as np
 
 OPS = dict(SET=0, SET_SCALAR=1, COPY=2, ADD=3, SUB=4, MUL=5, DIV=6, ADD_CONST=7, SUB_CONST=8, CONST_SUB=9, MUL_CONST=10,
-           MONTMUL_CONST=11, ASSERT_EQUAL=12, BIT_DECOMPOSE=13, FREE=14)
+           MONTMUL_CONST=11, ASSERT_EQUAL=12, BIT_DECOMPOSE=13, FREE=14, UPSTREAM_COMPAT=15)
+F_WRITE_LIMBS = 1        # lig_batch_op.reserved of SET / SET_SCALAR: written by the write_limbs family (nothing cleared)
 
 
 class BatchOp(C.Structure):
@@ -22,11 +23,15 @@ class Program:
         self.data += b
         return off
 
-    def _op(self, name, out=0, x=0, y=0, length=0, off=0):
-        self.ops.append((OPS[name], out, x, y, length, off))
+    def _op(self, name, out=0, x=0, y=0, length=0, off=0, flags=0):
+        self.ops.append((OPS[name], out, x, y, length, off, flags))
 
-    def set(self, x, values): self._op("SET", x=x, length=len(values), off=self._blob(b"".join(int(v).to_bytes(32, "little") for v in values)))
-    def set_scalar(self, x, v): self._op("SET_SCALAR", x=x, off=self._blob(int(v).to_bytes(32, "little")))
+    def upstream_compat(self): self._op("UPSTREAM_COMPAT")       # slices as src/webgpu/buffer_view.cpp:91-95 defines them, from here on
+
+    def set(self, x, values, limbs=False):
+        self._op("SET", x=x, length=len(values), off=self._blob(b"".join(int(v).to_bytes(32, "little") for v in values)), flags=F_WRITE_LIMBS if limbs else 0)
+
+    def set_scalar(self, x, v, limbs=False): self._op("SET_SCALAR", x=x, off=self._blob(int(v).to_bytes(32, "little")), flags=F_WRITE_LIMBS if limbs else 0)
     def copy(self, out, x): self._op("COPY", out=out, x=x)
     def add(self, out, x, y): self._op("ADD", out, x, y)
     def sub(self, out, x, y): self._op("SUB", out, x, y)
@@ -42,8 +47,8 @@ class Program:
     def pack(self):
         """-> (ops ctypes array, data ctypes array); keep both alive while a job points at them"""
         arr = (BatchOp * max(1, len(self.ops)))()
-        for i, (op, out, x, y, length, off) in enumerate(self.ops):
-            arr[i].op, arr[i].out, arr[i].x, arr[i].y, arr[i].len, arr[i].data_off = op, out, x, y, length, off
+        for i, (op, out, x, y, length, off, flags) in enumerate(self.ops):
+            arr[i].op, arr[i].out, arr[i].x, arr[i].y, arr[i].len, arr[i].data_off, arr[i].reserved = op, out, x, y, length, off, flags
         data = (C.c_uint8 * max(1, len(self.data))).from_buffer_copy(bytes(self.data) or b"\0")
         return arr, data
 

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/lig_hip_row_batcher.hpp"
@@ -23,7 +24,9 @@ using buffer_t = hip_context::buffer_type;
 struct stage_context {                    // what vbn254fr_module sees of a stage context
     stage_context(hip_context& e, ligero::hip_row_batcher& b) : exe(e), batcher(b) {}
     hip_context& executor() { return exe; }
-    void on_batch_init(buffer_t& x) { batcher.on_batch_init(x.data()); }
+    // nonbatch_context.hpp:502-505: the pad is written to x.slice(message_size * 32) -- through the view's slice(), so that the
+    // upstream slicing semantics (hip_context::set_upstream_slice_compat) decide where it lands
+    void on_batch_init(buffer_t& x) { batcher.on_batch_init(x.data(), x.slice(exe.message_size() * 32).data()); }
     void on_batch_bit(buffer_t& x) { batcher.on_batch_bit(x.data()); }
     void on_batch_equal(buffer_t& x, buffer_t& y) { batcher.on_batch_equal(x.data(), y.data()); }
     void on_batch_quadratic(buffer_t& x, buffer_t& y, buffer_t& z) { batcher.on_batch_quadratic(x.data(), y.data(), z.data()); }
@@ -71,13 +74,39 @@ static void guest(layer_t& v, bool with_bits) {
     v.finalize();
 }
 
+// a guest that is a true statement under BOTH slicing semantics of buffer_view: variable 0 through
+// write_buffer_clear, the others through the write_limbs family, one write_buffer_clear on a later variable (upstream: wipes
+// the slab up to the end of that variable; products of zeros still hold)
+static void guest_slicing(layer_t& v) {
+    using H = layer_t::handle_t;
+    H x[8];
+    for (auto& h : x) h = v.vbn254fr_alloc();
+    uint32_t ui[10];
+    for (int i = 0; i < 10; i++) ui[i] = 3 + 2 * i;
+    v.vbn254fr_set_ui(x[0], ui, 10);
+    v.vbn254fr_set_scalar(x[1], scalar_of(9, 0));
+    v.vbn254fr_mulmod(x[2], x[0], x[1]);
+    v.vbn254fr_set(x[3], {scalar_of(5, 0), scalar_of(6, 0), scalar_of(7, 0)});
+    v.vbn254fr_addmod(x[4], x[2], x[3]);
+    v.vbn254fr_copy(x[5], x[4]);
+    v.vbn254fr_mulmod(x[4], x[4], x[4]);
+    v.vbn254fr_set(x[2], {scalar_of(11, 0), scalar_of(12, 0)});
+    v.vbn254fr_mulmod(x[7], x[2], x[5]);
+    v.vbn254fr_set_ui_scalar(x[6], 77);
+    v.vbn254fr_mulmod(x[7], x[6], x[6]);
+    v.vbn254fr_mulmod(x[7], x[7], x[2]);
+    v.finalize();
+}
+
 int main(int argc, char** argv) {
-    if (argc < 5) { std::fprintf(stderr, "usage: %s n_linear n_quad with_bits k\n", argv[0]); return 2; }
+    if (argc < 5) { std::fprintf(stderr, "usage: %s n_linear n_quad with_bits k [slicing: declared | upstream]\n", argv[0]); return 2; }
     const uint32_t k = std::atoi(argv[4]), l = k - 192, n = 4 * k;
     const bool with_bits = std::atoi(argv[3]) != 0;
+    const bool slicing = argc > 5, upstream = slicing && std::string(argv[5]) == "upstream";
     hip_context executor;
     executor.webgpu_init(k, "");
     executor.ntt_init(l, k, n, 0, 0, 0, 0, 0);
+    executor.set_upstream_slice_compat(upstream);         // before the layer makes its slab
     lig_ctx* ctx = executor.native();
 
     lo_job j;
@@ -104,8 +133,9 @@ int main(int argc, char** argv) {
         {
             layer_t v(&sc);
             v.record(true);
-            guest(v, with_bits);
+            if (slicing) guest_slicing(v); else guest(v, with_bits);
             ops = v.recorded_ops(); data = v.recorded_data();
+            if (upstream != (!ops.empty() && ops[0].op == LIG_BOP_UPSTREAM_COMPAT)) throw std::runtime_error("the recorded program does not say which slicing it ran under");
         }
         static_assert(sizeof(lig_batch_op) == sizeof(lo_batch_op), "same program layout");
         j.batch_ops = reinterpret_cast<const lo_batch_op*>(ops.data()); j.n_batch_ops = ops.size();
@@ -142,7 +172,7 @@ int main(int argc, char** argv) {
         lo_rand_rows(&j, seed1, rands.data(), &cs);
         {
             layer_t v(&sc);
-            guest(v, with_bits);
+            if (slicing) guest_slicing(v); else guest(v, with_bits);
         }
         stream(&rands);
         size_t len = 0;

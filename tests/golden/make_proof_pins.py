@@ -24,13 +24,16 @@ JOBS = [
     dict(l=832, k=1024, n=4096, n_linear=2000, n_quad=900, generated_at=3, batch=None),
     dict(l=320, k=512, n=2048, n_linear=100, n_quad=0, generated_at=5, batch="demo"),
     dict(l=320, k=512, n=2048, n_linear=100, n_quad=0, generated_at=5, batch="demo_no_bits"),
+    # the two slicing semantics of buffer_view (include/lig_hip.h, LIG_BOP_UPSTREAM_COMPAT): declared / as upstream defines it
+    dict(l=320, k=512, n=2048, n_linear=100, n_quad=0, generated_at=5, batch="slicing_declared"),
+    dict(l=320, k=512, n=2048, n_linear=100, n_quad=0, generated_at=5, batch="slicing_upstream"),
 ]
 
 
 def run(job):
     j = ol.make_job(job["l"], job["k"], job["n"], 192, job["n_linear"], job["n_quad"], generated_at=job["generated_at"], threads=4)
     if job["batch"]:
-        tb.demo_program(with_bits=job["batch"] == "demo").attach(j)
+        tb.pin_program(job["batch"]).attach(j)
     pr = ol.Proof()
     assert ol.lib().lo_prove(C.byref(j), C.byref(pr)) == 0
     out = dict(job, rows=pr.rows, proof_len=pr.proof_len, proof_sha256=hashlib.sha256(bytes(pr.proof[:pr.proof_len])).hexdigest(),

@@ -46,6 +46,30 @@ def demo_program(bad_assert=False, with_bits=True):
     return p
 
 
+def slicing_program(upstream):
+    """a program on which the two slicing semantics of buffer_view (include/lig_hip.h, LIG_BOP_UPSTREAM_COMPAT) differ and which is a
+    TRUE statement under both: variable 0 through write_buffer_clear (the same either way), variables written by the write_limbs
+    family (data intact either way; their on_batch_init pads go to their own slots as declared / to variable 0's as upstream
+    defines slice_bytes), and one write_buffer_clear on variable 6 (declared: clears the rest of variable 6; upstream: wipes the
+    slab from variable 0's slot l to the end of variable 6 -- products of zeros still satisfy x*y = z)"""
+    p = batch_prog.Program()
+    if upstream:
+        p.upstream_compat()
+    p.set(0, [3 + 2 * i for i in range(10)])
+    p.set_scalar(1, 9, limbs=True)
+    p.mul(2, 0, 1)
+    p.set(3, [5, 6, 7], limbs=True)                          # slots 3.. keep what variable 3 held (zeros)
+    p.add(4, 2, 3)
+    p.copy(5, 4)
+    p.mul(4, 4, 4)
+    p.set(2, [11, 12], limbs=True)                           # over the product: slots 2.. keep the product's values
+    p.mul(7, 2, 5)
+    p.set_scalar(6, 77)
+    p.mul(7, 6, 6)
+    p.mul(7, 7, 2)
+    return p
+
+
 def oracle_prove(n_linear, n_quad, prog, threads=2):
     job = ol.make_job(L_, K_, N_, 192, n_linear, n_quad, generated_at=5, threads=threads)
     if prog is not None:
@@ -81,6 +105,86 @@ def test_oracle_batch_program_proves_and_verifies(n_linear, n_quad):
         assert ol.lib().lo_verify(C.byref(job2), cs, buf, len(proof)) == 0
     finally:
         ol.lib().lo_proof_free(C.byref(pr))
+
+
+@pytest.mark.parametrize("upstream", [False, True])
+def test_oracle_slicing_semantics_declared_and_upstream(upstream):
+    """both semantics give a valid, verifying proof of the slicing program -- and different ones: the upstream definition of
+    buffer_view::slice_bytes (src/webgpu/buffer_view.cpp:91-95) puts every on_batch_init pad into variable 0 and lets
+    write_buffer_clear wipe the slab up to the end of the variable"""
+    job, pr = oracle_prove(100, 0, slicing_program(upstream))
+    try:
+        assert (pr.valid_code, pr.valid_linear, pr.valid_quad) == (1, 1, 1)
+        proof = bytes(pr.proof[:pr.proof_len])
+        cs = (C.c_uint64 * 4)(*pr.const_sum)
+        buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+        assert ol.lib().lo_verify(C.byref(job), cs, buf, len(proof)) == 1
+        job2, pr2 = oracle_prove(100, 0, slicing_program(not upstream))
+        try:
+            assert pr2.rows == pr.rows and bytes(pr2.root) != bytes(pr.root)
+        finally:
+            ol.lib().lo_proof_free(C.byref(pr2))
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
+
+
+def test_oracle_upstream_slicing_rows_are_what_buffer_view_cpp_defines():
+    """row by row against a direct model of the reference's calls: views = (offset, size) pairs sliced as
+    buffer_view.cpp:91-95 defines slice_bytes, write_buffer / clear_buffer / copy on a byte array"""
+    l, k = L_, K_
+    job = ol.make_job(l, k, N_, 192, 1, 0, generated_at=5, threads=1)
+    slicing_program(True).attach(job)
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job)
+    # the model: a slab of 8 variables as python ints, upstream's slice_bytes
+    slab = [0] * (8 * k)
+    enc = ol.rng_fill(bytes(job.encoding_seed), 0, 192 * 6).reshape(-1, 8)     # pads of the 6 init rows, in program order
+    to_int = lambda e: int.from_bytes(np.asarray(e, dtype=np.uint32).tobytes(), "little")
+    n_init = [0]
+
+    def slice_up(view, begin):                               # buffer_view::slice<u8>(begin) -> slice_bytes(begin, size - begin), as DEFINED
+        off, size = view
+        return (begin, off + (size - begin))
+
+    def init(x_elem):                                        # on_batch_init: write 192 pads at x.slice(l * 32), then commit x
+        off, _ = slice_up((x_elem * 32, k * 32), l * 32)
+        for i in range(192):
+            slab[off // 32 + i] = to_int(enc[192 * n_init[0] + i])
+        n_init[0] += 1
+        return slab[x_elem:x_elem + k]
+
+    def write_clear(x_elem, vals):                           # write_buffer_clear: write, then clear_buffer(x.slice(len * 32))
+        for i, v in enumerate(vals):
+            slab[x_elem + i] = v
+        off, size = slice_up((x_elem * 32, k * 32), len(vals) * 32)
+        for e in range(off // 32, (off + size) // 32):
+            slab[e] = 0
+
+    def write(x_elem, vals):
+        for i, v in enumerate(vals):
+            slab[x_elem + i] = v
+
+    want = []
+    V = lambda i: i * k
+    mul = lambda a, b: [(x * y) % P for x, y in zip(slab[a:a + k], slab[b:b + k])]
+    write_clear(V(0), [3 + 2 * i for i in range(10)]); want.append(init(V(0)))
+    write(V(1), [9] * l); want.append(init(V(1)))
+    t = mul(V(0), V(1)); want += [slab[V(0):V(0) + k], slab[V(1):V(1) + k], t]; slab[V(2):V(2) + k] = t
+    write(V(3), [5, 6, 7]); want.append(init(V(3)))
+    slab[V(4):V(4) + k] = [(x + y) % P for x, y in zip(slab[V(2):V(2) + k], slab[V(3):V(3) + k])]
+    slab[V(5):V(5) + k] = slab[V(4):V(4) + k]; want += [slab[V(5):V(5) + k], slab[V(4):V(4) + k]]
+    t = mul(V(4), V(4)); want += [slab[V(4):V(4) + k], slab[V(4):V(4) + k], t]; slab[V(4):V(4) + k] = t
+    write(V(2), [11, 12]); want.append(init(V(2)))
+    t = mul(V(2), V(5)); want += [slab[V(2):V(2) + k], slab[V(5):V(5) + k], t]; slab[V(7):V(7) + k] = t
+    write_clear(V(6), [77] * l); want.append(init(V(6)))
+    t = mul(V(6), V(6)); want += [slab[V(6):V(6) + k], slab[V(6):V(6) + k], t]; slab[V(7):V(7) + k] = t
+    t = mul(V(7), V(2)); want += [slab[V(7):V(7) + k], slab[V(2):V(2) + k], t]; slab[V(7):V(7) + k] = t
+    nb = int((np.asarray(kinds) >= 4).sum())
+    assert nb == len(want) == 5 + 3 + 2 + 3 + 3 + 3 + 3
+    for r in range(nb):
+        got = [to_int(e) for e in rows[r]]
+        assert got == want[r], "batch row %d" % r
+    assert all(v == 0 for v in want[-1][:l]) and any(want[0])          # variable 6's write_buffer_clear wiped the slab: zeros from there on
 
 
 def test_oracle_false_equality_fails_the_quadratic_test():
@@ -155,6 +259,27 @@ def test_hip_batch_rows_equal_oracle(amd, n_linear, n_quad, bits):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("upstream", [False, True])
+def test_hip_slicing_semantics_equal_oracle(amd, upstream):
+    """LIG_BOP_UPSTREAM_COMPAT / LIG_BOP_F_WRITE_LIMBS on the device interpreter (csrc/prover.hip, lig_run_batch_program): the
+    envelope equals the oracle's under the declared and under the upstream slicing semantics"""
+    prog = slicing_program(upstream)
+    ojob, pr = oracle_prove(700, 330, prog, threads=4)
+    c = amd.Context(L_, K_, N_)
+    try:
+        job = prog.attach(amd.Context.make_job(700, 330, generated_at=5))
+        tr = c.synth_prepare_job(job)
+        proof, info = c.synth_prove(tr)
+        c.trace_destroy(tr)
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert bytes(info.root) == bytes(pr.root) and proof == bytes(pr.proof[:pr.proof_len])
+        assert c.synth_verify(job, bytes(info.const_sum), proof).accept == 1
+    finally:
+        ol.lib().lo_proof_free(C.byref(pr))
+        c.close()
+
+
+@pytest.mark.gpu
 def test_hip_false_equality_fails_quadratic_test_and_bad_program_is_rejected(amd):
     prog = demo_program(bad_assert=True, with_bits=False)
     ojob, pr = oracle_prove(100, 0, prog)
@@ -190,6 +315,11 @@ import os                                           # noqa: E402
 PINS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_pins.json")))["jobs"]
 
 
+def pin_program(name):
+    return {"demo": lambda: demo_program(with_bits=True), "demo_no_bits": lambda: demo_program(with_bits=False),
+            "slicing_declared": lambda: slicing_program(False), "slicing_upstream": lambda: slicing_program(True)}[name]()
+
+
 def _pin_id(p):
     return "l%d_k%d_lin%d_quad%d_%s" % (p["l"], p["k"], p["n_linear"], p["n_quad"], p["batch"] or "nobatch")
 
@@ -199,7 +329,7 @@ def test_oracle_matches_whole_proof_pins(pin):
     """tests/golden/proof_pins.json (made by tests/golden/make_proof_pins.py from this oracle): drift detector"""
     j = ol.make_job(pin["l"], pin["k"], pin["n"], 192, pin["n_linear"], pin["n_quad"], generated_at=pin["generated_at"], threads=2)
     if pin["batch"]:
-        demo_program(with_bits=pin["batch"] == "demo").attach(j)
+        pin_program(pin["batch"]).attach(j)
     pr = ol.Proof()
     assert ol.lib().lo_prove(C.byref(j), C.byref(pr)) == 0
     try:
@@ -216,7 +346,7 @@ def test_hip_matches_whole_proof_pins(amd, pin):
     try:
         job = amd.Context.make_job(pin["n_linear"], pin["n_quad"], generated_at=pin["generated_at"])
         if pin["batch"]:
-            demo_program(with_bits=pin["batch"] == "demo").attach(job)
+            pin_program(pin["batch"]).attach(job)
         tr = c.synth_prepare_job(job)
         proof, info = c.synth_prove(tr)
         c.trace_destroy(tr)

@@ -170,6 +170,17 @@ def test_row_batcher_bench_at_2p20_matches_the_oracle_on_every_path():
     assert out["ok"] == 1 and out["checked_against_oracle"] == 1 and out["rows"] == 135
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("slicing", ["declared", "upstream"])
+def test_vbn254fr_layer_under_both_slicing_semantics_gives_the_oracle_envelope(slicing):
+    """hip_context::set_upstream_slice_compat: the vbn254fr layer + the shim's on_batch_init run a guest under buffer_view's declared
+    slicing and under upstream's definition of slice_bytes (src/webgpu/buffer_view.cpp:91-95: parameters swapped -- pads land in
+    variable 0, write_buffer_clear wipes the slab); the program the layer RECORDS says which (LIG_BOP_UPSTREAM_COMPAT,
+    LIG_BOP_F_WRITE_LIMBS) and the oracle's interpreter of that program gives the same envelope"""
+    out = subprocess.check_output([build_batch_batcher_exe(), "900", "330", "0", "512", slicing]).decode()
+    assert out.startswith("equal 1 "), out
+
+
 SBSRC = os.path.join(ROOT, "tests", "cpp", "sharded_batcher_prog.cpp")
 SBEXE = os.path.join(ROOT, "tests", "cpp", "sharded_batcher_prog")
 
