@@ -39,8 +39,10 @@ class Model:
     def __init__(self):
         self.log, self.inits = [], 0
 
-    def init(self, vals):
-        x = list(vals) + [0] * (K_ - len(vals))
+    def init(self, vals, keep=None):
+        """keep: the variable's previous content -- the write_limbs family (vbn254fr_set_str / _set_bytes, vbn254fr.hpp:200,251)
+        clears nothing, slots beyond the written ones stay; None: write_buffer_clear (vbn254fr_set_ui, :154) zeroes the rest"""
+        x = list(vals) + (list(keep[len(vals):]) if keep is not None else [0] * (K_ - len(vals)))
         for j in range(K_ - L_):
             x[L_ + j] = 1000 * self.inits + j
         self.inits += 1
@@ -71,7 +73,7 @@ def replay():
     d = list(e); m.equal(d, e)
     m.equal(e, e)
     z = [x * x % P for x in e]; m.quad(e, e, z); e = z
-    c = m.init([(0xffffffffffffffff | (0x1fffffffffffffff << 128)) % P, 1, 0])
+    c = m.init([(0xffffffffffffffff | (0x1fffffffffffffff << 128)) % P, 1, 0], keep=c)      # vbn254fr_set over the product a*b
     d = m.init([Kc] * L_)
     c = [(x + y) % P for x, y in zip(c, d)]
     q = [x * inv(y) % P if y else 0 for x, y in zip(d, c)]; m.quad(q, c, d); c = q
