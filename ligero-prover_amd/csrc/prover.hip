@@ -549,7 +549,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     lig::launch_lin_interleave(s, lin, linH, linC, k);
     HIP_TRY(c, hipMemsetAsync(lin + 2 * (size_t)k, 0, (size_t)(n - 2 * k) * 32, s));
     const lig::CwView view{T->msgs, T->cw, k};
-    lig::launch_quad_rows29_view(s, view, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad);
+    // (the group partials of the row loop have been combined above: their space holds the quadratic test's group sums now)
+    lig::launch_quad_rows29_view(s, view, 2 * k, T->tri_dev, T->coef_dev + R, T->coef_dev + R + NT, NT, quad, T->parts, 2 * groups * (size_t)n);
     // Each accumulator is extended to the n evaluation points, masked (nonbatch_context.hpp:739-753) and sent to the host
     // as soon as it is final; the host absorbs it into the stage-2 seed hash (a sequential SHA-256 over 3 MiB, the longest
     // host step of the proof) while the GPU extends the next one.

@@ -26,9 +26,9 @@ void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t firs
 void launch_rlc_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
                        const f29s* rc_dev, fr* code, fr* lin, fr* part_code, fr* part_lin, uint32_t group_rows);
 void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
-                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad);
+                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad, fr* part = nullptr, size_t part_elems = 0);
 void launch_quad_rows29_view(hipStream_t s, CwView cw, uint32_t count, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
-                             size_t n_triples, fr* quad);
+                             size_t n_triples, fr* quad, fr* part = nullptr, size_t part_elems = 0);
 void launch_sum_elems(hipStream_t s, const fr* in, uint32_t count, uint32_t stride, fr* out, fr* neg_out);
 void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, const fr* Rn, size_t rrs, size_t rows, uint32_t count,
                              const f29s* rc_dev, fr* part_code, fr* part_lin, uint32_t group_rows);

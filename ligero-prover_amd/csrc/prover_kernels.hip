@@ -56,14 +56,21 @@ __global__ void __launch_bounds__(256) k_rlc_combine(fr* __restrict__ acc, const
 // <w_n^2> (codeword elements 2j) of a CwView: even j from the message row, odd j from the coset-2 plane.
 struct StridedRows { const fr* U; size_t urs; uint32_t ues; __device__ const fr* at(size_t row, uint32_t j) const { return U + row * urs + (size_t)j * ues; } };
 struct EvenOfView { CwView v; __device__ const fr* at(size_t row, uint32_t j) const { return v.at(row, 2 * j); } };
+// gridDim.y > 1: the terms are cut into gridDim.y groups of `per_group`, group g writes its sum (< 2p) to part[g * count + j] and
+// k_rlc_combine adds the groups to quad -- a trace with a thousand triples is a thousand dependent iterations per thread on
+// 64 workgroups otherwise (2.5 ms of a 23 ms proof with half of the constraints quadratic, profiles/r04_quad_mix.md)
 template <class Src>
 __global__ void __launch_bounds__(256) k_quad_rows(Src src, uint32_t count,
                                                    const uint32_t* __restrict__ triples, const f29s* __restrict__ rq2,
-                                                   const f29s* __restrict__ rq1, size_t n_triples, fr* __restrict__ quad) {
+                                                   const f29s* __restrict__ rq1, size_t n_triples, fr* __restrict__ quad,
+                                                   fr* __restrict__ part, size_t per_group) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    f29 a = unpack29(fr_load(quad + j));
-    for (size_t t = 0; t < n_triples; t++) {
+    const bool grouped = part != nullptr;
+    const size_t t0 = grouped ? (size_t)blockIdx.y * per_group : 0;
+    const size_t t1 = grouped ? (t0 + per_group < n_triples ? t0 + per_group : n_triples) : n_triples;
+    f29 a = grouped ? f29_zero() : unpack29(fr_load(quad + j));
+    for (size_t t = t0; t < t1; t++) {
         const uint32_t yi = triples[3 * t + 1];
         const f29 x = unpack29(fr_load(src.at(triples[3 * t], j)));
         const f29 z = unpack29(fr_load(src.at(triples[3 * t + 2], j)));
@@ -74,7 +81,8 @@ __global__ void __launch_bounds__(256) k_quad_rows(Src src, uint32_t count,
         a = f29_add(a, f29_add(xy, f29_sub_k2(f29_zero(), zq)));                    // + xy + (2p - zq)
         a = f29_reduce_2p(a);
     }
-    fr_store(quad + j, pack29(f29_canon(a)));
+    if (grouped) fr_store(part + (size_t)blockIdx.y * count + j, pack29(a));        // normalised, < 2p: what k_rlc_combine adds up
+    else fr_store(quad + j, pack29(f29_canon(a)));
 }
 
 // one group-partial pass + combine.  Either rc_dev (code-type: acc_code += sum rc*U) or Rn (linear-type:
@@ -99,16 +107,29 @@ void launch_rlc_accumulate29(hipStream_t s, const fr* U, size_t urs, uint32_t ue
 void launch_rlc_combine(hipStream_t s, fr* acc, const fr* part, uint32_t groups, uint32_t count) {
     hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, acc, part, groups, count);
 }
-void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
-                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad) {
+// part (optional): scratch of part_elems elements for group partials; with it and enough terms the sum runs in up to 64 groups
+template <class Src>
+static void launch_quad_any(hipStream_t s, Src src, uint32_t count, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1, size_t n_triples,
+                            fr* quad, fr* part, size_t part_elems) {
     if (!n_triples) return;
-    hipLaunchKernelGGL(k_quad_rows<StridedRows>, dim3((count + 255) / 256), dim3(256), 0, s, StridedRows{U, urs, ues}, count, triples_dev, rq2, rq1, n_triples, quad);
+    size_t groups = part ? std::min<size_t>(std::min<size_t>(64, part_elems / count), (n_triples + 15) / 16) : 1;     // >= 16 terms per group
+    if (groups < 2) {
+        hipLaunchKernelGGL(k_quad_rows<Src>, dim3((count + 255) / 256), dim3(256), 0, s, src, count, triples_dev, rq2, rq1, n_triples, quad, (fr*)nullptr, (size_t)0);
+        return;
+    }
+    const size_t per_group = (n_triples + groups - 1) / groups;
+    groups = (n_triples + per_group - 1) / per_group;
+    hipLaunchKernelGGL(k_quad_rows<Src>, dim3((count + 255) / 256, (uint32_t)groups), dim3(256), 0, s, src, count, triples_dev, rq2, rq1, n_triples, quad, part, per_group);
+    hipLaunchKernelGGL(k_rlc_combine, dim3((count + 255) / 256), dim3(256), 0, s, quad, part, (uint32_t)groups, count);
+}
+void launch_quad_rows29(hipStream_t s, const fr* U, size_t urs, uint32_t ues, uint32_t count, const uint32_t* triples_dev,
+                        const f29s* rq2, const f29s* rq1, size_t n_triples, fr* quad, fr* part, size_t part_elems) {
+    launch_quad_any(s, StridedRows{U, urs, ues}, count, triples_dev, rq2, rq1, n_triples, quad, part, part_elems);
 }
 // the same sum over the 2k even codeword positions of a planar codeword matrix
 void launch_quad_rows29_view(hipStream_t s, CwView cw, uint32_t count, const uint32_t* triples_dev, const f29s* rq2, const f29s* rq1,
-                             size_t n_triples, fr* quad) {
-    if (!n_triples) return;
-    hipLaunchKernelGGL(k_quad_rows<EvenOfView>, dim3((count + 255) / 256), dim3(256), 0, s, EvenOfView{cw}, count, triples_dev, rq2, rq1, n_triples, quad);
+                             size_t n_triples, fr* quad, fr* part, size_t part_elems) {
+    launch_quad_any(s, EvenOfView{cw}, count, triples_dev, rq2, rq1, n_triples, quad, part, part_elems);
 }
 
 // ---------------------------------------------------------------------------------------------- linear-test constant

@@ -524,7 +524,7 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     lig::launch_rlc_combine(s, linC, p_linC, dot_groups, k);
     lig::launch_lin_interleave(s, lin, linH, linC, k);       // see lig_synth_prove: even points of <w_n^2> = message domain
     const lig::CwView view{S->msgs, S->cw, k};
-    lig::launch_quad_rows29_view(s, view, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad);
+    lig::launch_quad_rows29_view(s, view, 2 * k, S->tri_dev, S->coef_dev + Rl, S->coef_dev + Rl + NTl, NTl, quad, S->parts, 2 * (size_t)pg * k);
     // partial sums [code (k message values) | lin (2k) | quad (2k)] -> every rank -> added mod p (one rank: they are the sums)
     if (W > 1 || S->exchange_even_alone) {
         HIP_TRY(c, hipMemcpyAsync(S->accp, tmp, (size_t)k * 32, hipMemcpyDeviceToDevice, s));
