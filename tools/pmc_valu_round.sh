@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc
-CMD="python bench.py --no-cpu-baseline --no-h2d --no-verify --no-sharded-leg --inflight 1 --steps 2 --warmup 1"
+CMD="python bench.py --no-cpu-baseline --no-h2d --no-verify --no-sharded-leg --quad-mix 0 --inflight 1 --steps 2 --warmup 1"
 for c in VALUBusy LDSBankConflict MemUnitStalled; do
     rm -rf /tmp/pmcv_$c
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcv_$c -o pmc -- $CMD > /dev/null 2> gpurun_out/pmc/full_$c.err || true
