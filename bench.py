@@ -953,10 +953,10 @@ def main():
             out["roofline"]["hbm_frac_end_to_end"] = e2e / 8000.0
             out["roofline"]["end_to_end_GBps"] = e2e
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_valu_lds_full_proof.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_pmc_valu_lds_full_proof.json")) as f:
                 out["roofline"]["valu_busy_pct"] = {kname: v.get("VALUBusy") for kname, v in json.load(f).get("kernels", {}).items()
                                                     if v.get("VALUBusy", 0) >= 20}
-                out["roofline"]["valu_busy_source"] = ("profiles/r03_pmc_valu_lds_full_proof.json (rocprofv3 --pmc VALUBusy over full proofs, one in flight; "
+                out["roofline"]["valu_busy_source"] = ("profiles/r04_pmc_valu_lds_full_proof.json (rocprofv3 --pmc VALUBusy over full proofs, one in flight; "
                                                        "a committed measurement of this build, not taken in this run)")
         except (OSError, ValueError):
             pass
@@ -964,12 +964,12 @@ def main():
             # chip-wide: the VALU issue time ONE proof needs (sum over all its launches of stand-alone duration x VALUBusy, a committed PMC
             # pass of this build: tools/valu_budget.sh) against the time the bench takes per proof -- the fraction of issue slots in use
             try:
-                with open(os.path.join(ROOT, "profiles", "r03_valu_budget.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r04_valu_budget.json")) as f:
                     busy_ms = json.load(f)["valu_busy_ms_per_proof"]
                 ms_per_proof = 1e3 * dt / a.steps / max(1, getattr(wl, "inflight", 1))
                 out["roofline"]["valu_issue"] = {"busy_ms_per_proof": busy_ms, "measured_ms_per_proof": ms_per_proof, "frac": busy_ms / ms_per_proof,
-                                                 "source": "profiles/r03_valu_budget.json (rocprofv3 --pmc VALUBusy --kernel-trace over full proofs of this build; "
-                                                           "a committed measurement, not taken in this run), see profiles/r03_valu_budget.md"}
+                                                 "source": "profiles/r04_valu_budget.json (rocprofv3 --pmc VALUBusy --kernel-trace over full proofs of this build; "
+                                                           "a committed measurement, not taken in this run), see profiles/r03_valu_budget.md (method) and DESIGN.md section 4"}
             except (OSError, ValueError, KeyError):
                 pass
         out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the bench contract of this repo: the PCIe-inclusive rate "
