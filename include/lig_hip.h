@@ -393,7 +393,7 @@ void lig_shard_destroy(lig_shard *shard);
  * The sharded entry takes full-width rows only: job->elem_bytes must be NULL (LIG_E_ARG otherwise). ==== */
 int lig_shard_rows_plan(const uint8_t *kinds, size_t n_rows, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
 int lig_shard_rows_begin(lig_ctx *ctx, const lig_rows_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
-int lig_shard_rows_restart(lig_shard *shard, const void *local_msgs, int msgs_on_device);   /* next trace, same shape */
+int lig_shard_rows_restart(lig_shard *shard, const void *local_msgs, int msgs_on_device);   /* next trace, same shape; after lig_shard_rows_prove of the previous one (LIG_E_STATE otherwise) */
 int lig_shard_rows_commit(lig_shard *shard, uint8_t root[32], uint8_t stage1_seed[32]);
 int lig_shard_rows_prove(lig_shard *shard, const void *local_rands, int rands_on_device, const uint8_t *const_sum,
                          const uint8_t **proof, size_t *proof_len, lig_proof_info *info);

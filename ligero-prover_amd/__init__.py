@@ -640,6 +640,20 @@ class Context:
             return (C.addressof(proof.contents), ln.value), info
         return C.string_at(proof, ln.value), info
 
+    def host_alloc(self, nbytes):
+        """page-locked host memory (lig_host_alloc) as a uint8 numpy view; keep the returned (array, ptr) until host_free(ptr)"""
+        p = C.c_void_p()
+        self.check(self.L.lig_host_alloc(self.h, nbytes, C.byref(p)))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(1, nbytes),))[:nbytes]
+        return arr, p
+
+    def host_free(self, p):
+        self.check(self.L.lig_host_free(self.h, p))
+
+    def rows_push_rands(self, trace, first_row, n_rows, host_ptr):
+        """lig_rows_push_rands: randomness rows [first_row, first_row + n_rows), host memory valid until rows_prove returns"""
+        self.check(self.L.lig_rows_push_rands(trace, first_row, n_rows, C.c_void_p(host_ptr)))
+
     def rows_verify_begin(self, kinds, proof, public_args=None):
         """-> (vtrace or None, stage1_seed bytes, VerifyInfo): the verifier's first half for a rows job (kinds + public data)"""
         kinds = np.ascontiguousarray(kinds, dtype=np.uint8)

@@ -1027,6 +1027,13 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     *info = T->info1;
     const auto t_begin = clk::now();
     RandSource rs;                                        // default: generated from the dense counts of the job
+    if (rands && T->rands_pushed) {                       // explicit rows win over rows pushed earlier: drop what the uploader still holds of those
+        T->up_abort.store(1, std::memory_order_release);
+        uploader_drain(T);
+        T->up_abort.store(0, std::memory_order_release);
+        (void)T->up_failed.exchange(0);
+        T->rands_pushed = 0;
+    }
     if (rands && rands_on_device) rs.dev = (const fr*)rands; else if (rands) rs.host = (const uint8_t*)rands;
     else if (T->rands_pushed) {
         if (T->rands_pushed != T->R) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_push_rands has not delivered every row");

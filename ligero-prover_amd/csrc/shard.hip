@@ -775,6 +775,8 @@ int lig_shard_rows_restart(lig_shard* S, const void* local_msgs, int msgs_on_dev
     lig_ctx* c = S->c;
     CHECK_CTX(c);
     if (!S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_rows_restart: not a rows shard");
+    // (unlike lig_rows_restart there is no second message matrix here: stage 2 of a committed trace still reads the local rows)
+    if (S->committed) FAIL(c, LIG_E_STATE, "lig_shard_rows_restart: the committed trace has not been proved yet");
     return shard_rows_load(S, local_msgs, msgs_on_device != 0);
 }
 int lig_shard_rows_commit(lig_shard* S, uint8_t root[32], uint8_t stage1_seed[32]) {

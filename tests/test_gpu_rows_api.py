@@ -330,3 +330,46 @@ def test_rows_entry_narrow_row_format_equals_oracle(amd, bits, n_linear, n_quad,
             c.rows_begin(kk, packed, generated_at=31, elem_bytes=w2)
     finally:
         c.close()
+
+
+def test_rows_push_rands_in_pieces_equals_rows_prove_with_all_rows(amd):
+    """lig_rows_push_rands (the stage-2 callbacks of a constraint generator deliver their rows one at a time, nonbatch_context.hpp:
+    654-712): randomness rows handed over in three pieces from page-locked memory (lig_host_alloc) while "the guest runs", then
+    lig_rows_prove(rands = NULL) -- the envelope of lig_rows_prove with the whole matrix, which is the oracle's; gaps, disorder and a
+    proof before the last piece are refused"""
+    l, k, n = 320, 512, 2048
+    job = ol.make_job(l, k, n, 192, 320 * 700 + 5, 330, generated_at=12, threads=8)          # 701 + 6 rows: two stage-2 chunks
+    want = oracle_prove(job)
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job)
+    R = rows.shape[0]
+    c = amd.Context(l, k, n)
+    try:
+        tr, keep = c.rows_begin(kinds, rows, generated_at=12)
+        root, seed1 = c.rows_commit(tr)
+        rands, const_sum = ol.rand_rows(job, seed1)
+        pinned, ptr = c.host_alloc(R * k * 32)
+        pinned[:] = np.ascontiguousarray(rands, dtype=np.uint32).view(np.uint8).reshape(-1)
+        base = ptr.value
+        with pytest.raises(amd.LigError):
+            c.rows_push_rands(tr, 5, 10, base + 5 * k * 32)                      # not from row 0
+        cuts = [0, 200, 513, R]
+        for a, b in zip(cuts[:-2], cuts[1:-1]):
+            c.rows_push_rands(tr, a, b - a, base + a * k * 32)
+        with pytest.raises(amd.LigError):
+            c.rows_push_rands(tr, cuts[-2] + 1, 1, base)                           # a gap
+        with pytest.raises(amd.LigError):
+            c.rows_prove(tr, None, const_sum)                                      # not every row delivered yet
+        c.rows_push_rands(tr, cuts[-2], R - cuts[-2], base + cuts[-2] * k * 32)   # (the refused prove dropped nothing: the last piece completes the matrix)
+        proof, info = c.rows_prove(tr, None, const_sum)
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert proof == want["proof"]
+        # the same trace again with the whole matrix in one call: same bytes
+        c.rows_restart(tr, np.ascontiguousarray(rows, dtype=np.uint32).ctypes.data)
+        assert c.rows_commit(tr) == (root, seed1)
+        proof2, _ = c.rows_prove(tr, rands, const_sum)
+        assert proof2 == proof
+        c.trace_destroy(tr)
+        c.host_free(ptr)
+    finally:
+        c.close()
