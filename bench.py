@@ -972,8 +972,9 @@ def main():
                                                            "a committed measurement, not taken in this run), see profiles/r03_valu_budget.md (method) and DESIGN.md section 4"}
             except (OSError, ValueError, KeyError):
                 pass
-        out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the bench contract of this repo: the PCIe-inclusive rate "
-                                   "is never `value`); SURVEY 8(d)'s H2D-inclusive figure is value_incl_h2d, measured in the same run")
+        out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the measurement contract this build is judged by reserves `value` for "
+                                   "inputs resident in HBM; a PCIe-inclusive rate is reported beside it, never as `value`); SURVEY 8(d)'s H2D-inclusive figure is "
+                                   "value_incl_h2d, and with the caller's randomness rows from host memory as well incl_h2d.caller_rands, measured in the same run")
         if quad_mix is not None:
             out["quad_mix"] = quad_mix
         if incl is not None:
