@@ -6,6 +6,5 @@ f=$1; pat=$2; root=$(cd "$(dirname "$0")/.." && pwd); tmp=$(mktemp -d)
 awk -v p="$pat" '$0 ~ "^_ZN3lig[0-9]*" p ".*:" {f=1} f{print} f&&/s_endpgm/{exit}' $tmp/k.s > $tmp/body.s
 echo "# $f  $pat  ($(grep -cE '^\s+[vs]_|^\s+ds_|^\s+buffer_|^\s+global_' $tmp/body.s) instructions)"
 grep -E "^\s+[vs]_|^\s+ds_|^\s+buffer_|^\s+global_" $tmp/body.s | awk '{print $1}' | sort | uniq -c | sort -rn
-awk -v p="$pat" '$0 ~ "^_ZN3lig[0-9]*" p ".*:" {f=1} f&&/\.vgpr_count|\.sgpr_count|NumVgprs|ScratchSize|LDSByteSize|Occupancy/{print}' $tmp/k.s | head -8
 grep -A40 "amdhsa_kernel _ZN3lig[0-9]*$pat" $tmp/k.s | grep -E "next_free_vgpr|group_segment_fixed_size|private_segment_fixed_size" | head -3
 rm -rf $tmp
