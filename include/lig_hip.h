@@ -296,6 +296,11 @@ int lig_rows_prove(lig_trace *trace, const void *rands, int rands_on_device, con
  * lig_rows_prove returns.  The upload starts at once (the library's uploader thread) into a device-resident matrix.  When all
  * rows have been pushed, lig_rows_prove(rands = NULL) uses them: stage 2 waits chunk by chunk for what is still on the bus. */
 int lig_rows_push_rands(lig_trace *trace, uint64_t first_row, uint64_t n_rows, const void *host_rows);
+/* The same for a generator that puts no linear constraint on many rows (the narrow format of randomness rows): present[i] != 0
+ * says that row first_row + i has a randomness row; the present rows follow each other in host_rows (k x 32 bytes each), the
+ * others are zero rows and are not shipped -- batch-kind rows always are (nonbatch_context.hpp:782-850 hands no randomness to the
+ * vbn254fr hooks), quadratic rows often.  present == NULL: every row is present. */
+int lig_rows_push_rands_sparse(lig_trace *trace, uint64_t first_row, uint64_t n_rows, const uint8_t *present, const void *host_rows);
 /* the next trace of the same shape (same kinds, seeds, metadata) with new message rows, reusing every buffer of `trace`
  * (no allocation on the proving path of a service); same upload semantics as lig_rows_begin.  It may be called right
  * after lig_rows_commit, BEFORE lig_rows_prove of the committed trace: the new rows then go to a second message matrix

@@ -115,10 +115,12 @@ public:
     uint64_t* next_slot() {
         if (pass_ == 1) { rows_.reserve(kinds_.size() + 1, kinds_.size()); return rows_.row(kinds_.size()); }
         if (pass_ != 2 || next_ >= kinds_.size()) throw std::logic_error("hip_row_batcher::next_slot: no row expected");
-        const size_t slot = sharded_ ? local_of_[next_] : next_;
+        if (!sharded_) return rands_.row(n_present_);            // randomness rows are kept packed: only rows that have one take a slot
+        const size_t slot = local_of_[next_];
         return slot == (size_t)-1 ? nullptr : rands_.row(slot);
     }
-    void commit_slot(uint8_t kind) { row(kind, pass_ == 1 ? rows_.row(kinds_.size()) : nullptr, nullptr, true); }
+    // has_rand = false in pass 2: the row has no randomness row (nothing was exported into the slot; it stays free for the next row)
+    void commit_slot(uint8_t kind, bool has_rand = true) { row(kind, pass_ == 1 ? rows_.row(kinds_.size()) : nullptr, nullptr, true, has_rand); }
     void mask_callback(size_t code_size, size_t linear_size, size_t quad_size) const {
         if (code_size != k_ || linear_size != 2 * (size_t)k_ || quad_size != 2 * (size_t)k_) throw std::invalid_argument("mask_callback: unexpected mask sizes");
     }
@@ -244,13 +246,16 @@ private:
     }
     void begin_pass2(size_t local_rows) {
         rands_.reserve(local_rows ? local_rows : 1, 0);
-        pass_ = 2; next_ = 0; enc_pos_ = 0; pushed_ = 0;  // the guest's second run starts the encoding stream over
+        present_.assign(kinds_.size(), 0);
+        pass_ = 2; next_ = 0; enc_pos_ = 0; pushed_ = 0; n_present_ = 0; pushed_present_ = 0;  // the guest's second run starts the encoding stream over
     }
-    // randomness rows [pushed_, upto) are complete: hand them to the library while the guest goes on (lig_rows_push_rands)
+    // randomness rows [pushed_, upto) are complete: hand them to the library while the guest goes on.  Only the rows that HAVE a
+    // randomness row are in the staging (packed) and go over the link; the library zero-fills the others on the device
+    // (lig_rows_push_rands_sparse) -- batch rows never have one, quadratic rows often do not.
     void push_rands(size_t upto) {
         if (sharded_ || upto <= pushed_) return;
-        check(lig_rows_push_rands(trace_, pushed_, upto - pushed_, rands_.row(pushed_)), "lig_rows_push_rands");
-        pushed_ = upto;
+        check(lig_rows_push_rands_sparse(trace_, pushed_, upto - pushed_, present_.data() + pushed_, rands_.row(pushed_present_)), "lig_rows_push_rands_sparse");
+        pushed_ = upto; pushed_present_ = n_present_;
     }
     void commit_sharded(lig_rows_job& job, uint8_t root[32], uint8_t stage1_seed[32]) {
         const size_t R = kinds_.size(), words = (size_t)k_ * 4;
@@ -275,7 +280,7 @@ private:
     void check(int rc, const char* what) const {
         if (rc != LIG_OK) throw std::runtime_error(std::string(what) + ": " + lig_last_error(ctx_));
     }
-    void row(uint8_t kind, const uint64_t* val, const uint64_t* rand, bool in_slot = false) {
+    void row(uint8_t kind, const uint64_t* val, const uint64_t* rand, bool in_slot = false, bool slot_has_rand = true) {
         const size_t words = (size_t)k_ * 4;
         // witness_manager pads every linear row and every row of a quadratic triple with k - l stream elements when it forms
         // it (the rows arrive with their pads): the position of the next on_batch_init pad moves past them
@@ -288,10 +293,13 @@ private:
         } else if (pass_ == 2) {
             // the guest is deterministic: pass 2 must replay the callbacks of pass 1 in the same order
             if (next_ >= kinds_.size() || kinds_[next_] != kind) throw std::logic_error("hip_row_batcher: pass 2 diverges from pass 1");
-            const size_t slot = sharded_ ? local_of_[next_] : next_;                 // sharded: only the randomness rows of this rank's rows are kept
-            if (slot != (size_t)-1 && !in_slot) {
-                if (rand) std::memcpy(rands_.row(slot), rand, words * 8);
-                else if (!sharded_) std::memset(rands_.row(slot), 0, words * 8);     // (the staging is reused: a row without randomness is a zero row)
+            if (sharded_) {                                                          // dense local matrix: only the rows of this rank's chunks are kept
+                const size_t slot = local_of_[next_];
+                if (slot != (size_t)-1 && !in_slot && rand) std::memcpy(rands_.row(slot), rand, words * 8);
+            } else if (in_slot ? slot_has_rand : rand != nullptr) {                   // packed: this row takes the next slot
+                if (!in_slot) std::memcpy(rands_.row(n_present_), rand, words * 8);
+                present_[next_] = 1;
+                n_present_++;
             }
             next_++;
             if (!sharded_ && next_ - pushed_ >= push_rows) push_rands(next_);
@@ -312,7 +320,8 @@ private:
     hip_proof_meta meta_, shape_meta_;
     uint32_t k_, l_;
     int pass_ = 1;
-    size_t next_ = 0, pushed_ = 0;
+    size_t next_ = 0, pushed_ = 0, n_present_ = 0, pushed_present_ = 0;   // pass 2: rows replayed / pushed, rows with a randomness row seen / pushed
+    std::vector<uint8_t> present_;
     uint64_t enc_pos_ = 0;                                // encoding-stream position (elements) of the next row's pad
     std::vector<uint8_t> kinds_, shape_kinds_, shape_widths_;
     hip_row_staging rows_, rands_;

@@ -35,7 +35,7 @@ EXPORTS = [
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
-    "lig_device_pci_bus_id", "lig_device_peer_access", "lig_host_alloc", "lig_host_free", "lig_rows_push_rands",
+    "lig_device_pci_bus_id", "lig_device_peer_access", "lig_host_alloc", "lig_host_free", "lig_rows_push_rands", "lig_rows_push_rands_sparse",
     "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
 ]
 
@@ -204,6 +204,7 @@ def load_library():
     L.lig_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.lig_host_free.argtypes = [vp, vp]
     L.lig_rows_push_rands.argtypes = [vp, u64, u64, vp]
+    L.lig_rows_push_rands_sparse.argtypes = [vp, u64, u64, vp, vp]
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     return L
@@ -653,6 +654,11 @@ class Context:
     def rows_push_rands(self, trace, first_row, n_rows, host_ptr):
         """lig_rows_push_rands: randomness rows [first_row, first_row + n_rows), host memory valid until rows_prove returns"""
         self.check(self.L.lig_rows_push_rands(trace, first_row, n_rows, C.c_void_p(host_ptr)))
+
+    def rows_push_rands_sparse(self, trace, first_row, present, host_ptr):
+        """lig_rows_push_rands_sparse: `present` (uint8 per row) says which of the rows have a randomness row at host_ptr (packed)"""
+        present = np.ascontiguousarray(present, dtype=np.uint8)
+        self.check(self.L.lig_rows_push_rands_sparse(trace, first_row, len(present), _hptr(present), C.c_void_p(host_ptr)))
 
     def rows_verify_begin(self, kinds, proof, public_args=None):
         """-> (vtrace or None, stage1_seed bytes, VerifyInfo): the verifier's first half for a rows job (kinds + public data)"""

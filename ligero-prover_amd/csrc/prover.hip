@@ -777,7 +777,13 @@ struct Uploader {
                 }
             }
             const bool skip = j.first.abort && j.first.abort->load(std::memory_order_acquire);
-            const hipError_t e = (j.first.bytes && !skip) ? hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st) : hipSuccess;
+            hipError_t e = hipSuccess;
+            if (!skip && j.first.segs) {
+                for (const UploadSeg& g : *j.first.segs) {
+                    if (!g.bytes || e != hipSuccess) continue;
+                    e = g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, st) : hipMemsetAsync(g.dst, 0, g.bytes, st);
+                }
+            } else if (!skip && j.first.bytes) e = hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st);
             const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
             // (a failed copy publishes too: no stream may hang on the flag; lig_rows_commit reports the error once stage 1 has drained)
             if (e2 != hipSuccess) { (void)hipGetLastError(); j.first.failed->store((int)e2, std::memory_order_release); }
@@ -1062,12 +1068,18 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
 }
 
 int lig_rows_push_rands(lig_trace* T, uint64_t first_row, uint64_t n_rows, const void* host_rows) {
+    return lig_rows_push_rands_sparse(T, first_row, n_rows, nullptr, host_rows);
+}
+int lig_rows_push_rands_sparse(lig_trace* T, uint64_t first_row, uint64_t n_rows, const uint8_t* present, const void* host_rows) {
     if (!T) return LIG_E_ARG;
     lig_ctx* c = T->c;
     CHECK_CTX(c);
     if (!T->from_rows || !T->committed) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: lig_rows_commit has not run on this trace");
-    if (first_row != T->rands_pushed || first_row + n_rows > T->R || (n_rows && !host_rows)) FAIL(c, LIG_E_ARG, "lig_rows_push_rands: rows must arrive in order, without gaps, inside the trace");
+    if (first_row != T->rands_pushed || first_row + n_rows > T->R) FAIL(c, LIG_E_ARG, "lig_rows_push_rands: rows must arrive in order, without gaps, inside the trace");
     if (!n_rows) return LIG_OK;
+    size_t n_present = n_rows;
+    if (present) { n_present = 0; for (uint64_t i = 0; i < n_rows; i++) n_present += present[i] != 0; }
+    if (n_present && !host_rows) FAIL(c, LIG_E_ARG, "lig_rows_push_rands: null rows");
     if (lig::knobs().upload_mode != 2 || !lig_internal_uploader_available(c)) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: no uploader thread on this device (stream memory operations unavailable)");
     const size_t row_bytes = (size_t)c->k * 32;
     if (!T->rands_full) HIP_TRY(c, hipMalloc((void**)&T->rands_full, T->R * row_bytes));
@@ -1076,6 +1088,18 @@ int lig_rows_push_rands(lig_trace* T, uint64_t first_row, uint64_t n_rows, const
     if (first_row == 0) { __atomic_store_n(arrived, 0u, __ATOMIC_RELEASE); T->up_abort.store(0, std::memory_order_release); }
     // one job per push: the uploader publishes the number of rows that have arrived (jobs of a trace are taken in order)
     UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->up_failed};
+    if (present && n_present != n_rows) {       // runs of present rows are copied from where they follow each other in host_rows, the others zero-filled on the device
+        j.segs = std::make_shared<std::vector<UploadSeg>>();
+        const uint8_t* src = (const uint8_t*)host_rows;
+        for (uint64_t i = 0; i < n_rows;) {
+            uint64_t e = i + 1;
+            const bool p = present[i] != 0;
+            while (e < n_rows && (present[e] != 0) == p) e++;
+            j.segs->push_back(UploadSeg{j.dst + i * row_bytes, p ? src : nullptr, (size_t)(e - i) * row_bytes});
+            if (p) src += (e - i) * row_bytes;
+            i = e;
+        }
+    }
     j.abort = &T->up_abort; j.prio = 1;
     lig_internal_uploader_submit(c->device, {j}, &T->up_pending);
     T->rands_pushed = first_row + n_rows;

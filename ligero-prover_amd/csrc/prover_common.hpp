@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -45,9 +46,13 @@ void launch_copy_from_host(hipStream_t s, uint8_t* dst_dev, const uint8_t* src_m
 // the copy ON THE HOST, then publishes `seq` in *flag (pinned host memory; streams wait for it with hipStreamWaitValue32).
 // `wait` (optional): the copy may only start once *wait >= wait_val -- a word in pinned host memory that a stream of the proof writes
 // (hipStreamWriteValue32) when it is done with the destination buffer (the double-buffered randomness rows of stage 2)
+// `segs` (optional, instead of dst / src / bytes): several pieces under one arrival word; a piece without a source is zero-filled on
+// the device (rows a sparse randomness matrix does not ship)
+struct UploadSeg { uint8_t* dst; const uint8_t* src; size_t bytes; };
 struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint32_t* flag; uint32_t seq; std::atomic<int>* failed;
                    const volatile uint32_t* wait = nullptr; uint32_t wait_val = 0; const std::atomic<int>* abort = nullptr;
-                   int prio = 0; };     // 1: a proof is waiting for it NOW (randomness rows) -- ahead of the prefetch of a next trace's witness rows
+                   int prio = 0;        // 1: a proof is waiting for it NOW (randomness rows) -- ahead of the prefetch of a next trace's witness rows
+                   std::shared_ptr<std::vector<UploadSeg>> segs; };
 extern "C" bool lig_internal_uploader_available(lig_ctx* c);          // false: no stream memory operations on this device (callers fall back to stream copies)
 extern "C" void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending);   // *pending += jobs, -1 per finished job
 

@@ -373,3 +373,40 @@ def test_rows_push_rands_in_pieces_equals_rows_prove_with_all_rows(amd):
         c.host_free(ptr)
     finally:
         c.close()
+
+
+def test_rows_push_rands_sparse_ships_only_rows_that_have_randomness(amd):
+    """lig_rows_push_rands_sparse: a trace that starts with the rows of a batch program (their randomness rows are zero: the vbn254fr
+    hooks carry none, nonbatch_context.hpp:782-850) -- only the rows that HAVE a randomness row are in the pinned staging, packed, the
+    library zero-fills the others on the device; the envelope is the oracle's"""
+    import test_batch_rows
+    l, k, n = 320, 512, 2048
+    job = ol.make_job(l, k, n, 192, 320 * 300 + 9, 330, generated_at=5, threads=8)
+    test_batch_rows.demo_program(with_bits=False).attach(job)
+    want = oracle_prove(job)
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job)
+    R = rows.shape[0]
+    c = amd.Context(l, k, n)
+    try:
+        tr, keep = c.rows_begin(kinds, rows, generated_at=5)
+        root, seed1 = c.rows_commit(tr)
+        assert root == want["root"]
+        rands, const_sum = ol.rand_rows(job, seed1)
+        rands = np.ascontiguousarray(rands, dtype=np.uint32).reshape(R, -1)
+        present = rands.any(axis=1).astype(np.uint8)
+        assert 0 < present.sum() < R and not present[kinds >= 4].any()           # the batch rows are the absent ones
+        packed = rands[present != 0]
+        pinned, ptr = c.host_alloc(packed.nbytes)
+        pinned[:] = packed.view(np.uint8).reshape(-1)
+        cut = 23                                                                  # first push ends inside the batch rows, the second holds the rest
+        off = int(present[:cut].sum()) * k * 32
+        c.rows_push_rands_sparse(tr, 0, present[:cut], ptr.value)
+        c.rows_push_rands_sparse(tr, cut, present[cut:], ptr.value + off)
+        proof, info = c.rows_prove(tr, None, const_sum)
+        assert (info.valid_code, info.valid_linear, info.valid_quad) == (1, 1, 1)
+        assert proof == want["proof"]
+        c.trace_destroy(tr)
+        c.host_free(ptr)
+    finally:
+        c.close()
