@@ -91,3 +91,27 @@ def test_shard_plan_block_cyclic_deal():
                     assert kinds[x] not in (2, 3, 7, 9, 10), "a chunk boundary inside a row group"
             per_rank = [sum(sizes[g] for g in range(r, len(sizes), W)) for r in range(W)]
             assert sum(per_rank) == R and max(per_rank) - min(per_rank) <= max(3 * rounds + (R % (W * rounds) != 0) * (-(-R // (W * rounds))), 3)
+
+
+def test_transport_names_and_default_ladders(monkeypatch):
+    """dist.Group's transports (the rungs of bench.py's ladder) and which ladder bench.py climbs where"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lig_dist", os.path.join(ROOT, "ligero-prover_amd", "dist.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    spec = importlib.util.spec_from_file_location("lig_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LIG_COMM"):
+        monkeypatch.delenv(k, raising=False)
+    g = m.Group("nccl")                                   # world 1: no process group is made
+    assert g.default_transport() == "rccl-stream" and m.Group("gloo").default_transport() == "host"
+    monkeypatch.setenv("LIG_COMM", "ipc")
+    assert g.default_transport() == "ipc-stream" and b.ladder_transports(2) == ["ipc-stream", "ipc-sync", "host"]
+    monkeypatch.delenv("LIG_COMM")
+    assert b.ladder_transports(8) == ["rccl-stream", "rccl-sync", "torch", "ipc-stream"]        # product path first
+    assert b.ladder_transports(1) == ["rccl-stream", "rccl-sync", "host"]
+    assert set(b.ladder_transports(8)) | set(b.ladder_transports(1)) <= set(m.Group.TRANSPORTS) and set(b.TRANSPORT_NOTES) == set(m.Group.TRANSPORTS)
+    import pytest
+    with pytest.raises(ValueError):
+        g.make_comm(None, None, "carrier-pigeon")
