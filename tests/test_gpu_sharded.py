@@ -259,7 +259,7 @@ def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_pat
 def test_bench_ladder_falls_through_an_injected_transport_failure_with_two_real_ranks(tmp_path, fault, delivered_by, failed):
     """a failure of the first rung (LIG_FAULT_COMM: injected in the library's communicators) must not cost the
     measurement -- the ladder falls through to the next rung, which still produces the oracle pin's envelope on both ranks"""
-    out = _bench(TWO_ON_ONE + ["--sharded-log2", "24", "--sharded-timeout", "60" if fault == "3" else "180"],
+    out = _bench(TWO_ON_ONE + ["--sharded-log2", "24", "--sharded-timeout", "30" if fault == "3" else "180"],
                  LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()), LIG_FAULT_COMM=fault)
     sh = out["sharded"]
     assert out["value"] > 0 and sh["transport"] == delivered_by
