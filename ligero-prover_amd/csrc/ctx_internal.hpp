@@ -17,6 +17,7 @@ struct lig_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: column hash and samplers, overlapped with the encodes on `stream`
     hipStream_t stream3 = nullptr;            // copy stream: host rows of lig_rows_begin arrive here under the encodes
+    hipStream_t stream_sha = nullptr;         // experiment (LIG_SHA_CUMASK): a CU-masked stream for the stage-1 column hash; null: stream2
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2
     std::string err;

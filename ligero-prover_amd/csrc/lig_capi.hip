@@ -3,6 +3,7 @@
 // (src/webgpu/device_context.cpp): one HIP stream instead of a WebGPU queue, plain device pointers instead of
 // WGPUBuffer/bind groups, twiddle tables generated with host_field.hpp instead of GMP.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -309,6 +310,7 @@ const lig::Knobs& lig::knobs() {
         t.sha_gate = (int)num("LIG_SHA_GATE", 1);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
         t.sha_prio = (int)num("LIG_SHA_PRIO", 0);
+        t.sha_cumask = (int)num("LIG_SHA_CUMASK", 0);
         t.s1_head = (size_t)num("LIG_S1_HEAD", 128); t.s1_tail = (size_t)num("LIG_S1_TAIL", 96); t.s2_head = (size_t)num("LIG_S2_HEAD", 192);
         t.fused_rlc = std::getenv("LIG_NO_FUSED_RLC") == nullptr;
         t.early_code = num("LIG_EARLY_CODE", 1) != 0;
@@ -362,6 +364,22 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     } else
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));      // side stream: column hash, samplers
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));      // copy stream
+    if (lig::knobs().sha_cumask) {
+        // experiment (profiles/r04_sha_cumask_ab.md): with two proofs in flight the hash kernels of both may be placed on the same
+        // CUs (two hash waves per SIMD: both chains at half speed); even / odd contexts hash on disjoint halves of the chip
+        static std::atomic<uint32_t> n_ctx{0};
+        const uint32_t parity = n_ctx.fetch_add(1) & 1u;
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, device));
+        const uint32_t cus = (uint32_t)prop.multiProcessorCount, words = (cus + 31) / 32;
+        std::vector<uint32_t> mask(words, 0);
+        const int mode = lig::knobs().sha_cumask;         // 1: lower / upper half of the CU numbers, 2: even / odd CU numbers
+        for (uint32_t i = 0; i < cus; i++) {
+            const bool mine = mode == 2 ? (i & 1u) == parity : (i < cus / 2) == (parity == 0);
+            if (mine) mask[i / 32] |= 1u << (i % 32);
+        }
+        HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->stream_sha, words, mask.data()));
+    }
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     // LIG_ENCODE_GENERIC=1 (tests): take the generic radix-2 row path even where the tiled encoder exists
@@ -404,6 +422,7 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream_sha) { (void)hipStreamSynchronize(c->stream_sha); (void)hipStreamDestroy(c->stream_sha); }
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);

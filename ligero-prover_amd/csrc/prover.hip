@@ -315,7 +315,9 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     // b+1 is being encoded (the hash has only n = 32768 lanes of parallelism -- 512 waves -- and would otherwise
     // leave most of the chip idle for its whole duration).  Row order = hash order is preserved by stream order.
     hipStream_t s2 = c->stream2;
-    hipStream_t s_sha = s2, s_enc = s;      // (dedicated CUs for the hash via CU-masked streams were measured: no gain, profiles/r01_overlap_experiments.md)
+    // (dedicated CUs for the hash via CU-masked streams were measured with one proof: no gain, profiles/r01_overlap_experiments.md;
+    // LIG_SHA_CUMASK: disjoint halves for the hashes of two proofs in flight, profiles/r04_sha_cumask_ab.md)
+    hipStream_t s_sha = c->stream_sha ? c->stream_sha : s2, s_enc = s;
     TRY(lig_sha_init(c, T->sha_state, n));
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
