@@ -3,7 +3,7 @@
 #   tools/ab_env.sh OUT.txt ROUNDS "NAME1:ENV=.. ENV=.." "NAME2:..." ...
 # every round runs every variant once, in order; one line per run: variant, constraints/s, ms per step, one-proof wall, stage ms
 out=$1; rounds=$2; shift 2
-: > "$out"
+mkdir -p "$(dirname "$out")"; : > "$out"
 for r in $(seq 1 "$rounds"); do
   for v in "$@"; do
     name=${v%%:*}; envs=${v#*:}
