@@ -75,6 +75,9 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
                                                                    const f29wt tw_inv, const f29wt tw_fwd, const f29wt twist, const f29wt seam_fwd) {
     constexpr uint32_t B = 1u << LOG2B, T = B / 4, NC = FULL ? 3 : 1;
     __shared__ TileLds<LOG2B> L;
+#ifdef LIG_K2_SETPRIO            // A/B (profiles/r04_tile_setprio_ab.md): tile waves ahead of the other streams' waves in the SIMD's arbiter
+    __builtin_amdgcn_s_setprio(LIG_K2_SETPRIO);
+#endif
     const uint32_t t = threadIdx.x;
     const uint32_t j1 = blockIdx.x & 7u;
     const size_t row = blockIdx.x >> 3;
