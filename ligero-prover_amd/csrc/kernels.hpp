@@ -21,6 +21,7 @@ struct Knobs {
     int      sha_gate = 1;             // LIG_SHA_GATE       place every chunk's hash before the encode stream goes on
     size_t   sha_gate_rows = 2;        // LIG_SHA_GATE_ROWS  rows hashed before the encode stream is released
     int      sha_prio = 0;             // LIG_SHA_PRIO       1: the side stream (column hash, samplers) is a high-priority stream
+    int      ctx_low_prio_every = 0;   // LIG_CTX_LOW_PRIO_EVERY  n > 0: every n-th context of the process gets lowest-priority streams (a "filler" proof)
     int      sha_cumask = 0;           // LIG_SHA_CUMASK     1: the stage-1 hash of even / odd contexts runs on disjoint halves of the CUs (CU-masked stream)
     size_t   s1_head = 128, s1_tail = 96, s2_head = 192;   // LIG_S1_HEAD / LIG_S1_TAIL / LIG_S2_HEAD  chunk schedule
     bool     fused_rlc = true;         // LIG_NO_FUSED_RLC   (set: the two-kernel sampler / accumulate path of round 2)

@@ -311,6 +311,7 @@ const lig::Knobs& lig::knobs() {
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
         t.sha_prio = (int)num("LIG_SHA_PRIO", 0);
         t.sha_cumask = (int)num("LIG_SHA_CUMASK", 0);
+        t.ctx_low_prio_every = (int)num("LIG_CTX_LOW_PRIO_EVERY", 0);
         t.s1_head = (size_t)num("LIG_S1_HEAD", 128); t.s1_tail = (size_t)num("LIG_S1_TAIL", 96); t.s2_head = (size_t)num("LIG_S2_HEAD", 192);
         t.fused_rlc = std::getenv("LIG_NO_FUSED_RLC") == nullptr;
         t.early_code = num("LIG_EARLY_CODE", 1) != 0;
@@ -349,7 +350,15 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     c->device = device; c->l = l; c->k = k; c->n = n;
     *out = c;    // returned even on failure so that lig_last_error works; caller destroys
     HIP_TRY(c, hipSetDevice(device));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // experiment (profiles/r04_filler_proof_ab.md): every n-th context as a low-priority "filler" whose kernels only take what the others leave
+    static std::atomic<uint32_t> n_created{0};
+    const uint32_t ctx_index = n_created.fetch_add(1);
+    const int every = lig::knobs().ctx_low_prio_every;
+    const bool low = every > 0 && (ctx_index % (uint32_t)every) == (uint32_t)every - 1;
+    int prio_lo = 0, prio_hi = 0;
+    if (low) HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    auto make_stream = [&](hipStream_t* st) { return low ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    HIP_TRY(c, make_stream(&c->stream));
     H::Fr wk, w2k, w4k;
     H::omegas(k, wk, w2k, w4k);
     int rc;
@@ -362,8 +371,8 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
         HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
     } else
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));      // side stream: column hash, samplers
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));      // copy stream
+    HIP_TRY(c, make_stream(&c->stream2));      // side stream: column hash, samplers
+    HIP_TRY(c, make_stream(&c->stream3));      // copy stream
     if (lig::knobs().sha_cumask) {
         // experiment (profiles/r04_sha_cumask_ab.md): with two proofs in flight the hash kernels of both may be placed on the same
         // CUs (two hash waves per SIMD: both chains at half speed); even / odd contexts hash on disjoint halves of the chip
