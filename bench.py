@@ -15,9 +15,13 @@ N > 1: one process per GPU over RCCL.  Under torch.distributed.run the ranks exi
 a plain `python bench.py --gpus N` spawns the N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each).
 `value`: traces are independent objects, so every rank proves its own traces (weak scaling, no data-path collective); the
 timed region is bracketed by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.  For N > 1 the line also
-carries `sharded`: configs[3] -- ONE 2^26-constraint trace row-sharded over the N ranks (column-partitioned hash after a
-per-round all-to-all of codeword column slices, all-gathered leaves / partial sums / opened columns, all on RCCL), with
-its own barrier-bracketed timing, the number of ranks RCCL reports and the comparison with the oracle's pin.
+carries `sharded` (+ `sharded_2p24`, `preflight`): configs[3] -- ONE 2^26-constraint trace row-sharded over the N ranks
+(column-partitioned hash after a per-round all-to-all of codeword column slices, all-gathered leaves / partial sums / opened
+columns), with its own barrier-bracketed timing, the number of ranks RCCL reports and the comparison with the oracle's pin.  That
+leg runs rung by rung in FRESH child processes (sharded_ladder: stream-ordered RCCL -> host-synchronous RCCL -> torch's own
+communicator -> process-to-process over mapped memory), so a failing or hanging collective cannot cost the weak figure.
+N = 1 also reports, beside `value`: proof_wall_ms, quad_mix (half of the constraints quadratic), value_incl_h2d / incl_h2d
+(witness from pinned host memory; .caller_rands: the randomness rows too; .narrow_format), the verifier, cpu_baseline.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
