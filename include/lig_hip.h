@@ -361,6 +361,16 @@ typedef struct {
      * communicator that exports them to its peers (lig_ipc_comm_create) must not keep handles / mappings of a recycled
      * address.  Contract: call it before freeing any buffer that has been a `send_dev` (lig_shard_destroy does). */
     void (*forget)(void *user);
+    /* optional (NULL: the communicator cannot tell): non-zero once the communicator has FAILED -- a peer died, left, or stopped
+     * responding -- and the reason is in lig_last_error of its context.  A stream-ordered collective cannot return an error from
+     * inside a queue: lig_shard_* asks this after it has drained its streams and returns LIG_E_STATE instead of an envelope made
+     * of garbage.  lig_ipc_comm_create: watchdog thread (peer pids, an abort word, a stall timer; waits already queued are
+     * released); lig_rccl_comm_create: ncclCommGetAsyncError. */
+    int (*failed)(void *user);
+    /* optional: make every collective already queued on this rank's streams give up NOW (ncclCommAbort; comm_ipc: poison).  lig_shard_*
+     * calls it when queued work containing collectives has not completed LIG_COMM_TIMEOUT_S seconds (default 300) after the host
+     * started to wait for it; the communicator is unusable afterwards (failed() != 0). */
+    void (*abort)(void *user);
 } lig_comm;
 /* RCCL communicator: rank 0 calls lig_rccl_unique_id and hands the 128 bytes to every rank through the launcher's
  * rendezvous (torch.distributed / MPI / a file); every rank then calls lig_rccl_comm_create with its context. */
@@ -395,13 +405,24 @@ void lig_shard_destroy(lig_shard *shard);
  * public linear constant (NULL: minus the sum of all inner products, as lig_rows_prove).  Every rank obtains the envelope of
  * lig_rows_prove on the whole trace.  Replaces the per-row callbacks of include/zkp/nonbatch_context.hpp:445-471, :654-780,
  * :924-970 when the rows of one trace live on several GPUs.
- * The sharded entry takes full-width rows only: job->elem_bytes must be NULL (LIG_E_ARG otherwise). ==== */
+ * The sharded entry takes full-width rows only: job->elem_bytes must be NULL (LIG_E_ARG otherwise).
+ * LIFETIME: local rows in HOST memory (msgs_on_device == 0) are uploaded asynchronously by the library's uploader thread, chunk by
+ * chunk under the encodes: the memory passed to lig_shard_rows_begin / lig_shard_rows_restart must stay valid and unchanged until
+ * lig_shard_rows_commit (or lig_shard_destroy) has returned.  Device rows are copied before the call returns.  Randomness rows
+ * passed to lig_shard_rows_prove are consumed before it returns.
+ * FAILURE: a peer that dies, leaves or stops responding makes these calls return LIG_E_STATE (lig_comm.failed / .abort), they do not hang. ==== */
 int lig_shard_rows_plan(const uint8_t *kinds, size_t n_rows, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
 int lig_shard_rows_begin(lig_ctx *ctx, const lig_rows_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
 int lig_shard_rows_restart(lig_shard *shard, const void *local_msgs, int msgs_on_device);   /* next trace, same shape; after lig_shard_rows_prove of the previous one (LIG_E_STATE otherwise) */
 int lig_shard_rows_commit(lig_shard *shard, uint8_t root[32], uint8_t stage1_seed[32]);
 int lig_shard_rows_prove(lig_shard *shard, const void *local_rands, int rands_on_device, const uint8_t *const_sum,
                          const uint8_t **proof, size_t *proof_len, lig_proof_info *info);
+
+/* sizeof of the public structs as this build of the library sees them, in the order {lig_batch_op, lig_synth_job, lig_proof_info,
+ * lig_verify_info, lig_rows_job, lig_comm}: a binding in another language (ctypes, cgo, JNI) checks its own layouts against these at
+ * load time -- members are appended to these structs over time and a short struct on the caller's side is read past its end. */
+enum { LIG_ABI_STRUCTS = 6 };
+void lig_abi_sizes(uint32_t out[LIG_ABI_STRUCTS]);
 
 /* Measurement hook (no reference counterpart): while enabled, every lig_encode_rows launch group records HIP
  * events on the context stream immediately around the dominant kernel (k_encode_tiles).  lig_profile_read syncs

@@ -36,7 +36,7 @@ EXPORTS = [
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
     "lig_device_pci_bus_id", "lig_device_peer_access", "lig_host_alloc", "lig_host_free", "lig_rows_push_rands", "lig_rows_push_rands_sparse",
-    "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
+    "lig_abi_sizes", "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
 ]
 
 ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
@@ -57,7 +57,8 @@ A2A_ON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
 class Comm(C.Structure):
     """lig_comm: host-synchronous callbacks (tests over gloo) and, when made by lig_rccl_comm_create, the stream-ordered RCCL forms"""
     _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN),
-                ("all_to_all_on", A2A_ON_FN), ("all_gather_on", A2A_ON_FN), ("forget", C.CFUNCTYPE(None, C.c_void_p))]
+                ("all_to_all_on", A2A_ON_FN), ("all_gather_on", A2A_ON_FN), ("forget", C.CFUNCTYPE(None, C.c_void_p)),
+                ("failed", C.CFUNCTYPE(C.c_int, C.c_void_p)), ("abort", C.CFUNCTYPE(None, C.c_void_p))]
 
 
 class SynthJob(C.Structure):
@@ -116,6 +117,16 @@ def load_library():
                            "-- there is no CPU fallback for the HIP path" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     vp, sz, u32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64
+    # struct layouts of this binding against the library's own sizeof (include/lig_hip.h: lig_abi_sizes): a stale binding would hand the
+    # library structs it reads past the end of
+    sizes = (u32 * 6)()
+    L.lig_abi_sizes.argtypes = [C.POINTER(u32)]
+    L.lig_abi_sizes.restype = None
+    L.lig_abi_sizes(sizes)
+    for idx, (name, cls) in {1: ("lig_synth_job", SynthJob), 2: ("lig_proof_info", ProofInfo), 3: ("lig_verify_info", VerifyInfo),
+                             4: ("lig_rows_job", RowsJob), 5: ("lig_comm", Comm)}.items():
+        if C.sizeof(cls) != sizes[idx]:
+            raise RuntimeError("binding out of date: sizeof(%s) is %d in %s, %d in this module" % (name, sizes[idx], LIB_PATH, C.sizeof(cls)))
     L.lig_ctx_create.argtypes = [C.POINTER(vp), C.c_int, u32, u32, u32]
     L.lig_ctx_destroy.argtypes = [vp]
     L.lig_ctx_destroy.restype = None
@@ -488,6 +499,7 @@ class Context:
 
     def shard_destroy(self, shard):
         self.L.lig_shard_destroy(shard)
+        getattr(self, "_shard_keep", {}).pop(shard.value, None)
 
     # ---- one trace sharded over ranks, rows supplied by the caller (lig_shard_rows_*)
     def shard_rows_begin(self, kinds_all, local_msgs, rank, world, comm, on_device=False, encoding_seed=None, generated_at=0,
@@ -518,7 +530,22 @@ class Context:
             keep += (dr,)
         t = C.c_void_p()
         self.check(self.L.lig_shard_rows_begin(self.h, C.byref(job), rank, world, C.byref(comm), C.byref(t)))
+        # host rows are read asynchronously (uploader thread) until lig_shard_rows_commit returns: the arrays live as long as the shard
+        if not hasattr(self, "_shard_keep"):
+            self._shard_keep = {}
+        self._shard_keep[t.value] = keep
         return t
+
+    def shard_rows_restart(self, shard, local_msgs, on_device=False):
+        """the next trace of the same shape (after shard_rows_prove of the previous one)"""
+        if on_device:
+            ptr, keep = (local_msgs if hasattr(local_msgs, "value") else C.c_void_p(int(local_msgs))), ()
+        else:
+            local_msgs = np.ascontiguousarray(local_msgs, dtype=np.uint32)
+            ptr, keep = C.c_void_p(local_msgs.ctypes.data if local_msgs.size else None), (local_msgs,)
+        if hasattr(self, "_shard_keep"):
+            self._shard_keep[shard.value] = keep
+        self.check(self.L.lig_shard_rows_restart(shard, ptr, int(bool(on_device))))
 
     def shard_rows_commit(self, shard):
         root, seed = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)

@@ -25,8 +25,13 @@
 //     of shared blocks and the importer is handed the block's base.
 // Build: compiled in with -DLIG_WITH_IPC_COMM (the Makefile's default: the GPU test-suite needs it); `make RELEASE=1` leaves it
 // out -- lig_ipc_comm_create then returns LIG_E_STATE and the library carries no shared-memory / IPC-handle code at all.
-// Failure model: this is a test communicator.  A rank that fails in the middle of a collective leaves its peers' streams
-// waiting on flags that never come (their hosts give up after 120 s in the next collective; a stream wait has no timeout).
+// Failure model (round 5): a stream wait has no timeout, so every communicator runs a host WATCHDOG thread.  It declares the
+// communicator dead when (a) a peer has declared it dead (abort word in the segment: any rank whose collective fails on the
+// host writes it), (b) a peer's process is gone (pids are in the segment; /proc/<pid>/stat: missing or a zombie), or (c) a
+// collective has been outstanding without any flag of any rank changing for LIG_IPC_STALL_S seconds (default 60).  A dead
+// communicator is POISONED: the watchdog keeps writing 0x7fffffff into every ready / pulled word, so every wait already in a
+// queue of this rank is released and the streams drain; lig_comm.failed() then reports it (the data of collectives since is
+// garbage) and lig_shard_* returns LIG_E_STATE with the reason instead of hanging.  Every later collective fails on entry.
 #include <cstring>
 
 #include "ctx_internal.hpp"
@@ -46,10 +51,15 @@ void lig_ipc_comm_destroy(lig_comm*) {}
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <signal.h>
+
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ctx_internal.hpp"
@@ -72,6 +82,8 @@ struct Pub {
 struct Shm {
     std::atomic<uint32_t> magic, arrived, departed;
     uint32_t world;
+    std::atomic<uint32_t> abort_by;       // rank + 1 of the first rank that declared the communicator dead (0: alive)
+    std::atomic<int32_t> pid[MAXW];       // process of every rank (0: not arrived yet / left in good order)
     std::atomic<uint64_t> forgot[MAXW];   // epoch up to which rank h has closed every mapping of its peers' buffers
     hipIpcMemHandle_t window[MAXW];       // every rank's staging window (exported once, at creation)
     Pub pub[MAXW][RING];
@@ -105,22 +117,110 @@ struct IpcComm {
     uint8_t* window = nullptr;
     const uint8_t* peer_window[MAXW] = {nullptr};
     bool registered = false;
+    // watchdog (see the failure model in the header of this file)
+    std::thread wd;
+    std::atomic<int> wd_stop{0}, dead{0};
+    std::atomic<uint64_t> calls_pub{0};   // = calls, for the watchdog
+    std::mutex why_mu;
+    std::string why;                      // first reason the communicator was declared dead
+    int stall_s = 60;
 };
 
 using clk = std::chrono::steady_clock;
 constexpr int HOST_TIMEOUT_S = 120;
 
+constexpr uint32_t POISON = 0x7fffffffu;      // >= every call number, whichever signedness the comparison uses
+
+// declare the communicator dead (idempotent): the watchdog of every rank sees the abort word and poisons its own view
+void declare_dead(IpcComm* r, const std::string& msg) {
+    {
+        std::lock_guard<std::mutex> lk(r->why_mu);
+        if (r->why.empty()) r->why = msg;
+    }
+    r->dead.store(1, std::memory_order_release);
+    if (r->shm) {
+        uint32_t none = 0;
+        (void)r->shm->abort_by.compare_exchange_strong(none, r->rank + 1);
+    }
+}
+std::string dead_reason(IpcComm* r) {
+    std::lock_guard<std::mutex> lk(r->why_mu);
+    return r->why;
+}
+// a host-side failure inside a collective: the peers must not wait for this rank
 int fail(IpcComm* r, const std::string& msg) {
     if (r && r->ctx) r->ctx->err = "ipc comm: " + msg;
+    if (r && r->shm) declare_dead(r, msg);
     return 1;
 }
+void poison(Shm* sh) {
+    for (uint32_t i = 0; i < FLAGS_PER_KIND; i += FLAG_STRIDE) {
+        __atomic_store_n(&sh->ready[i], POISON, __ATOMIC_RELEASE);
+        __atomic_store_n(&sh->pulled[i], POISON, __ATOMIC_RELEASE);
+    }
+}
+// is the process of a peer still running?  (kill(pid, 0) also succeeds for a zombie nobody has reaped yet: ask /proc for the state)
+bool process_alive(int32_t pid) {
+    if (pid <= 0) return true;                   // not arrived yet, or left in good order
+    char path[64], buf[256];
+    std::snprintf(path, sizeof path, "/proc/%d/stat", (int)pid);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return kill(pid, 0) == 0 || errno == EPERM;      // no /proc: fall back on the signal probe
+    const size_t got = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[got] = 0;
+    const char* p = std::strrchr(buf, ')');      // "pid (comm) S ..."
+    return !(p && p[1] == ' ' && (p[2] == 'Z' || p[2] == 'X' || p[2] == 'x'));
+}
 
+void watchdog(IpcComm* r) {
+    Shm* sh = r->shm;
+    const uint32_t W = r->world;
+    uint64_t last_sum = 0;
+    auto last_change = clk::now();
+    constexpr uint32_t RS = SLOTS * FLAG_STRIDE;
+    while (!r->wd_stop.load(std::memory_order_acquire)) {
+        if (r->dead.load(std::memory_order_acquire)) { poison(sh); usleep(2000); continue; }     // late "ready <- c" writes of queued work must not re-arm a wait
+        std::string why;
+        if (const uint32_t by = sh->abort_by.load(std::memory_order_acquire)) why = "rank " + std::to_string(by - 1) + " declared the communicator dead";
+        for (uint32_t h = 0; h < W && why.empty(); h++)
+            if (h != r->rank && !process_alive(sh->pid[h].load(std::memory_order_acquire)))
+                why = "the process of rank " + std::to_string(h) + " (pid " + std::to_string(sh->pid[h].load()) + ") is gone";
+        if (why.empty()) {
+            const uint64_t c = r->calls_pub.load(std::memory_order_acquire);
+            bool complete = true;
+            uint64_t sum = c;
+            for (uint32_t h = 0; h < W; h++) {
+                for (uint32_t sl = 0; sl < SLOTS; sl++)
+                    sum = sum * 1315423911u + __atomic_load_n(&sh->ready[h * RS + sl * FLAG_STRIDE], __ATOMIC_ACQUIRE) + ((uint64_t)__atomic_load_n(&sh->pulled[h * RS + sl * FLAG_STRIDE], __ATOMIC_ACQUIRE) << 32);
+                if (c && __atomic_load_n(&sh->pulled[h * RS + (c % SLOTS) * FLAG_STRIDE], __ATOMIC_ACQUIRE) < (uint32_t)c) complete = false;
+            }
+            const auto now = clk::now();
+            // a rank that has LEFT (its streams were drained first) will never write the flags an incomplete collective still waits for
+            if (c && !complete && sh->departed.load(std::memory_order_acquire)) why = "a rank left the communicator while collective " + std::to_string(c) + " was outstanding";
+            else if (!c || complete || sum != last_sum) { last_sum = sum; last_change = now; }
+            else if (now - last_change > std::chrono::seconds(r->stall_s)) {
+                why = "collective " + std::to_string(c) + " outstanding and no flag of any rank changed for " + std::to_string(r->stall_s) + " s; flags [ready/pulled per rank, slot " + std::to_string(c % SLOTS) + "]:";
+                for (uint32_t h = 0; h < W; h++)
+                    why += " " + std::to_string(__atomic_load_n(&sh->ready[h * RS + (c % SLOTS) * FLAG_STRIDE], __ATOMIC_ACQUIRE)) + "/" +
+                           std::to_string(__atomic_load_n(&sh->pulled[h * RS + (c % SLOTS) * FLAG_STRIDE], __ATOMIC_ACQUIRE));
+            }
+        }
+        if (!why.empty()) { declare_dead(r, why); continue; }
+        usleep(10000);
+    }
+}
+
+// host-side wait for the peers' HOSTS; gives up at once when the communicator is dead
 template <class Pred>
-bool host_wait(Pred done, int timeout_s = HOST_TIMEOUT_S) {
+bool host_wait(IpcComm* r, Pred done, int timeout_s = HOST_TIMEOUT_S) {
     const auto t0 = clk::now();
     for (unsigned spins = 0; !done(); spins++) {
         if (spins > 2000) usleep(50);
-        if ((spins & 255) == 255 && clk::now() - t0 > std::chrono::seconds(timeout_s)) return false;
+        if ((spins & 63) == 63) {
+            if (r && r->dead.load(std::memory_order_acquire)) return false;
+            if (clk::now() - t0 > std::chrono::seconds(timeout_s)) return false;
+        }
     }
     return true;
 }
@@ -128,7 +228,8 @@ bool host_wait(Pred done, int timeout_s = HOST_TIMEOUT_S) {
 // peer h's pointer for publication `c` (mapped on first sight of the handle)
 int peer_pointer(IpcComm* r, uint32_t h, uint64_t c, const uint8_t** out) {
     Pub& p = r->shm->pub[h][c % RING];
-    if (!host_wait([&] { return p.seq.load(std::memory_order_acquire) == c; })) return fail(r, "peer " + std::to_string(h) + " never reached collective " + std::to_string(c));
+    if (!host_wait(r, [&] { return p.seq.load(std::memory_order_acquire) == c; }))
+        return fail(r, r->dead.load() ? dead_reason(r) : "peer " + std::to_string(h) + " never reached collective " + std::to_string(c));
     if (p.via_window) { *out = r->peer_window[h] + p.offset; return 0; }
     const hipIpcMemHandle_t hd = p.handle;
     const uint64_t off = p.offset, ep = p.epoch;
@@ -151,6 +252,7 @@ int peer_pointer(IpcComm* r, uint32_t h, uint64_t c, const uint8_t** out) {
 // common part: publish my send buffer (or that it goes through the window), return the call number
 int publish(IpcComm* r, const void* send, size_t total_bytes, uint64_t* call, bool* via_window) {
     const uint64_t c = ++r->calls;
+    r->calls_pub.store(c, std::memory_order_release);
     Pub& p = r->shm->pub[r->rank][c % RING];
     void* base = nullptr;
     size_t size = 0;
@@ -186,6 +288,7 @@ int publish(IpcComm* r, const void* send, size_t total_bytes, uint64_t* call, bo
 // what = 0: all-to-all (recv block h <- peer h's send block `me`), 1: all-gather (recv block h <- peer h's send)
 int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t bytes, hipStream_t st) {
     if (!r->shm || !r->ctx) return 1;
+    if (r->dead.load(std::memory_order_acquire)) { r->ctx->err = "ipc comm: " + dead_reason(r); return 1; }
     if (hipSetDevice(r->ctx->device) != hipSuccess) return fail(r, "hipSetDevice");
     const uint32_t W = r->world, me = r->rank;
     uint64_t c = 0;
@@ -233,6 +336,14 @@ int a2a_on(void* user, const void* send, void* recv, size_t block, void* stream)
     return collective_on(r, 0, send, recv, block, static_cast<hipStream_t>(stream));
 }
 int ag_on(void* user, const void* send, void* recv, size_t bytes, void* stream) { return collective_on(static_cast<IpcComm*>(user), 1, send, recv, bytes, static_cast<hipStream_t>(stream)); }
+// lig_comm.failed: non-zero once the communicator is dead -- the caller has drained its streams and asks whether what the
+// collectives delivered is data or the leftovers of a poisoned wait
+int comm_failed(void* user) {
+    IpcComm* r = static_cast<IpcComm*>(user);
+    if (!r->dead.load(std::memory_order_acquire)) return 0;
+    if (r->ctx) r->ctx->err = "ipc comm: " + dead_reason(r);
+    return 1;
+}
 // the caller is about to free device buffers it has used as send buffers
 // Collective on the host (every rank calls it at the same point of the program, lig_shard_destroy): the caller's streams are
 // drained, so its own pulls are finished and -- a collective only completes once every rank has pulled -- so are the peers'
@@ -250,8 +361,9 @@ void forget(void* user) {
     const uint64_t ep = ++r->epoch;
     r->shm->forgot[r->rank].store(ep, std::memory_order_release);
     for (uint32_t h = 0; h < r->world; h++)
-        (void)host_wait([&] { return r->shm->forgot[h].load(std::memory_order_acquire) >= ep; }, 60);
+        (void)host_wait(r, [&] { return r->shm->forgot[h].load(std::memory_order_acquire) >= ep; }, 60);
 }
+void comm_abort(void* user) { declare_dead(static_cast<IpcComm*>(user), "aborted by the caller (its wait for queued collectives timed out)"); }
 int a2a_sync(void* user, const void* send, void* recv, size_t block) {
     IpcComm* r = static_cast<IpcComm*>(user);
     if (!r->ctx || lig_internal_comm_fault(r->ctx, false) || collective_on(r, 0, send, recv, block, r->ctx->stream)) return 1;
@@ -264,6 +376,7 @@ int ag_sync(void* user, const void* send, void* recv, size_t bytes) {
 }
 
 void finalize(IpcComm* r) {
+    // a dead communicator: the watchdog keeps the flags poisoned while this rank's streams drain (below), and is stopped after
     if (r->ctx) {
         (void)hipSetDevice(r->ctx->device);
         (void)hipStreamSynchronize(r->ctx->stream); (void)hipStreamSynchronize(r->ctx->stream2); (void)hipStreamSynchronize(r->ctx->stream3);
@@ -274,10 +387,13 @@ void finalize(IpcComm* r) {
         if (r->peer_window[h] && h != r->rank) (void)hipIpcCloseMemHandle(const_cast<uint8_t*>(r->peer_window[h]));
         r->peer_window[h] = nullptr;
     }
+    r->wd_stop.store(1, std::memory_order_release);
+    if (r->wd.joinable()) r->wd.join();
     if (r->shm) {
-        // nobody may unmap / unlink while a peer's stream still polls the flags: leave together
+        // nobody may unmap / unlink while a peer's stream still polls the flags: leave together (a dead communicator: nobody waits)
+        r->shm->pid[r->rank].store(0, std::memory_order_release);       // left in good order: not a crash
         r->shm->departed.fetch_add(1);
-        (void)host_wait([&] { return r->shm->departed.load() >= r->world; }, 15);
+        if (!r->dead.load()) (void)host_wait(r, [&] { return r->shm->departed.load() >= r->world; }, 15);
         if (r->registered) (void)hipHostUnregister(r->shm->ready);
         (void)munmap(r->shm, sizeof(Shm));
         if (r->rank == 0) (void)shm_unlink(r->name.c_str());
@@ -352,8 +468,9 @@ int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_
         (void)hipHostUnregister(r->shm->ready); if (r->window) (void)hipFree(r->window);
         return bail("window allocation / export failed", LIG_E_HIP);
     }
+    r->shm->pid[rank].store((int32_t)getpid(), std::memory_order_release);
     r->shm->arrived.fetch_add(1);
-    if (!host_wait([&] { return r->shm->arrived.load() >= world; })) { (void)hipHostUnregister(r->shm->ready); (void)hipFree(r->window); return bail("not all ranks arrived", LIG_E_STATE); }
+    if (!host_wait(nullptr, [&] { return r->shm->arrived.load() >= world; })) { (void)hipHostUnregister(r->shm->ready); (void)hipFree(r->window); return bail("not all ranks arrived", LIG_E_STATE); }
     for (uint32_t h = 0; h < world; h++) {
         if (h == rank) { r->peer_window[h] = r->window; continue; }
         void* pw = nullptr;
@@ -363,6 +480,8 @@ int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_
         }
         r->peer_window[h] = static_cast<const uint8_t*>(pw);
     }
+    r->stall_s = lig::knobs().ipc_stall_s;
+    r->wd = std::thread([r] { watchdog(r); });
     c->comms.push_back({r, finalize_erased});
     out->user = r;
     out->all_to_all = a2a_sync;
@@ -370,6 +489,8 @@ int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_
     out->all_to_all_on = a2a_on;
     out->all_gather_on = ag_on;
     out->forget = forget;
+    out->failed = comm_failed;
+    out->abort = comm_abort;
     return LIG_OK;
 }
 

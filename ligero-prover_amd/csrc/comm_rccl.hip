@@ -38,6 +38,8 @@ struct RcclApi {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;     // optional (failure reporting)
+    decltype(&ncclCommAbort) CommAbort = nullptr;                     // optional
     bool ok = false;
 };
 
@@ -60,6 +62,8 @@ RcclApi& api() {
         sym(a.CommCount, "ncclCommCount"); sym(a.GetErrorString, "ncclGetErrorString"); sym(a.GetVersion, "ncclGetVersion");
         sym(a.GroupStart, "ncclGroupStart"); sym(a.GroupEnd, "ncclGroupEnd"); sym(a.Send, "ncclSend"); sym(a.Recv, "ncclRecv");
         sym(a.AllGather, "ncclAllGather");
+        a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(dlsym(a.handle, "ncclCommGetAsyncError"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.handle, "ncclCommAbort"));
         a.ok = all;
         Dl_info info;
         if (all && dladdr(reinterpret_cast<void*>(a.Send), &info) && info.dli_fname) a.path = info.dli_fname;
@@ -72,6 +76,7 @@ struct RcclComm {
     lig_ctx* ctx = nullptr;                 // cleared by lig_ctx_destroy (lig_internal_comms_release): the context may die first
     uint32_t rank = 0, world = 1;
     bool in_sync = false;                   // a2a_sync is running a2a_on (fault injection tells the two forms apart)
+    bool aborted = false;
 };
 
 int fail(RcclComm* r, const char* what, ncclResult_t e) {
@@ -116,6 +121,24 @@ int ag_sync(void* user, const void* send, void* recv, size_t bytes) {
     RcclComm* r = static_cast<RcclComm*>(user);
     if (!r->ctx || ag_on(user, send, recv, bytes, r->ctx->stream)) return 1;
     return hipStreamSynchronize(r->ctx->stream) == hipSuccess ? 0 : 1;
+}
+
+// lig_comm.failed / .abort (include/lig_hip.h): what RCCL itself knows about the communicator (asynchronous errors of its proxy
+// threads and transports), and ncclCommAbort -- queued RCCL kernels of this rank exit, the streams drain
+int comm_failed(void* user) {
+    RcclComm* r = static_cast<RcclComm*>(user);
+    if (r->aborted) { if (r->ctx) r->ctx->err = "nccl: communicator aborted (a wait for queued collectives timed out)"; return 1; }
+    if (!r->comm || !api().CommGetAsyncError) return 0;
+    ncclResult_t st = ncclSuccess;
+    if (api().CommGetAsyncError(r->comm, &st) != ncclSuccess || st == ncclSuccess || st == ncclInProgress) return 0;
+    if (r->ctx) r->ctx->err = std::string("nccl asynchronous error: ") + api().GetErrorString(st);
+    return 1;
+}
+void comm_abort(void* user) {
+    RcclComm* r = static_cast<RcclComm*>(user);
+    if (!r->comm || r->aborted) return;
+    r->aborted = true;
+    if (api().CommAbort) { (void)api().CommAbort(r->comm); r->comm = nullptr; }       // (abort also frees the communicator)
 }
 
 // drain the context's streams and end the communicator; the RcclComm object itself stays (the caller's lig_comm points to it)
@@ -171,6 +194,8 @@ int lig_rccl_comm_create(lig_ctx* c, const uint8_t id[LIG_RCCL_ID_BYTES], uint32
     out->all_gather = ag_sync;
     out->all_to_all_on = a2a_on;
     out->all_gather_on = ag_on;
+    out->failed = comm_failed;
+    out->abort = comm_abort;
     return LIG_OK;
 }
 

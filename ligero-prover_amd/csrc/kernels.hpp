@@ -33,6 +33,8 @@ struct Knobs {
     bool     trace = false;            // LIG_TRACE          synchronised phase timeline on stderr
     int      fault_comm = 0;           // LIG_FAULT_COMM     tests: 1 = the stream-ordered all-to-all of the library's communicators
                                        //                    fails on first use, 2 = the host-synchronous one fails as well
+    int      comm_timeout_s = 300;     // LIG_COMM_TIMEOUT_S  lig_shard_*: seconds the host waits for queued work with collectives before it calls lig_comm.abort
+    int      ipc_stall_s = 60;         // LIG_IPC_STALL_S    comm_ipc watchdog: seconds without any flag changing before an outstanding collective is declared dead
     std::string rccl_lib;              // LIG_RCCL_LIB       the librccl to load instead of the one already mapped / found
 };
 const Knobs& knobs();

@@ -321,6 +321,8 @@ const lig::Knobs& lig::knobs() {
         t.shard_force_exchange = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
         t.trace = std::getenv("LIG_TRACE") != nullptr;
         t.fault_comm = (int)num("LIG_FAULT_COMM", 0);
+        t.ipc_stall_s = (int)pos("LIG_IPC_STALL_S", 60);
+        t.comm_timeout_s = (int)pos("LIG_COMM_TIMEOUT_S", 300);
         { const char* e = std::getenv("LIG_RCCL_LIB"); if (e) t.rccl_lib = e; }
         return t;
     }();
@@ -341,6 +343,10 @@ int lig_internal_comm_fault(lig_ctx* c, bool stream_ordered) {
 extern "C" {
 
 const char* lig_version(void) { return "lig_hip 0.1 (gfx950)"; }
+void lig_abi_sizes(uint32_t out[LIG_ABI_STRUCTS]) {
+    const uint32_t v[LIG_ABI_STRUCTS] = {sizeof(lig_batch_op), sizeof(lig_synth_job), sizeof(lig_proof_info), sizeof(lig_verify_info), sizeof(lig_rows_job), sizeof(lig_comm)};
+    if (out) std::memcpy(out, v, sizeof v);
+}
 
 int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n) {
     if (!out) return LIG_E_ARG;

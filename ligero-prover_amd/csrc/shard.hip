@@ -1,5 +1,7 @@
 // shard.hip -- one trace sharded over the GPUs of a node (lig_shard_*).
 #include "prover_common.hpp"
+#include <unistd.h>
+#include <functional>
 #include <thread>
 
 // =====================================================================================================================
@@ -297,6 +299,48 @@ void lig_shard_destroy(lig_shard* S) {
     delete S;
 }
 
+// Bounded wait for queued work that contains stream-ordered collectives (round 5: a sharded call returns an error, it never hangs).
+// A collective inside a queue cannot time out or report a failure; so the host polls instead of blocking, and
+//   * asks lig_comm.failed (comm_ipc: watchdog thread -- dead peer, abort word, stall timer; comm_rccl: ncclCommGetAsyncError):
+//     a failed communicator releases / aborts its queued waits, the streams drain, the call returns LIG_E_STATE with the reason;
+//   * after LIG_COMM_TIMEOUT_S (default 300 s -- fifty times the longest sharded proof measured) calls lig_comm.abort
+//     (ncclCommAbort / poison) itself.
+// Without stream-ordered forms (host-synchronous callbacks) the wait is a plain synchronize: nothing of a peer is in the queues.
+static int shard_bounded_wait(lig_shard* S, const std::function<hipError_t()>& query, const char* what) {
+    lig_ctx* c = S->c;
+    const lig_comm& cm = S->comm;
+    const auto t0 = clk::now();
+    const double limit_s = (double)lig::knobs().comm_timeout_s;
+    bool aborted = false, failed = false;
+    auto t_fail = t0;
+    std::string why;
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = query();
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); c->err = std::string(what) + ": " + hipGetErrorString(e); return LIG_E_HIP; }
+        if (spins < 4000) { std::this_thread::yield(); continue; }
+        usleep(50);
+        if ((spins & 63) != 0) continue;
+        const auto now = clk::now();
+        if (!failed && cm.failed && cm.failed(cm.user)) { failed = true; t_fail = now; why = c->err; }
+        if (!failed && !aborted && std::chrono::duration<double>(now - t0).count() > limit_s) {
+            aborted = failed = true; t_fail = now;
+            why = std::string(what) + ": no completion after " + std::to_string((int)limit_s) + " s (LIG_COMM_TIMEOUT_S)";
+            if (cm.abort) cm.abort(cm.user);
+        }
+        if (failed && std::chrono::duration<double>(now - t_fail).count() > 20.0) {        // the queues did not drain even so: report, leave the rest to the caller
+            c->err = "collective failed and the streams did not drain: " + why;
+            return LIG_E_STATE;
+        }
+    }
+    if (failed || (cm.failed && cm.failed(cm.user))) {
+        if (failed) c->err = why;
+        if (c->err.find("ipc comm") == std::string::npos && c->err.find("nccl") == std::string::npos) c->err = "collective failed: " + c->err;
+        return LIG_E_STATE;
+    }
+    return LIG_OK;
+}
+
 // where the stage-2 randomness rows of the LOCAL rows come from: generated (dense rows of the synthetic stream) or the caller's
 struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
 #define SHARD_COMMON \
@@ -313,7 +357,15 @@ struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
         if (S->comm.all_gather(S->comm.user, src, dst, bytes)) return comm_fail(what); \
         return LIG_OK; \
     }; \
-    (void)l; (void)pad; (void)RM; (void)t; (void)s_comm; (void)W; (void)Rl; (void)R; (void)CAP; (void)ncol; (void)s_hash; (void)all_gather
+    auto drain = [&](hipStream_t st, const char* what) -> int { \
+        if (!ordered) { HIP_TRY(c, hipStreamSynchronize(st)); return LIG_OK; } \
+        return shard_bounded_wait(S, [&] { return hipStreamQuery(st); }, what); \
+    }; \
+    auto drain_event = [&](hipEvent_t ev, const char* what) -> int { \
+        if (!ordered) { HIP_TRY(c, hipEventSynchronize(ev)); return LIG_OK; } \
+        return shard_bounded_wait(S, [&] { return hipEventQuery(ev); }, what); \
+    }; \
+    (void)l; (void)pad; (void)RM; (void)t; (void)s_comm; (void)W; (void)Rl; (void)R; (void)CAP; (void)ncol; (void)s_hash; (void)all_gather; (void)drain; (void)drain_event
 
 static int shard_stage1(lig_shard* S, lig_proof_info* info) {
     SHARD_COMMON;
@@ -409,7 +461,7 @@ static int shard_stage1(lig_shard* S, lig_proof_info* info) {
     TRY(all_gather(S->leaves_slice, leaf_level, ncol * 32, s, "all_gather(leaves)"));
     TRY(lig_merkle_build(c, leaf_level, n, S->nodes));
     HIP_TRY(c, hipMemcpyAsync(info->root, S->nodes, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    TRY(drain(s, "stage 1 (exchange, column hash, leaves)"));
     if (S->rows_by_thread) {                                  // every round has been waited for: the caller's rows are no longer read
         S->rows_by_thread = false;
         if (const int e = S->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("rows upload failed: ") + hipGetErrorString((hipError_t)e));
@@ -573,7 +625,7 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
         Sha256 h2;
         h2.add("LigetronStage2", 15).add(info->root, 32);
         for (int a3 = 0; a3 < 3; a3++) {
-            HIP_TRY(c, hipEventSynchronize(ev_acc[a3]));
+            TRY(drain_event(ev_acc[a3], "stage 2 (accumulators)"));
             h2.add(enc + (size_t)a3 * vec_bytes, vec_bytes);
         }
         h2.finish(info->stage2_seed);
@@ -586,7 +638,7 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     }
     const std::vector<uint32_t> idx = sample_columns(info->stage2_seed, n, t);
     TRY(lig_sample_init(c, idx.data(), idx.size()));
-    HIP_TRY(c, hipEventSynchronize(c->ev_join));          // decoded accumulators and Merkle nodes are on the host
+    TRY(drain_event(c->ev_join, "stage 2 (decodes)"));     // decoded accumulators and Merkle nodes are on the host
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
     info->valid_code = 1;
     for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
@@ -623,7 +675,7 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
         dst += rg * (size_t)t * 32;
     }
     HIP_TRY(c, hipMemcpyAsync(dst, S->smp + Rl * (size_t)t, 3 * (size_t)t * 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    TRY(drain(s, "stage 3 (opened columns)"));
     *proof = S->h_proof;
     *proof_len = lay.total;
     info->ms_stage3 = ms_since(t0);

@@ -42,6 +42,29 @@ def test_pure_host_entry_points():
     assert L.lig_sync(None) == -1
 
 
+def test_struct_layouts_of_the_bindings_match_the_library():
+    """lig_abi_sizes: the ctypes structs (and tests/batch_prog.py's BatchOp) have the library's sizeof; load_library refuses a mismatch"""
+    import batch_prog
+    mod = hip_lib.load()
+    L = mod.load_library()                       # raises on a mismatch of the five structs it binds
+    sizes = (ctypes.c_uint32 * 6)()
+    L.lig_abi_sizes(sizes)
+    assert sizes[0] == ctypes.sizeof(batch_prog.BatchOp) == 32
+    assert sizes[5] == ctypes.sizeof(mod.Comm) == 8 * ctypes.sizeof(ctypes.c_void_p)
+    orig = mod.Comm
+    class Short(ctypes.Structure):
+        _fields_ = orig._fields_[:-2]
+    mod.Comm = Short
+    try:
+        mod.load_library()
+    except RuntimeError as e:
+        assert "lig_comm" in str(e)
+    else:
+        raise AssertionError("a short lig_comm must be refused")
+    finally:
+        mod.Comm = orig
+
+
 def test_binding_fails_loudly_without_library(tmp_path, monkeypatch):
     mod = hip_lib.load()
     monkeypatch.setattr(mod, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -28,12 +28,10 @@ def test_gpus_2_spawns_two_ranks_and_reports_them():
 
 
 def test_under_an_external_launcher_the_ranks_are_used_as_given():
-    port = "29957"
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "2", "--warmup", "0"],
-                              env=_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port),
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
-    outs = [p.communicate(timeout=300) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs[0][1].decode()[-2000:]
+    import multirank as mr
+    argv = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "2", "--warmup", "0"]
+    res = mr.run_ranks(argv, 2, mr.rendezvous_env(2, base=_env()), timeout=180)
+    outs = [(o.encode(), e.encode()) for o, e in res]
     line0 = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")]
     assert len(line0) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
     out = json.loads(line0[0])
@@ -45,7 +43,7 @@ def test_world_size_that_disagrees_with_gpus_fails_loudly():
                        env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), capture_output=True, timeout=120)
     assert p.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in p.stderr
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub"],
-                       env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29958"), capture_output=True, timeout=120)
+                       env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(__import__("multirank").free_port())), capture_output=True, timeout=120)
     assert p.returncode != 0 and b"--gpus 1 but WORLD_SIZE=2" in p.stderr
 
 

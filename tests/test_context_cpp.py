@@ -206,10 +206,9 @@ def test_sharded_row_batcher_gives_the_oracle_envelope_on_every_rank(world, n_li
     """hip_row_batcher::shard_over: the same guest on `world` ranks (processes on the one GPU, comm_ipc), each keeping the rows of its
     chunks; every rank's envelope is the oracle's -- the backend side of configs[4] (one guest trace on the GPUs of a node)"""
     exe = build_sharded_batcher_exe()
-    name = "/lig_sb_%d_%d" % (os.getpid(), world)
+    import multirank as mr
+    name = "/lig_sb_" + mr.fresh_tag()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([exe, str(r), str(world), name, str(n_lin), str(n_quad)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-             for r in range(world)]
-    for r, p in enumerate(procs):
-        o, e = p.communicate(timeout=600)
-        assert p.returncode == 0 and ("rank %d: equal 1 " % r) in o.decode(), (o.decode(), e.decode()[-2000:])
+    outs = mr.run_ranks(lambda r: [exe, str(r), str(world), name, str(n_lin), str(n_quad)], world, env, timeout=120)
+    for r, (o, e) in enumerate(outs):
+        assert ("rank %d: equal 1 " % r) in o, (o, e[-2000:])

@@ -29,16 +29,9 @@ WORKER = textwrap.dedent('''
 def test_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2")
-    procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
-    outs = []
-    for p in procs:
-        o, err = p.communicate(timeout=180)
-        assert p.returncode == 0, err.decode()[-2000:]
-        outs.append(__import__("json").loads(o.decode().strip().splitlines()[-1]))
+    import multirank as mr
+    res = mr.run_ranks(mr.python_argv(script, ROOT), 2, mr.rendezvous_env(2), timeout=120)
+    outs = [__import__("json").loads(o.strip().splitlines()[-1]) for o, _ in res]
     outs.sort(key=lambda d: d["rank"])
     assert [o["world"] for o in outs] == [2, 2]
     assert outs[0]["jobs"] == [0, 2, 4, 6] and outs[1]["jobs"] == [1, 3, 5]            # every job exactly once

@@ -12,6 +12,8 @@ import textwrap
 
 import pytest
 
+import multirank as mr
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
@@ -51,23 +53,14 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch=False, comm=None):
+def run_world(tmp_path, world, l, k, n, n_lin, n_quad, batch=False, comm=None, timeout=120):
     """comm=None: host-synchronous gloo callbacks; comm="ipc": the stream-ordered process-to-process communicator
-    (csrc/comm_ipc.hip) -- the double-buffered exchange pipeline of lig_shard_prove with real peers on the one GPU"""
+    (csrc/comm_ipc.hip) -- the double-buffered exchange pipeline of lig_shard_prove with real peers on the one GPU.
+    Every invocation has its own rendezvous port and communicator tag; all ranks are watched (tests/multirank.py)."""
     script = tmp_path / "shard_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if comm:
-        env.update(LIG_COMM=comm, LIG_COMM_TAG=str(os.getpid()))
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad), "1" if batch else "0"],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-             for r in range(world)]
-    outs = []
-    for p in procs:
-        o, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err.decode()[-3000:]
-        outs.append(json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1]))
-    return sorted(outs, key=lambda d: d["rank"])
+    outs = mr.run_ranks(mr.python_argv(script, ROOT, l, k, n, n_lin, n_quad, "1" if batch else "0"), world, mr.rendezvous_env(world, comm), timeout=timeout)
+    return sorted((mr.last_json(o) for o, _ in outs), key=lambda d: d["rank"])
 
 
 @pytest.mark.parametrize("world,l,k,n,n_lin,n_quad", [
@@ -78,7 +71,7 @@ def run_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch=False, comm=N
     (4, 320, 512, 2048, 320 * 4300 + 1, 0),       # three rounds on 4 ranks, the last chunks shorter
 ])
 def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, n_quad):
-    outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, 29741 + world)
+    outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad)
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert len({o["sha"] for o in outs}) == 1
     assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
@@ -88,7 +81,7 @@ def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, l, k, n, n_lin, 
 def test_sharded_proof_with_batch_rows_equals_single_gpu_proof(tmp_path, world):
     """the batch program's rows are dealt to the ranks like any other rows (every rank runs the small program and keeps
     its slice; equality pairs and product triples are never split across ranks)"""
-    outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, 29791 + world, batch=True)
+    outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, batch=True)
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
 
@@ -106,7 +99,7 @@ def test_sharded_over_stream_ordered_ipc_comm_equals_single_gpu_proof(tmp_path, 
     """W processes on the one GPU, collectives = comm_ipc.hip: peers pull from each other's send buffers, ordering on the
     GPU (stream memory operations), so lig_shard_prove takes its `ordered` branch (exchange of round c on the copy stream
     under the encode of round c+1 and the hash of round c-1) with W > 1"""
-    outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, 29841 + world, comm="ipc")
+    outs = run_world(tmp_path, world, l, k, n, n_lin, n_quad, comm="ipc")
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert len({o["sha"] for o in outs}) == 1
     assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
@@ -114,7 +107,7 @@ def test_sharded_over_stream_ordered_ipc_comm_equals_single_gpu_proof(tmp_path, 
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_batch_rows_over_ipc_comm(tmp_path, world):
-    outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, 29861 + world, batch=True, comm="ipc")
+    outs = run_world(tmp_path, world, 320, 512, 2048, 900, 330, batch=True, comm="ipc")
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["all_equal"] for o in outs)
     assert outs[0]["ref_sha"] == outs[0]["sha"], "sharded envelope differs from the single-GPU envelope"
 
@@ -153,9 +146,9 @@ def test_rccl_stream_ordered_collectives_one_rank(tmp_path):
     can exercise of the RCCL path"""
     script = tmp_path / "nccl_worker.py"
     script.write_text(NCCL_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29761", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(mr.free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                LIG_SHARD_FORCE_EXCHANGE="1")
-    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=600)
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=240)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])     # RCCL prints its own lines
     assert out == {"equal": True, "valid": [1, 1, 1]}
@@ -191,9 +184,9 @@ def test_sharded_configs3_trace_full_size_equals_oracle_pin(tmp_path):
         pin = json.load(f)
     script = tmp_path / "big_worker.py"
     script.write_text(BIG_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29771", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(mr.free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                LIG_SHARD_FORCE_EXCHANGE="1")
-    p = subprocess.run([sys.executable, str(script), ROOT, "26"], env=env, capture_output=True, timeout=900)
+    p = subprocess.run([sys.executable, str(script), ROOT, "26"], env=env, capture_output=True, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
@@ -208,19 +201,14 @@ def test_sharded_configs3_trace_full_size_over_ipc_comm_equals_oracle_pin(tmp_pa
         pin = json.load(f)
     script = tmp_path / "big_worker.py"
     script.write_text(BIG_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29871 + world), WORLD_SIZE=str(world), LIG_COMM="ipc",
-               LIG_COMM_TAG=str(os.getpid()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, "26", "gloo"], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
-    for p in procs:
-        o, err = p.communicate(timeout=900)
-        assert p.returncode == 0, err.decode()[-3000:]
-        out = json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1])
+    outs = mr.run_ranks(mr.python_argv(script, ROOT, "26", "gloo"), world, mr.rendezvous_env(world, "ipc"), timeout=420)
+    for o, _ in outs:
+        out = mr.last_json(o)
         assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
         assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
 
 
-def _bench(args, timeout=1200, **envkw):
+def _bench(args, timeout=600, **envkw):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **envkw)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, timeout=timeout)
@@ -239,7 +227,7 @@ def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_pat
     comm_ipc over a gloo rendezvous): the N > 1 code path of the bench -- weak leg on every rank, preflight, then ONE trace
     sharded over the ranks in child processes, at two sizes -- prints one JSON line with n_gpus = 2 and a `sharded` object whose
     envelope equals the oracle pin, delivered by the first rung of the ladder"""
-    out = _bench(TWO_ON_ONE + ["--sharded-log2", "22,24"], LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()))
+    out = _bench(TWO_ON_ONE + ["--sharded-log2", "22,24"], LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=mr.fresh_tag())
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     sh = out["sharded"]
     assert sh["ranks"] == 2 and sh["log2_constraints"] == 24 and sh["scaling"] == "strong"
@@ -260,7 +248,7 @@ def test_bench_ladder_falls_through_an_injected_transport_failure_with_two_real_
     """a failure of the first rung (LIG_FAULT_COMM: injected in the library's communicators) must not cost the
     measurement -- the ladder falls through to the next rung, which still produces the oracle pin's envelope on both ranks"""
     out = _bench(TWO_ON_ONE + ["--sharded-log2", "24", "--sharded-timeout", "30" if fault == "3" else "180"],
-                 LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=str(os.getpid()), LIG_FAULT_COMM=fault)
+                 LIG_BENCH_SHARE_GPU="1", LIG_COMM="ipc", LIG_COMM_TAG=mr.fresh_tag(), LIG_FAULT_COMM=fault)
     sh = out["sharded"]
     assert out["value"] > 0 and sh["transport"] == delivered_by
     assert [a["transport"] for a in sh["attempts"] if not a["ok"]] == failed
@@ -309,9 +297,9 @@ def test_torch_transport_zero_copy_on_device_buffers_one_rank(tmp_path):
         print(json.dumps({"same": proof == ref, "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
         ctx.close(); g.close()
     '''))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(mr.free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                LIG_SHARD_FORCE_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=600)
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, timeout=240)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert out == {"same": True, "valid": [1, 1, 1]}
@@ -392,20 +380,11 @@ ROWS_WORKER = textwrap.dedent('''
 ''')
 
 
-def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch, mode, comm):
+def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, batch, mode, comm, timeout=120, **env):
     script = tmp_path / "shard_rows_worker.py"
     script.write_text(ROWS_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if comm:
-        env.update(LIG_COMM=comm, LIG_COMM_TAG=str(os.getpid()))
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(l), str(k), str(n), str(n_lin), str(n_quad), "1" if batch else "0", mode],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
-    outs = []
-    for p in procs:
-        o, err = p.communicate(timeout=900)
-        assert p.returncode == 0, err.decode()[-3000:]
-        outs.append(json.loads([ln for ln in o.decode().splitlines() if ln.startswith("{")][-1]))
-    return sorted(outs, key=lambda d: d["rank"])
+    outs = mr.run_ranks(mr.python_argv(script, ROOT, l, k, n, n_lin, n_quad, "1" if batch else "0", mode), world, mr.rendezvous_env(world, comm, **env), timeout=timeout)
+    return sorted((mr.last_json(o) for o, _ in outs), key=lambda d: d["rank"])
 
 
 @pytest.mark.parametrize("world,n_lin,n_quad,batch,mode,comm", [
@@ -422,8 +401,93 @@ def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, port, batch, mode, c
 def test_sharded_rows_entry_equals_rows_prove_and_oracle(tmp_path, world, n_lin, n_quad, batch, mode, comm):
     """lig_shard_rows_*: one trace whose rows come from the caller, sharded over W ranks (each rank passes all kinds + its own
     rows and randomness rows): every rank's envelope == lig_rows_prove on the whole trace == the oracle's prover"""
-    outs = run_rows_world(tmp_path, world, 320, 512, 2048, n_lin, n_quad, 29881 + world, batch, mode, comm)
+    outs = run_rows_world(tmp_path, world, 320, 512, 2048, n_lin, n_quad, batch, mode, comm)
     assert all(o["valid"] == [1, 1, 1] and o["again"] and o["const"] and o["all_equal"] for o in outs), outs
     assert outs[0]["equals_rows_prove"] is True and outs[0]["equals_oracle"] is True, outs
     if world == 4 and n_lin == 700:
         assert min(o["local_rows"] for o in outs) == 0
+
+
+FAILING_PEER_WORKER = textwrap.dedent('''
+    import importlib.util, json, os, signal, sys, time
+    import numpy as np
+    root, how = sys.argv[1], sys.argv[2]
+    sys.path.insert(0, os.path.join(root, "tests"))
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "ligero-prover_amd", rel))
+        m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+    pkg = load("ligero_prover_amd", "__init__.py")
+    dist = load("lig_dist", "dist.py")
+    import oracle_lib as ol
+    l, k, n = 320, 512, 2048
+    g = dist.Group("gloo")
+    ctx = pkg.Context(l, k, n, device=0)
+    job = ol.make_job(l, k, n, 192, 320 * 1500 + 7, 330, generated_at=55, threads=4)      # two exchange rounds
+    rows, _, _, _ = ol.form_rows(job)
+    kinds = ol.row_kinds(job).copy()
+    rounds, b = pkg.shard_rows_plan(kinds, g.world)
+    mine = pkg.local_rows_of(b, g.rank, g.world)
+    local = rows[mine]
+    comm = g.make_comm(pkg, ctx)
+    sh = ctx.shard_rows_begin(kinds, local, g.rank, g.world, comm, generated_at=55)
+    g.barrier()
+    if g.rank == 1:
+        if how == "killed":                          # the process disappears (no destructor runs)
+            os.kill(os.getpid(), signal.SIGKILL)
+        if how == "leaves":                          # an orderly exit of a rank that never joins the collective
+            ctx.shard_destroy(sh); ctx.ipc_comm_destroy(comm); ctx.close(); os._exit(0)
+        if how == "stalls":                          # alive, but never reaches the collective
+            time.sleep(25); os._exit(0)
+    t0 = time.time()
+    try:
+        ctx.shard_rows_commit(sh)
+        out = {"error": None}
+    except pkg.LigError as e:
+        out = {"error": str(e)}
+    out["seconds"] = time.time() - t0
+    t1 = time.time()
+    try:                                             # the communicator is dead: the next call fails at once
+        ctx.shard_rows_commit(sh)
+        out["again"] = None
+    except pkg.LigError as e:
+        out["again"] = str(e)
+    out["again_seconds"] = time.time() - t1
+    ctx.shard_destroy(sh)
+    ctx.close()
+    out["closed_after"] = time.time() - t0
+    print(json.dumps(out), flush=True)
+    os._exit(0)                                      # (no process-group barrier with a dead peer)
+''')
+
+
+@pytest.mark.parametrize("how,needle,limit", [
+    ("killed", "is gone", 30),                       # the peer's process is killed: noticed through its pid
+    ("leaves", "left the communicator", 30),         # the peer destroys its communicator without ever joining the collective
+    ("stalls", "no flag of any rank changed", 30),   # the peer is alive but stuck: the stall timer (LIG_IPC_STALL_S = 5 here)
+])
+def test_a_failing_peer_makes_the_sharded_call_return_an_error_instead_of_hanging(tmp_path, how, needle, limit):
+    """VERDICT r4 item 1: stream-ordered collectives wait inside GPU queues, where nothing times out.  comm_ipc's watchdog thread
+    declares the communicator dead (dead pid / departed peer / stall), releases the queued waits, and lig_shard_rows_commit returns
+    LIG_E_STATE with the reason -- in seconds, with every stream drained so that the shard and the context can be destroyed."""
+    script = tmp_path / "failing_peer_worker.py"
+    script.write_text(FAILING_PEER_WORKER)
+    env = mr.rendezvous_env(2, "ipc", LIG_IPC_STALL_S=5)
+    tmpd = tmp_path / "ranks"
+    tmpd.mkdir()
+    procs, files = [], []
+    for r in range(2):
+        fo, fe = open(tmpd / ("out%d" % r), "w+b"), open(tmpd / ("err%d" % r), "w+b")
+        files.append((fo, fe))
+        procs.append(subprocess.Popen(mr.python_argv(script, ROOT, how), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=fo, stderr=fe, start_new_session=True))
+    try:
+        rc0 = procs[0].wait(timeout=120)
+    finally:
+        for p in procs:
+            mr._kill_group(p)
+    files[0][0].seek(0); files[0][1].seek(0)
+    o, e = files[0][0].read().decode(), files[0][1].read().decode()
+    assert rc0 == 0, e[-3000:]
+    out = mr.last_json(o)
+    assert out["error"] and needle in out["error"], out
+    assert out["seconds"] < limit and out["closed_after"] < limit + 10, out
+    assert out["again"] and out["again_seconds"] < 5, out

@@ -5,6 +5,8 @@ so that buffers are freed and re-allocated under recycled addresses between proo
 compared with the unsharded prover's.  Not part of the product path.
 
     python tools/soak_sharded.py --world 2 --iters 40        (launcher; spawns the ranks)
+    python tools/soak_sharded.py --rows-entry --iters 200    (round 5: FRESH processes per iteration through the lig_shard_rows_* entry --
+                                                             the test that hung once in the round-4 driver run -- every rank's stderr kept)
 """
 import argparse
 import hashlib
@@ -60,12 +62,56 @@ def worker(iters):
     return bad
 
 
+def rows_entry_soak(iters, only_hung, log):
+    """tests/test_gpu_sharded.py::test_sharded_rows_entry_equals_rows_prove_and_oracle, its parameters in a loop, every iteration in
+    fresh processes (as under pytest); the parameter that hung in the round-4 driver run ([2-900-330-True-own_pads-ipc]) every other
+    iteration.  Failures (with every rank's stderr) go to `log`; the run goes on."""
+    import tempfile
+    import time
+    import pathlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multirank as mr
+    import test_gpu_sharded as tgs
+    hung = (2, 900, 330, True, "own_pads", "ipc")
+    others = [(2, 2000, 900, False, "own_pads", "ipc"), (4, 700, 0, False, "library_pads", "ipc"), (2, 320 * 1500 + 7, 330, False, "device_rows", "ipc"),
+              (4, 320 * 4300 + 1, 0, False, "library_pads", "ipc"), (2, 320 * 700 + 9, 335, False, "dense_rands", "ipc"), (4, 900, 330, True, "own_pads", "ipc"),
+              (2, 900, 330, True, "library_pads", "ipc"), (8, 900, 330, True, "own_pads", "ipc")]
+    tmp = pathlib.Path(tempfile.mkdtemp(prefix="lig_soak_"))
+    bad, t_all, worst = 0, time.time(), 0.0
+    with open(log, "a") as f:
+        for it in range(iters):
+            par = hung if (only_hung or it % 2 == 0) else others[(it // 2) % len(others)]
+            world, n_lin, n_quad, batch, mode, comm = par
+            t0 = time.time()
+            try:
+                outs = tgs.run_rows_world(tmp, world, 320, 512, 2048, n_lin, n_quad, batch, mode, comm, timeout=90, LIG_IPC_STALL_S=20)
+                ok = all(o["valid"] == [1, 1, 1] and o["again"] and o["const"] and o["all_equal"] for o in outs) and outs[0]["equals_rows_prove"] and outs[0]["equals_oracle"]
+                err = "" if ok else "MISMATCH %r" % (outs,)
+            except AssertionError as e:
+                ok, err = False, str(e)
+            dt = time.time() - t0
+            worst = max(worst, dt)
+            bad += not ok
+            f.write("iter %d %r: %s in %.1f s\n" % (it, par, "ok" if ok else "FAILED", dt))
+            if not ok:
+                f.write(err + "\n")
+            f.flush()
+        f.write("rows-entry soak: %d iterations, %d failures, slowest %.1f s, total %.0f s\n" % (iters, bad, worst, time.time() - t_all))
+    print("rows-entry soak: %d iterations, %d failures, slowest iteration %.1f s" % (iters, bad, worst))
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--iters", type=int, default=21)
     ap.add_argument("--comm", default="ipc")
+    ap.add_argument("--rows-entry", action="store_true")
+    ap.add_argument("--only-hung", action="store_true")
+    ap.add_argument("--log", default="soak_rows_entry.log")
     a = ap.parse_args()
+    if a.rows_entry:
+        sys.exit(1 if rows_entry_soak(a.iters, a.only_hung, a.log) else 0)
     if "RANK" in os.environ:
         sys.exit(1 if worker(a.iters) else 0)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29931", WORLD_SIZE=str(a.world), LIG_COMM_TAG=str(os.getpid()),
