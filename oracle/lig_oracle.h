@@ -214,6 +214,13 @@ void lo_proof_free(lo_proof *p);
 void lo_form_rows(const lo_job *j, lo_fr *rows /* (R-3)*k */, lo_fr *mask_code /* k */,
                   lo_fr *mask_lin /* 2k */, lo_fr *mask_quad /* 2k */);
 
+/* the three masks from the encoding stream at element position `pos` (witness_manager.hpp:271-321) */
+void lo_form_masks(const uint8_t encoding_seed[32], uint64_t pos, uint32_t l, uint32_t k, lo_fr *mask_code, lo_fr *mask_lin, lo_fr *mask_quad);
+/* the three-stage prover over a row stream formed elsewhere (kinds 0..3; rows with pads; masks; randomness rows and constant sum of the
+ * constraint generator's stage-2 replay): what lo_prove does after lo_form_rows.  Uses j->l,k,n,t, generated_at, threads, public args. */
+int  lo_prove_rows(const lo_job *j, const uint8_t *kinds, size_t rows_count, const lo_fr *rows, const lo_fr *mask_code,
+                   const lo_fr *mask_lin, const lo_fr *mask_quad, const lo_fr *rands, const lo_fr *const_sum, lo_proof *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -308,19 +308,18 @@ void lo_rand_rows(const lo_job *j, const uint8_t stage1_seed[32], lo_fr *rands, 
     free(rows); free(mc); free(ml); free(mq); free(rr); free(d);
 }
 
-int lo_prove(const lo_job *j, lo_proof *P) {
-    memset(P, 0, sizeof *P);
+/* The three stages over a formed row stream.  d / rows / masks: the committed rows in commit order.  given_rands == NULL: the dense
+ * randomness rows of the synthetic stream are drawn here (d[r].data draws per row); otherwise given_rands (R x k) are the rows the
+ * constraint generator produced (witness_manager's linear_random_ / quadratic_random_, nonbatch_context.hpp:654-700) and given_const its
+ * constant sum (witness_manager.hpp:393-405 constsum) -- NULL: minus the sum of the inner products. */
+static int prove_core(const lo_job *j, rowdesc *d, size_t R, lo_fr *rows, lo_fr *mc, lo_fr *ml, lo_fr *mq,
+                      const lo_fr *given_rands, const lo_fr *given_const, lo_proof *P) {
     const uint32_t l = j->l, k = j->k, n = j->n, t = j->t;
     const int T = j->threads > 0 ? j->threads : 1;
     lo_omp_threads = T;
-    if (batch_plan(j, NULL) < 0) return -1;
     lo_ctx *c = lo_ctx_new(l, k, n);
     if (!c) return -1;
-    rowdesc *d; size_t R = plan_rows(j, &d);
     P->rows = R + 3;
-    lo_fr *rows = malloc(sizeof(lo_fr) * (R ? R : 1) * k);
-    lo_fr *mc = malloc(sizeof(lo_fr) * k), *ml = malloc(sizeof(lo_fr) * 2 * k), *mq = malloc(sizeof(lo_fr) * 2 * k);
-    lo_form_rows(j, rows, mc, ml, mq);
     const size_t B = T > 32 ? 2 * (size_t)T : 64; /* rows encoded per parallel batch: at least two per thread */
     lo_fr *cws = malloc(sizeof(lo_fr) * B * n), *rws = malloc(sizeof(lo_fr) * B * n);
     lo_fr *m3 = malloc(sizeof(lo_fr) * 3 * n);
@@ -371,10 +370,11 @@ int lo_prove(const lo_job *j, lo_proof *P) {
 #endif
         for (long r = 0; r < (long)nb; r++) {
             lo_rng lr = lin_rng; lr.pos = lpos[r];
-            rand_row(&lr, rrows + r * k, d[b + r].data, k);
+            if (given_rands) memcpy(rrows + r * k, given_rands + (b + r) * k, sizeof(lo_fr) * k);
+            else rand_row(&lr, rrows + r * k, d[b + r].data, k);
             const lo_fr *w = rows + (b + r) * k, *rr = rrows + r * k;
             lo_fr acc; lo_fr_from_u64(&acc, 0);
-            for (uint32_t i = 0; i < d[b + r].data; i++) { lo_fr pr; lo_fr_mul(&pr, &w[i], &rr[i]); lo_fr_add(&acc, &acc, &pr); }
+            for (uint32_t i = 0; i < (given_rands ? k : d[b + r].data); i++) { lo_fr pr; lo_fr_mul(&pr, &w[i], &rr[i]); lo_fr_add(&acc, &acc, &pr); }
             psum[r] = acc;
         }
         for (size_t r = 0; r < nb; r++) lo_fr_add(&csum, &csum, &psum[r]);
@@ -394,7 +394,7 @@ int lo_prove(const lo_job *j, lo_proof *P) {
             for (size_t r = 0; r < nb; r++) {
                 const int kd = d[b + r].kind;
                 if (has_code_check(kd)) lo_eltwise(LO_OP_FMA_CONST, cws + r * n + jb, NULL, P->code + jb, blk, &rcs[r], 0);
-                if (d[b + r].data) lo_eltwise(LO_OP_FMA, cws + r * n + jb, rws + r * n + jb, P->lin + jb, blk, NULL, 0);
+                if (d[b + r].data || given_rands) lo_eltwise(LO_OP_FMA, cws + r * n + jb, rws + r * n + jb, P->lin + jb, blk, NULL, 0);
                 if (kd == 3 || kd == RK_BQZ || kd == RK_BIT) {           /* check_quadratic: x*y - z (bit: x*x - x) */
                     const size_t rx = kd == RK_BIT ? r : r - 2, ry = kd == RK_BIT ? r : r - 1;
                     lo_eltwise(LO_OP_MUL, cws + rx * n + jb, cws + ry * n + jb, tmp1 + jb, blk, NULL, 0);
@@ -411,7 +411,7 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     lo_eltwise(LO_OP_ADD_ASSIGN, m3, NULL, P->code, n, NULL, 0);
     lo_eltwise(LO_OP_ADD_ASSIGN, m3 + n, NULL, P->lin, n, NULL, 0);
     lo_eltwise(LO_OP_ADD_ASSIGN, m3 + 2 * (size_t)n, NULL, P->quad, n, NULL, 0);
-    lo_fr_neg(&P->const_sum, &csum);
+    if (given_const) P->const_sum = *given_const; else lo_fr_neg(&P->const_sum, &csum);
     lo_stage2_seed(P->root, P->code, P->lin, P->quad, n, P->stage2_seed);
     P->sample_idx = malloc(sizeof(uint32_t) * t);
     lo_sample_indices(P->stage2_seed, n, t, P->sample_idx);
@@ -446,9 +446,59 @@ int lo_prove(const lo_job *j, lo_proof *P) {
     P->t_stage3 = now_s() - t0;
 
     free(dec); free(sib); free(rrows); free(tmp1); free(tmp2); free(leaves); free(nodes); free(st);
-    free(cws); free(rws); free(m3); free(rows); free(mc); free(ml); free(mq); free(d);
+    free(cws); free(rws); free(m3);
     lo_ctx_free(c);
     return 0;
+}
+
+int lo_prove(const lo_job *j, lo_proof *P) {
+    memset(P, 0, sizeof *P);
+    const uint32_t k = j->k;
+    if (batch_plan(j, NULL) < 0) return -1;
+    rowdesc *d; size_t R = plan_rows(j, &d);
+    lo_fr *rows = malloc(sizeof(lo_fr) * (R ? R : 1) * k);
+    lo_fr *mc = malloc(sizeof(lo_fr) * k), *ml = malloc(sizeof(lo_fr) * 2 * k), *mq = malloc(sizeof(lo_fr) * 2 * k);
+    lo_form_rows(j, rows, mc, ml, mq);
+    const int rc = prove_core(j, d, R, rows, mc, ml, mq, NULL, NULL, P);
+    free(rows); free(mc); free(ml); free(mq); free(d);
+    return rc;
+}
+
+/* masks as process_masks draws them (witness_manager.hpp:271-321) from the encoding stream at element position `pos` */
+void lo_form_masks(const uint8_t encoding_seed[32], uint64_t pos, uint32_t l, uint32_t k, lo_fr *mask_code, lo_fr *mask_lin, lo_fr *mask_quad) {
+    lo_rng enc; lo_rng_init(&enc, encoding_seed); enc.pos = pos;
+    lo_rng_fill(&enc, mask_code, l);
+    memset(mask_code + l, 0, sizeof(lo_fr) * (k - l));
+    lo_fr sum; lo_fr_from_u64(&sum, 0);
+    memset(mask_lin, 0, sizeof(lo_fr) * 2 * k);
+    for (uint32_t i = 0; i + 1 < l; i++) { lo_rng_next(&enc, &mask_lin[2 * i + 1]); lo_fr_add(&sum, &sum, &mask_lin[2 * i + 1]); }
+    lo_fr_neg(&mask_lin[2 * (l - 1) + 1], &sum);
+    lo_rng_fill(&enc, mask_lin + 2 * l, 2 * (k - l));
+    memset(mask_quad, 0, sizeof(lo_fr) * 2 * k);
+    for (uint32_t i = 0; i < l; i++) lo_rng_next(&enc, &mask_quad[2 * i + 1]);
+    lo_rng_fill(&enc, mask_quad + 2 * l, 2 * (k - l));
+}
+
+/* The prover over a row stream formed ELSEWHERE (a constraint generator's callbacks: tests feed it the stream recorded from the
+ * reference's own witness_manager, tests/golden/ref_rows_*.npz): kinds[r] in {0 linear, 1 / 2 / 3 x / y / z of a triple}, rows R x k
+ * with their pads in place, the three masks, the randomness rows R x k and the constant sum of the stage-2 replay.  Uses j->l, k, n, t,
+ * generated_at, threads and the public arguments; the synthetic-stream members of j are ignored. */
+int lo_prove_rows(const lo_job *j, const uint8_t *kinds, size_t R, const lo_fr *rows, const lo_fr *mask_code, const lo_fr *mask_lin,
+                  const lo_fr *mask_quad, const lo_fr *rands, const lo_fr *const_sum, lo_proof *P) {
+    memset(P, 0, sizeof *P);
+    const uint32_t k = j->k;
+    rowdesc *d = malloc(sizeof(rowdesc) * (R ? R : 1));
+    for (size_t r = 0; r < R; r++) {
+        if (kinds[r] > 3) { free(d); return -1; }
+        if ((kinds[r] == 1 && !(r + 2 < R && kinds[r + 1] == 2 && kinds[r + 2] == 3)) || ((kinds[r] == 2 || kinds[r] == 3) && !(r > 0 && kinds[r - 1] == kinds[r] - 1))) { free(d); return -1; }
+        d[r] = (rowdesc){kinds[r], 0};
+    }
+    lo_fr *rw = malloc(sizeof(lo_fr) * (R ? R : 1) * k), *mc = malloc(sizeof(lo_fr) * k), *ml = malloc(sizeof(lo_fr) * 2 * k), *mq = malloc(sizeof(lo_fr) * 2 * k);
+    memcpy(rw, rows, sizeof(lo_fr) * R * k); memcpy(mc, mask_code, sizeof(lo_fr) * k);
+    memcpy(ml, mask_lin, sizeof(lo_fr) * 2 * k); memcpy(mq, mask_quad, sizeof(lo_fr) * 2 * k);
+    const int rc = prove_core(j, d, R, rw, mc, ml, mq, rands, const_sum, P);
+    free(rw); free(mc); free(ml); free(mq); free(d);
+    return rc;
 }
 void lo_proof_free(lo_proof *p) { free(p->sample_idx); free(p->code); free(p->lin); free(p->quad); free(p->samples); free(p->proof); memset(p, 0, sizeof *p); }
 

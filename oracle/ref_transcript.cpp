@@ -11,9 +11,10 @@
 //   include/zkp/merkle_tree.hpp:155-375           build_tree / decommit / recommit
 //   include/params.hpp:34                         params::hasher = sha256
 //
-// What is NOT reachable this way (needs GMP headers / Boost / protobuf-generated code, absent from this image):
-// util/csprng.hpp, finite_field_gmp.hpp, util/portable_sample.hpp (Boost uniform_int_distribution),
-// zkp/proof_serializer.hpp.  Those stay pinned as DESIGN.md section 5 says.
+// The GMP side of the reference (util/csprng.hpp, finite_field_gmp.hpp, src/bn254.cpp, util/mpz_vector.hpp, the constraint backend and
+// witness_manager) is built by the sibling driver ref_backend.cpp (round 5: the image has GMP headers under /opt/conda/include).
+// What is NOT reachable in this image: util/portable_sample.hpp (Boost uniform_int_distribution; Boost is absent) and
+// zkp/proof_serializer.hpp (protobuf-generated code).  Those stay pinned as DESIGN.md section 5 says.
 //
 // Build flags (oracle/Makefile): -std=c++20, -D__EMSCRIPTEN__ selects the reference's own no-Boost.Log branch of
 // util/log.hpp:19-28 (reached from merkle_tree.hpp via util/timer.hpp); `-include <std header>` supplies standard headers

@@ -277,6 +277,36 @@ def form_rows(job):
     return rows[:R], mc, ml, mq
 
 
+def form_masks(encoding_seed, pos, l, k):
+    """the three masks from the encoding stream at element position pos -> (k,8), (2k,8), (2k,8)"""
+    mc, ml, mq = (np.zeros((m * k, 8), dtype=np.uint32) for m in (1, 2, 2))
+    s = np.frombuffer(bytes(encoding_seed), dtype=np.uint8).copy()
+    lib().lo_form_masks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib().lo_form_masks(ptr(s), pos, l, k, ptr(mc), ptr(ml), ptr(mq))
+    return mc, ml, mq
+
+
+def prove_rows(l, k, n, t, kinds, rows, mask_code, mask_lin, mask_quad, rands, const_sum, generated_at=0, threads=4, public_args=None):
+    """the oracle's three stages over a row stream formed elsewhere (lo_prove_rows) -> dict(proof, root, stage1_seed, const_sum, valid)"""
+    j = Job()
+    j.set_public_args(public_args)
+    j.l, j.k, j.n, j.t, j.generated_at, j.threads = l, k, n, t, generated_at, threads
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (rows, mask_code, mask_lin, mask_quad)]
+    rands = np.ascontiguousarray(rands, dtype=np.uint32) if rands is not None else np.zeros((max(1, len(kinds)), k, 8), dtype=np.uint32)
+    cs = np.frombuffer(bytes(const_sum), dtype=np.uint8).copy() if const_sum is not None else None
+    pr = Proof()
+    L = lib()
+    L.lo_prove_rows.argtypes = [C.POINTER(Job), C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.POINTER(Proof)]
+    rc = L.lo_prove_rows(C.byref(j), ptr(kinds), len(kinds), *[ptr(a) for a in arrs], ptr(rands), ptr(cs) if cs is not None else None, C.byref(pr))
+    if rc != 0:
+        raise ValueError("lo_prove_rows rejected the row stream")
+    out = dict(proof=bytes(pr.proof[:pr.proof_len]), root=bytes(pr.root), stage1_seed=bytes(pr.stage1_seed), stage2_seed=bytes(pr.stage2_seed),
+               const_sum=bytes(pr.const_sum), valid=[pr.valid_code, pr.valid_linear, pr.valid_quad], rows=pr.rows)
+    L.lo_proof_free(C.byref(pr))
+    return out
+
+
 def make_job(l, k, n, t, n_linear, n_quad=0, synth_seed=1, generated_at=0, threads=1, public_args=None):
     j = Job()
     j.set_public_args(public_args)

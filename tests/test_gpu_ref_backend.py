@@ -1,0 +1,114 @@
+"""GPU: the HIP path against vectors produced by the REFERENCE's own GMP-side code (tests/golden/ref_field.json, ref_rows_*.npz; made by
+tests/golden/make_ref_backend.py from oracle/_ref/libref_backend.so -- the reference's bn254.cpp, finite_field_gmp.hpp, csprng.hpp,
+mpz_vector.hpp, witness_manager.hpp and core.hpp compiled in the build container):
+
+* the device AES-256-CTR field sampler (csrc/aes.hip) == bn254_gmp::generate_random over mpz_random_engine;
+* the executor's eltwise products / quotients / sums == bn254_gmp::mulmod / divmod / addmod / submod;
+* the rows entry (lig_rows_begin / _commit / _prove) on the row stream the reference's witness_manager + ligetron_backend emitted for
+  tests/i32_add.wat (configs[0]) and for a multiply-add guest: root, stage-1 seed and envelope equal what the oracle computes from the
+  same stream -- with the rows' own pads, and with the pads wiped and drawn by the library (LIG_ROW_DRAW_PAD: the library's sampler at
+  the positions the commit order implies must then reproduce pad_encoding_random).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hip_lib
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P = ol.P
+
+
+@pytest.fixture(scope="module")
+def amd():
+    return hip_lib.load()
+
+
+def field_gold():
+    with open(os.path.join(GOLD, "ref_field.json")) as f:
+        return json.load(f)
+
+
+def load_rows(name):
+    z = np.load(os.path.join(GOLD, "ref_rows_%s.npz" % name))
+    return dict(kinds=z["kinds"], vals=z["vals"], rands=z["rands"], constsum=z["constsum"].tobytes(), meta=json.loads(str(z["meta"])))
+
+
+def test_device_sampler_equals_reference_generate_random(amd):
+    c = amd.Context(320, 512, 2048)
+    try:
+        for s in field_gold()["sampler"]:
+            key, n = bytes.fromhex(s["key"]), s["count"]
+            d = c.malloc(n * 32)
+            c.rng_fill(key, 0, d, n)
+            got = c.download(d, (n, 8))
+            assert hashlib.sha256(got.tobytes()).hexdigest() == s["sha256_of_all"]
+            for i, hx in s["elements"].items():
+                assert got[int(i)].tobytes().hex() == hx
+            c.rng_fill(key, 1020, d, 8)                                  # any start position (the refill boundary at element 1024 inside)
+            assert np.array_equal(c.download(d, (8, 8)), got[1020:1028])
+            c.free(d)
+    finally:
+        c.close()
+
+
+def test_device_field_operations_equal_the_reference(amd):
+    ops = field_gold()["ops"]
+    c = amd.Context(320, 512, 2048)
+    try:
+        for name, op in (("mulmod", "MUL"), ("divmod", "DIV"), ("addmod", "ADD"), ("submod", "SUB")):
+            rows = [[int(x, 16) for x in r] for r in ops[name]]
+            a, b = ol.to_limbs([r[0] for r in rows]), ol.to_limbs([r[1] for r in rows])
+            da, db, do = c.upload(a), c.upload(b), c.malloc(len(rows) * 32)
+            c.eltwise(op, da, db, do, len(rows))
+            assert ol.from_limbs(c.download(do, (len(rows), 8))) == [r[2] for r in rows], name
+            for p in (da, db, do):
+                c.free(p)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("name", ["i32_add_320", "i32_add_8000", "mul_add_320"])
+@pytest.mark.parametrize("pads", ["own", "library"])
+def test_rows_entry_on_the_reference_backends_row_stream(amd, name, pads):
+    """configs[0]: the row stream of tests/i32_add.wat as the reference's constraint backend emits it (13 rows at l = 320, 4 at l = 8000)
+    through lig_rows_*: same root / seed / envelope as the oracle over the same rows, randomness rows and constant sum from the
+    reference's stage-2 replay"""
+    f = load_rows(name)
+    m = f["meta"]
+    l, k, n, t = m["l"], m["k"], m["n"], m["t"]
+    key = bytes.fromhex(m["encoding_seed"])
+    kinds, vals = f["kinds"].copy(), f["vals"].copy()
+    if pads == "library":
+        kinds |= amd.ROW_DRAW_PAD
+        vals[:, l:] = 0xDEADBEEF
+    masks = ol.form_masks(key, len(kinds) * (k - l), l, k)
+    want = ol.prove_rows(l, k, n, t, f["kinds"], f["vals"], *masks, f["rands"], f["constsum"], generated_at=m["generated_at"])
+    assert hashlib.sha256(want["proof"]).hexdigest() == m["oracle_proof_sha256"]          # (the fixture's own record of the same run)
+    c = amd.Context(l, k, n)
+    try:
+        tr, keep = c.rows_begin(kinds, vals, encoding_seed=key, generated_at=m["generated_at"])
+        root, seed1 = c.rows_commit(tr)
+        assert root.hex() == m["oracle_root"] and seed1.hex() == m["oracle_stage1_seed"]
+        proof, info = c.rows_prove(tr, f["rands"], f["constsum"])
+        assert [info.valid_code, info.valid_linear, info.valid_quad] == [1, 1, 1]
+        assert proof == want["proof"]
+        c.trace_destroy(tr)
+        # the constant the library derives when none is given (minus the sum of the inner products) is witness_manager::constsum()
+        tr, keep = c.rows_begin(kinds, vals, encoding_seed=key, generated_at=m["generated_at"])
+        c.rows_commit(tr)
+        proof3, info3 = c.rows_prove(tr, f["rands"], None)
+        assert bytes(info3.const_sum) == f["constsum"] and proof3 == want["proof"]
+        c.trace_destroy(tr)
+        # the HIP verifier on the same public data: kinds + proof -> the stage-1 seed -> the reference's randomness rows and constant
+        vt, vseed, vinfo = c.rows_verify_begin(f["kinds"], proof)
+        assert vt is not None and vseed == seed1 and vinfo.parsed == 1 and vinfo.indices_match == 1
+        v = c.rows_verify_finish(vt, f["rands"], f["constsum"])
+        assert [v.valid_merkle, v.valid_code, v.valid_linear, v.valid_quad, v.code_equal, v.linear_equal, v.quad_equal, v.accept] == [1] * 8
+    finally:
+        c.close()

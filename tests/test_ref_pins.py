@@ -6,8 +6,9 @@
   (liblig_hip.so: lig_instance_hash, lig_sample_columns' byte engine through the shared code path) must reproduce it.
 * tests/golden/ref_envelope.json was produced by the protobuf runtime from descriptors parsed out of the reference's
   proto/*.proto (tests/golden/make_ref_envelope.py); the oracle's hand-written encoder must give the same bytes.
-* when oracle/_ref/libref_transcript.so is present -- in the build container only: it is reference-built code and is
-  excluded from what travels to the GPU box (.gpurunignore) -- the same comparisons also run live on fresh random inputs.
+* when oracle/_ref/libref_transcript.so is present (built by `make -C oracle` where /root/reference exists; git-ignored, travels with
+  the snapshot) the same comparisons also run live on fresh random inputs.
+The GMP side (sampler, omegas, field operations, limb export, witness_manager's row stream): tests/test_ref_backend.py.
 Still unpinned by reference code: Boost's uniform_int_distribution (absent here), see DESIGN.md section 5.
 """
 import ctypes as C
