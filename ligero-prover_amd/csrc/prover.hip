@@ -69,9 +69,10 @@ struct lig_trace {
     fr* rands_full = nullptr;           // lig_rows_push_rands: R x k, device resident
     uint64_t rands_pushed = 0;          // rows handed to the uploader so far (word up_words - 1 counts the rows that have ARRIVED)
     size_t up_words = 0;                // words in up_flag: [stage-1 chunks | stage-2 chunks: randomness rows arrived | ... consumed]
+    bool push_sync = false;             // lig_rows_push_rands without an uploader thread: the pushed rows were copied synchronously
     std::atomic<int> up_abort{0};       // a failed lig_rows_prove: the uploader drops the randomness-row copies it still holds
     std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
-    std::atomic<int> up_failed{0};      // hipError_t of a chunk copy that failed (the chunk is published all the same: no stream may hang)
+    std::atomic<int> up_failed{0}, rand_pending{0}, rand_failed{0};      // hipError_t of a chunk copy that failed (the chunk is published all the same: no stream may hang)   -- rand_*: the same for randomness-row uploads, kept apart: lig_rows_prove must not wait for (or swallow the error of) the NEXT trace's witness prefetch
     // narrow row format (lig_rows_job.elem_bytes): packed byte offset of every row (+1 entry), the widths, the device staging
     // area the packed rows are uploaded to (expanded into `msgs` chunk by chunk in stage 1)
     bool narrow = false;
@@ -103,6 +104,7 @@ struct lig_trace {
 };
 
 static void uploader_drain(lig_trace* T);      // (below, with the uploader thread)
+static void rand_drain(lig_trace* T);
 static int ensure_up_flags(lig_ctx* c, lig_trace* T);
 
 // The batch program on the device (lig_hip.h, lig_batch_op): k-element variables in a slab, every operation one eltwise
@@ -454,12 +456,12 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         std::vector<UploadJob> jobs;
         for (size_t ci = 0; ci < n_chunks; ci++) {
             const size_t b = sched2[ci].first, nb = sched2[ci].second - b;
-            UploadJob j{(uint8_t*)rand_buf(ci), rs.host + b * (size_t)k * 32, nb * (size_t)k * 32, T->up_flag + rflag0 + ci, rseq, &T->up_failed};
+            UploadJob j{(uint8_t*)rand_buf(ci), rs.host + b * (size_t)k * 32, nb * (size_t)k * 32, T->up_flag + rflag0 + ci, rseq, &T->rand_failed};
             if (ci >= 2) { j.wait = T->up_flag + uflag0 + ci - 2; j.wait_val = rseq; }
             j.abort = &T->up_abort; j.prio = 1;
             jobs.push_back(j);
         }
-        lig_internal_uploader_submit(c->device, jobs, &T->up_pending);
+        lig_internal_uploader_submit(c->device, jobs, &T->rand_pending);
     }
     auto form_rand_chunk = [&](size_t ci) -> int {        // enqueued on the side stream
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
@@ -524,7 +526,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         const size_t b = sched2[ci].first, nb = sched2[ci].second - sched2[ci].first;
         fr* rb = rand_buf(ci);
         if (ci + 1 < n_chunks) TRY(form_rand_chunk(ci + 1));
-        if (rs.pushed) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + T->up_words - 1, (uint32_t)sched2[ci].second, hipStreamWaitValueGte, 0xffffffffu));
+        if (rs.pushed && !T->push_sync) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + T->up_words - 1, (uint32_t)sched2[ci].second, hipStreamWaitValueGte, 0xffffffffu));
         else if (rands_by_thread) HIP_TRY(c, hipStreamWaitValue32(s, T->up_flag_dev + rflag0 + ci, rseq, hipStreamWaitValueGte, 0xffffffffu));
         else HIP_TRY(c, hipStreamWaitEvent(s, T->ev_ready[ci & 1], 0));
         if (c->fast) {
@@ -700,6 +702,8 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream3);
     T->up_abort.store(1, std::memory_order_release);      // (copies that wait for a buffer of a proof that never ran)
     uploader_drain(T);                                    // an upload still in flight
+    rand_drain(T);
+    if (T->c->stream_sha) (void)hipStreamSynchronize(T->c->stream_sha);      // (experiment knob LIG_SHA_CUMASK: the stage-1 hash stream)
     T->c->sha.erase(T->sha_state);
     for (void* p : {(void*)T->rands_full, (void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->tri_dev,
@@ -823,6 +827,9 @@ void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs
 // every copy of this trace's uploads has been made (its host rows and its device matrix are no longer touched by the thread)
 static void uploader_drain(lig_trace* T) {
     while (T->up_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+}
+static void rand_drain(lig_trace* T) {
+    while (T->rand_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
 }
 // pinned flag words of a trace: one per stage-1 chunk (rows arrived), two per stage-2 chunk (caller randomness rows arrived / consumed)
 static int ensure_up_flags(lig_ctx* c, lig_trace* T) {
@@ -1006,7 +1013,7 @@ int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
         if (rc != LIG_OK) {           // the caller is told it may free its rows: nothing of ours may still read them
             const std::string why = c->err;
             uploader_drain(T);
-            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream_sha}) if (st) (void)hipStreamSynchronize(st);
             T->loaded = false; T->host_msgs = nullptr;
             c->err = why;
             return rc;
@@ -1037,9 +1044,9 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
     RandSource rs;                                        // default: generated from the dense counts of the job
     if (rands && T->rands_pushed) {                       // explicit rows win over rows pushed earlier: drop what the uploader still holds of those
         T->up_abort.store(1, std::memory_order_release);
-        uploader_drain(T);
+        rand_drain(T);
         T->up_abort.store(0, std::memory_order_release);
-        (void)T->up_failed.exchange(0);
+        (void)T->rand_failed.exchange(0);
         T->rands_pushed = 0;
     }
     if (rands && rands_on_device) rs.dev = (const fr*)rands; else if (rands) rs.host = (const uint8_t*)rands;
@@ -1053,15 +1060,15 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
         if (rc != LIG_OK) {           // randomness-row copies the uploader thread still holds read the caller's memory: drop them, wait
             T->rands_pushed = 0;
             T->up_abort.store(1, std::memory_order_release);
-            uploader_drain(T);
-            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            rand_drain(T);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream_sha}) if (st) (void)hipStreamSynchronize(st);
             c->err = why;
             return rc;
         }
         if (rs.host || rs.pushed) {
-            uploader_drain(T);
+            rand_drain(T);
             T->rands_pushed = 0;
-            if (const int e = T->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
+            if (const int e = T->rand_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
         }
     }
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
@@ -1082,14 +1089,34 @@ int lig_rows_push_rands_sparse(lig_trace* T, uint64_t first_row, uint64_t n_rows
     size_t n_present = n_rows;
     if (present) { n_present = 0; for (uint64_t i = 0; i < n_rows; i++) n_present += present[i] != 0; }
     if (n_present && !host_rows) FAIL(c, LIG_E_ARG, "lig_rows_push_rands: null rows");
-    if (lig::knobs().upload_mode != 2 || !lig_internal_uploader_available(c)) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: no uploader thread on this device (stream memory operations unavailable)");
     const size_t row_bytes = (size_t)c->k * 32;
     if (!T->rands_full) HIP_TRY(c, hipMalloc((void**)&T->rands_full, T->R * row_bytes));
+    if (lig::knobs().upload_mode != 2 || !lig_internal_uploader_available(c)) {
+        // no uploader thread (LIG_UPLOAD_MODE=1, or a device without stream memory operations): the same rows by plain copies on the
+        // copy stream, waited for here -- slower (the transfer sits in a HIP queue of the context) but every caller of the push
+        // interface (include/lig_hip_row_batcher.hpp) keeps working.  ADVICE r4.
+        if (first_row == 0) T->push_sync = true;
+        if (!T->push_sync) FAIL(c, LIG_E_STATE, "lig_rows_push_rands: the uploader became unavailable in the middle of a trace");
+        uint8_t* dst = (uint8_t*)T->rands_full + first_row * row_bytes;
+        const uint8_t* src = (const uint8_t*)host_rows;
+        for (uint64_t i = 0; i < n_rows;) {
+            uint64_t e = i + 1;
+            const bool p = !present || present[i] != 0;
+            while (e < n_rows && (!present || (present[e] != 0) == p)) e++;
+            if (p) { HIP_TRY(c, hipMemcpyAsync(dst + i * row_bytes, src, (size_t)(e - i) * row_bytes, hipMemcpyHostToDevice, c->stream3)); src += (e - i) * row_bytes; }
+            else HIP_TRY(c, hipMemsetAsync(dst + i * row_bytes, 0, (size_t)(e - i) * row_bytes, c->stream3));
+            i = e;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream3));
+        T->rands_pushed = first_row + n_rows;
+        return LIG_OK;
+    }
+    if (first_row == 0) T->push_sync = false;
     TRY(ensure_up_flags(c, T));
     volatile uint32_t* arrived = T->up_flag + T->up_words - 1;
     if (first_row == 0) { __atomic_store_n(arrived, 0u, __ATOMIC_RELEASE); T->up_abort.store(0, std::memory_order_release); }
     // one job per push: the uploader publishes the number of rows that have arrived (jobs of a trace are taken in order)
-    UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->up_failed};
+    UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->rand_failed};
     if (present && n_present != n_rows) {       // runs of present rows are copied from where they follow each other in host_rows, the others zero-filled on the device
         j.segs = std::make_shared<std::vector<UploadSeg>>();
         const uint8_t* src = (const uint8_t*)host_rows;
@@ -1103,7 +1130,7 @@ int lig_rows_push_rands_sparse(lig_trace* T, uint64_t first_row, uint64_t n_rows
         }
     }
     j.abort = &T->up_abort; j.prio = 1;
-    lig_internal_uploader_submit(c->device, {j}, &T->up_pending);
+    lig_internal_uploader_submit(c->device, {j}, &T->rand_pending);
     T->rands_pushed = first_row + n_rows;
     return LIG_OK;
 }

@@ -112,6 +112,14 @@ def test_row_batcher_shim_gives_the_oracle_envelope(l, k, n, n_lin, n_quad):
     assert out.startswith("equal 1 "), out
 
 
+@pytest.mark.gpu
+def test_row_batcher_shim_without_the_uploader_thread():
+    """with LIG_UPLOAD_MODE=1 (or on a device without stream memory operations) lig_rows_push_rands has no uploader thread to hand
+    the rows to -- it copies them on the copy stream and waits, the shim's two passes still end in the oracle's envelope"""
+    out = subprocess.check_output([build_batcher_exe(), "320", "512", "2048", str(320 * 530 + 1), "330"], env=dict(os.environ, LIG_UPLOAD_MODE="1")).decode()
+    assert out.startswith("equal 1 "), out
+
+
 BBSRC = os.path.join(ROOT, "tests", "cpp", "row_batcher_batch_prog.cpp")
 BBEXE = os.path.join(ROOT, "tests", "cpp", "row_batcher_batch_prog")
 
