@@ -307,6 +307,7 @@ const lig::Knobs& lig::knobs() {
         t.encode_chunk = (size_t)pos("LIG_ENCODE_CHUNK", 512);
         { const char* e = std::getenv("LIG_ENCODE_GENERIC"); t.encode_generic = e && e[0] == '1'; }
         t.sha_block = (uint32_t)pos("LIG_SHA_BLOCK", 256);
+        { const long v = num("LIG_SHA_WS", 2); t.sha_ws = (v == 0 || v == 1 || v == 4) ? (int)v : 2; }
         t.sha_gate = (int)num("LIG_SHA_GATE", 1);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
         t.sha_prio = (int)num("LIG_SHA_PRIO", 0);

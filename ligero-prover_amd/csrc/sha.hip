@@ -124,6 +124,137 @@ __global__ void k_sha_update_rows(uint32_t* __restrict__ st, size_t n_inst, cons
     for (int i = 0; i < 8; i++) st[(size_t)i * n_inst + j] = h[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised column hash (round 5).  leaf_j is a Merkle-Damgard chain over all rows of column j: nothing shortens it except
+// taking work OUT of the chain.  Of the 1760 instructions of a compression only the 64 rounds (14 instructions each) depend on the
+// chaining value; the message schedule sigma0 / sigma1 and the K[t] + W[t] additions (a third of the instructions) do not.  So a
+// group of 64 columns is served by TWO waves of one workgroup:
+//   producer  loads the two rows of block b + 1 from HBM, expands the schedule, adds K and leaves the 64 words K[t] + W[t] of every
+//             column in LDS (16 x ds_write_b128 per lane, 16 KiB per group);
+//   consumer  copies them into registers (16 x ds_read_b128, issued behind round 15 of block b, i.e. hidden under its remaining
+//             rounds) and runs nothing but the rounds: ~930 instructions per block on the critical path instead of 1760.
+// Hand-off without barriers: two LDS words per group -- `ready` = blocks the producer has published, `taken` = blocks the consumer
+// has copied out -- written with release, polled with acquire (s_sleep between polls; in steady state the producer is a block
+// ahead: its block costs ~620 instructions).  ONE slot per group suffices because the consumer holds block b + 1 in registers while it
+// works on block b.  The consumer keeps two register sets (even / odd blocks): no register copies between blocks.
+// Workgroup = GROUPS consumer waves followed by GROUPS producer waves; with GROUPS = 2 the four waves of a workgroup land on the four
+// SIMDs of a CU (32768 columns = 256 workgroups = one per CU: every wave alone on its SIMD when nothing else runs).
+// A two-wave variant with a barrier per block was measured in round 3 and lost (the barrier and the LDS round trip ate the shorter
+// chain); this one has no barrier after the prologue and no LDS latency on the chain.
+struct Kw4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t lds_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// rounds [R0, R1) of a compression on (a..hh) with the words K[t] + W[t] in kw[]
+template <int R0, int R1>
+__device__ __forceinline__ void sha256_rounds(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& e, uint32_t& f, uint32_t& g, uint32_t& hh,
+                                              const uint32_t (&kw)[64]) {
+#pragma unroll
+    for (int i = R0; i < R1; i++) {
+        const uint32_t t1 = (hh + xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25)) + ch(e, f, g)) + kw[i];
+        const uint32_t t2 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22)) + maj(a, b, c);
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+}
+
+template <int GROUPS>
+__global__ void __launch_bounds__(GROUPS * 128) k_sha_update_rows_ws(uint32_t* __restrict__ st, size_t n_inst, const fr* __restrict__ rows, size_t row_stride,
+                                                                      size_t nrows, uint64_t rows_before, uint32_t pk, const fr* __restrict__ msgs) {
+    __shared__ uint4 ring[GROUPS][16][64];
+    __shared__ uint32_t ready[GROUPS], taken[GROUPS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool producer = wave >= GROUPS;
+    const uint32_t g = producer ? wave - GROUPS : wave;
+    if (threadIdx.x < GROUPS) { ready[threadIdx.x] = 0; taken[threadIdx.x] = 0; }
+    __syncthreads();                                       // the only barrier: before any wave leaves
+    const size_t group = (size_t)blockIdx.x * GROUPS + g;
+    if (group * 64 >= n_inst) return;                      // (a whole group beyond the columns: both of its waves leave)
+    const size_t j = group * 64 + lane;
+    const bool live = j < n_inst;                          // a ragged last group: dead lanes take part in the hand-off, touch no memory
+    const size_t pend = (size_t)(rows_before & 1);
+    const size_t total = nrows + pend;
+    const uint32_t nblocks = (uint32_t)(total / 2);
+    uint4 (*slot)[64] = ring[g];
+
+    if (producer) {
+        const fr* p0 = rows + j;
+        size_t rs = row_stride;
+        if (pk && live) {
+            const uint32_t r = (uint32_t)j / pk, q = (uint32_t)j - r * pk;
+            if (msgs == nullptr) p0 = rows + 4 * (size_t)q + r;
+            else if (r == 0) { p0 = msgs + ((pk - q) & (pk - 1)); rs = pk; }
+            else { p0 = rows + (size_t)(r - 1) * pk + q; rs = 3 * (size_t)pk; }
+        }
+        auto elem = [&](size_t v) -> fr {                  // virtual element v: the pending half block (if any), then the new rows
+            if (!live) return fr_zero();
+            if (v == 0 && pend) {
+                fr e;
+#pragma unroll
+                for (int i = 0; i < 8; i++) e.v[i] = st[(size_t)(8 + i) * n_inst + j];
+                return e;
+            }
+            return fr_load(p0 + (v - pend) * rs);
+        };
+        fr n0 = fr_zero(), n1 = fr_zero();
+        if (nblocks) { n0 = elem(0); n1 = elem(1); }
+        for (uint32_t b = 0; b < nblocks; b++) {
+            uint32_t w[64];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { w[i] = n0.v[i]; w[8 + i] = n1.v[i]; }
+            if (b + 1 < nblocks) { n0 = elem(2 * (size_t)b + 2); n1 = elem(2 * (size_t)b + 3); }      // the next block's rows: in flight under the expansion
+#pragma unroll
+            for (int i = 16; i < 64; i++) {
+                const uint32_t w15 = w[i - 15], w2 = w[i - 2];
+                w[i] = (w[i - 16] + xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3) + w[i - 7]) + xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+            }
+#pragma unroll
+            for (int i = 0; i < 64; i++) w[i] += SHA_K[i];
+            while (__builtin_amdgcn_readfirstlane(lds_acquire(&taken[g])) < b) __builtin_amdgcn_s_sleep(2);      // the slot is free: block b - 1 is in the consumer's registers
+#pragma unroll
+            for (int i = 0; i < 16; i++) slot[i][lane] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+            lds_release(&ready[g], b + 1);
+        }
+        if ((total & 1) && live && !(total == 1 && pend)) {  // odd tail: keep the element for the next call / final
+            const fr e = fr_load(p0 + (total - 1 - pend) * rs);
+#pragma unroll
+            for (int i = 0; i < 8; i++) st[(size_t)(8 + i) * n_inst + j] = e.v[i];
+        }
+        return;
+    }
+
+    // ---- consumer
+    if (!nblocks) return;
+    uint32_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = live ? st[(size_t)i * n_inst + j] : 0u;
+    uint32_t ka[64], kb[64];
+    auto fetch = [&](uint32_t (&dst)[64], uint32_t upto) {   // block upto - 1 out of the slot (its 16 reads are asynchronous: first use waits)
+        while (__builtin_amdgcn_readfirstlane(lds_acquire(&ready[g])) < upto) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const uint4 q = slot[i][lane]; dst[4 * i] = q.x; dst[4 * i + 1] = q.y; dst[4 * i + 2] = q.z; dst[4 * i + 3] = q.w; }
+    };
+    auto block = [&](const uint32_t (&cur)[64], uint32_t (&nxt)[64], uint32_t b) {
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], gg = h[6], hh = h[7];
+        sha256_rounds<0, 16>(a, bb, c, d, e, f, gg, hh, cur);
+        const bool more = b + 1 < nblocks;
+        if (more) fetch(nxt, b + 2);
+        sha256_rounds<16, 64>(a, bb, c, d, e, f, gg, hh, cur);
+        if (more) lds_release(&taken[g], b + 2);             // (release: the reads above have landed) the producer may overwrite the slot
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += gg; h[7] += hh;
+    };
+    fetch(ka, 1);
+    lds_release(&taken[g], 1);
+    for (uint32_t b = 0; b < nblocks; b += 2) {
+        block(ka, kb, b);
+        if (b + 1 < nblocks) block(kb, ka, b + 1);
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[(size_t)i * n_inst + j] = h[i];
+    }
+}
+
 // padding + length (shader/sha256.wgsl:180-224); does not modify the state
 // pk != 0: plane-major instances (see k_sha_update_rows): instance j = r*pk + q is leaf 4q + r
 __global__ void k_sha_final(const uint32_t* __restrict__ st, size_t n_inst, uint64_t rows_total, uint32_t* __restrict__ digests, uint32_t pk) {
@@ -162,6 +293,14 @@ void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const
     // on all SIMDs of a CU (measured: encode kernels 2-3x slower next to 64-thread hash workgroups, 1.1-1.8x next to
     // 256-thread ones; tools/corun_bench.py).  LIG_SHA_BLOCK overrides for experiments.
     const uint32_t bs = lig::knobs().sha_block;
+    const int ws = lig::knobs().sha_ws;                  // LIG_SHA_WS: 0 = one wave per 64 columns (rounds 1-4), 1 / 2 / 4 = wave-specialised, groups per workgroup
+    if (ws && nrows + (rows_before & 1) >= 2) {
+        const size_t groups = (n_inst + 63) / 64;
+        if (ws == 1) hipLaunchKernelGGL(k_sha_update_rows_ws<1>, dim3((uint32_t)groups), dim3(128), 0, s, state, n_inst, rows, row_stride, nrows, rows_before, plane_k, msgs);
+        else if (ws == 4) hipLaunchKernelGGL(k_sha_update_rows_ws<4>, dim3((uint32_t)((groups + 3) / 4)), dim3(512), 0, s, state, n_inst, rows, row_stride, nrows, rows_before, plane_k, msgs);
+        else hipLaunchKernelGGL(k_sha_update_rows_ws<2>, dim3((uint32_t)((groups + 1) / 2)), dim3(256), 0, s, state, n_inst, rows, row_stride, nrows, rows_before, plane_k, msgs);
+        return;
+    }
     hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + bs - 1) / bs)), dim3(bs), 0, s, state, n_inst, rows, row_stride,
                        nrows, rows_before, plane_k, msgs);
 }
