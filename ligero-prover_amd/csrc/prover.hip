@@ -810,7 +810,14 @@ bool lig_internal_uploader_available(lig_ctx* c) {
         (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
         u = new Uploader();                         // lives for the process: its thread sleeps on the condition variable
         u->device = c->device;
-        u->ok = can && hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking) == hipSuccess;
+        // The uploader's stream must not share a HARDWARE queue with a stream that may hold a pending hipStreamWaitValue32 for the word this
+        // thread publishes: HIP maps the streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues per priority class, a pending stream
+        // wait occupies its queue, and a small host-to-device copy is a blit KERNEL in the copying stream's queue (tools/queue_share_probe.hip,
+        // profiles/r05_queue_share_probe.txt) -- behind the wait it would never run: the hang of the sharded rows entry in round 4.  Queues are
+        // pooled per priority class, the library's proof streams are normal priority: the uploader takes the highest.
+        int lo = 0, hi = 0;
+        const bool prio = lig::knobs().upload_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
+        u->ok = can && (prio ? hipStreamCreateWithPriority(&u->st, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking)) == hipSuccess;
         if (u->ok) { u->th = std::thread([u] { u->run(); }); u->th.detach(); }
     }
     return u->ok;

@@ -62,7 +62,7 @@ def worker(iters):
     return bad
 
 
-def rows_entry_soak(iters, only_hung, log):
+def rows_entry_soak(iters, only_hung, log, extra_env=None):
     """tests/test_gpu_sharded.py::test_sharded_rows_entry_equals_rows_prove_and_oracle, its parameters in a loop, every iteration in
     fresh processes (as under pytest); the parameter that hung in the round-4 driver run ([2-900-330-True-own_pads-ipc]) every other
     iteration.  Failures (with every rank's stderr) go to `log`; the run goes on."""
@@ -84,7 +84,7 @@ def rows_entry_soak(iters, only_hung, log):
             world, n_lin, n_quad, batch, mode, comm = par
             t0 = time.time()
             try:
-                outs = tgs.run_rows_world(tmp, world, 320, 512, 2048, n_lin, n_quad, batch, mode, comm, timeout=90, LIG_IPC_STALL_S=20)
+                outs = tgs.run_rows_world(tmp, world, 320, 512, 2048, n_lin, n_quad, batch, mode, comm, timeout=90, **dict({"LIG_IPC_STALL_S": 20}, **(extra_env or {})))
                 ok = all(o["valid"] == [1, 1, 1] and o["again"] and o["const"] and o["all_equal"] for o in outs) and outs[0]["equals_rows_prove"] and outs[0]["equals_oracle"]
                 err = "" if ok else "MISMATCH %r" % (outs,)
             except AssertionError as e:
@@ -109,9 +109,10 @@ def main():
     ap.add_argument("--rows-entry", action="store_true")
     ap.add_argument("--only-hung", action="store_true")
     ap.add_argument("--log", default="soak_rows_entry.log")
+    ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for the ranks (repeatable)")
     a = ap.parse_args()
     if a.rows_entry:
-        sys.exit(1 if rows_entry_soak(a.iters, a.only_hung, a.log) else 0)
+        sys.exit(1 if rows_entry_soak(a.iters, a.only_hung, a.log, dict(e.split("=", 1) for e in a.env)) else 0)
     if "RANK" in os.environ:
         sys.exit(1 if worker(a.iters) else 0)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29931", WORLD_SIZE=str(a.world), LIG_COMM_TAG=str(os.getpid()),
