@@ -206,7 +206,14 @@ void watchdog(IpcComm* r) {
                            std::to_string(__atomic_load_n(&sh->pulled[h * RS + (c % SLOTS) * FLAG_STRIDE], __ATOMIC_ACQUIRE));
             }
         }
-        if (!why.empty()) { declare_dead(r, why); continue; }
+        if (!why.empty()) {
+            declare_dead(r, why);
+            // diagnostics on stderr: why this rank's queues stand still (the call in progress registers a reporter with the context)
+            const std::string st = r->ctx ? lig_internal_debug_state(r->ctx) : std::string();
+            std::fprintf(stderr, "[lig ipc comm] rank %u: %s\n%s%s", r->rank, dead_reason(r).c_str(), st.c_str(), st.empty() ? "" : "\n");
+            std::fflush(stderr);
+            continue;
+        }
         usleep(10000);
     }
 }

@@ -1,6 +1,8 @@
 // ctx_internal.hpp -- the context object shared by lig_capi.hip and prover.hip (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -48,7 +50,13 @@ struct lig_ctx {
     uint64_t prof_rows = 0;
     // communicators made on this context (comm_rccl.hip, comm_ipc.hip): (object, its finalizer); ended with the context
     std::vector<std::pair<void*, void (*)(void*)>> comms;
+    // diagnostics: what the call in progress is waiting for (set by lig_shard_* around their queued work, read by a communicator's
+    // watchdog thread when it declares the communicator dead: the reason a rank stopped is then on stderr, not guessed afterwards)
+    std::mutex debug_mu;
+    std::function<std::string()> debug_state;
 };
+inline void lig_internal_set_debug_state(lig_ctx* c, std::function<std::string()> f) { std::lock_guard<std::mutex> lk(c->debug_mu); c->debug_state = std::move(f); }
+inline std::string lig_internal_debug_state(lig_ctx* c) { std::lock_guard<std::mutex> lk(c->debug_mu); return c->debug_state ? c->debug_state() : std::string(); }
 
 // end every communicator that still lives on the context (each finalizer drains the context's streams first and clears the
 // object's back pointer); called by lig_ctx_destroy

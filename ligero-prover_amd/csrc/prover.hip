@@ -753,6 +753,8 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
 // that alternate keep the link busy without ever sharing it.
 namespace {
 struct Uploader {
+    std::atomic<uint64_t> cur_bytes{0}, cur_since_us{0}, done_jobs{0};      // diagnostics
+    std::atomic<int> phase{0};                                              // 0 idle, 1 copy call, 2 waiting for the copy, 3 publishing
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<UploadJob, std::atomic<int>*>> q;
@@ -783,6 +785,9 @@ struct Uploader {
                 }
             }
             const bool skip = j.first.abort && j.first.abort->load(std::memory_order_acquire);
+            cur_bytes.store(j.first.bytes, std::memory_order_relaxed);
+            cur_since_us.store((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clk::now().time_since_epoch()).count(), std::memory_order_relaxed);
+            phase.store(1, std::memory_order_release);
             hipError_t e = hipSuccess;
             if (!skip && j.first.segs) {
                 for (const UploadSeg& g : *j.first.segs) {
@@ -790,11 +795,15 @@ struct Uploader {
                     e = g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, st) : hipMemsetAsync(g.dst, 0, g.bytes, st);
                 }
             } else if (!skip && j.first.bytes) e = hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st);
+            phase.store(2, std::memory_order_release);
             const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
+            phase.store(3, std::memory_order_release);
             // (a failed copy publishes too: no stream may hang on the flag; lig_rows_commit reports the error once stage 1 has drained)
             if (e2 != hipSuccess) { (void)hipGetLastError(); j.first.failed->store((int)e2, std::memory_order_release); }
             __atomic_store_n(j.first.flag, j.first.seq, __ATOMIC_RELEASE);
             j.second->fetch_sub(1, std::memory_order_acq_rel);
+            done_jobs.fetch_add(1, std::memory_order_relaxed);
+            phase.store(0, std::memory_order_release);
         }
     }
 };
@@ -822,6 +831,19 @@ bool lig_internal_uploader_available(lig_ctx* c) {
     }
     return u->ok;
 }
+}  // extern "C"
+std::string lig_internal_uploader_state(int device) {
+    if (device < 0 || device >= 64 || !g_uploader[device]) return "uploader: none";
+    Uploader* u = g_uploader[device];
+    size_t queued = 0;
+    { std::lock_guard<std::mutex> lk(u->mu); queued = u->q.size(); }
+    const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clk::now().time_since_epoch()).count();
+    const int ph = u->phase.load();
+    static const char* names[4] = {"idle", "in the copy call", "waiting for the copy", "publishing"};
+    return "uploader: " + std::string(names[ph & 3]) + (ph ? " (" + std::to_string(u->cur_bytes.load()) + " bytes, for " + std::to_string((now - u->cur_since_us.load()) / 1000) + " ms)" : "") +
+           ", " + std::to_string(queued) + " queued, " + std::to_string(u->done_jobs.load()) + " done";
+}
+extern "C" {
 void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending) {
     Uploader* u = g_uploader[device];
     pending->fetch_add((int)jobs.size(), std::memory_order_acq_rel);

@@ -55,6 +55,7 @@ struct UploadJob { uint8_t* dst; const uint8_t* src; size_t bytes; volatile uint
                    std::shared_ptr<std::vector<UploadSeg>> segs; };
 extern "C" bool lig_internal_uploader_available(lig_ctx* c);          // false: no stream memory operations on this device (callers fall back to stream copies)
 extern "C" void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending);   // *pending += jobs, -1 per finished job
+std::string lig_internal_uploader_state(int device);                  // diagnostics: queue length, the copy in progress and for how long
 
 // (outside the anonymous namespace: these types appear in functions shared between translation units)
 // kind: 0 linear, 1 x, 2 y, 3 z of the synthetic stream; >= 4: rows committed by the batch program (RK_* below)

@@ -367,8 +367,25 @@ struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
     }; \
     (void)l; (void)pad; (void)RM; (void)t; (void)s_comm; (void)W; (void)Rl; (void)R; (void)CAP; (void)ncol; (void)s_hash; (void)all_gather; (void)drain; (void)drain_event
 
+// what a watchdog prints when it declares the communicator dead while a sharded call is in progress
+static std::string shard_debug(lig_shard* S, const char* stage, uint32_t rseq) {
+    lig_ctx* c = S->c;
+    auto q = [](hipStream_t st) { const hipError_t e = hipStreamQuery(st); (void)hipGetLastError(); return e == hipSuccess ? "drained" : e == hipErrorNotReady ? "BUSY" : "error"; };
+    std::string o = std::string("[lig_shard] rank ") + std::to_string(S->rank) + " in " + stage + ": streams main " + q(c->stream) + ", side " + q(c->stream2) + ", copy " + q(c->stream3);
+    o += "; rows upload seq " + std::to_string(S->up_seq) + ", randomness seq " + std::to_string(rseq) + ", pending " + std::to_string(S->up_pending.load()) + ", flag words [arrived rows | arrived rands | consumed]:";
+    if (S->up_flag && S->rounds) for (size_t i = 0; i < 3 * S->rounds && i < 24; i++) o += (i % S->rounds == 0 ? " | " : " ") + std::to_string(S->up_flag[i]);
+    else o += " none";
+    return o + "; " + lig_internal_uploader_state(c->device);
+}
+struct ShardDebugScope {
+    lig_ctx* c;
+    ShardDebugScope(lig_shard* S, const char* stage, const uint32_t* rseq) : c(S->c) { lig_internal_set_debug_state(c, [S, stage, rseq] { return shard_debug(S, stage, rseq ? *rseq : 0); }); }
+    ~ShardDebugScope() { lig_internal_set_debug_state(c, nullptr); }
+};
+
 static int shard_stage1(lig_shard* S, lig_proof_info* info) {
     SHARD_COMMON;
+    ShardDebugScope dbg(S, "stage 1", nullptr);
     // ---------------- stage 1
     uint32_t rk[60];
     lig::aes256_expand_host(S->encoding_seed, rk);
@@ -474,6 +491,8 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     SHARD_COMMON;
     auto t0 = clk::now();
     uint32_t rk[60];
+    uint32_t rseq = 0;
+    ShardDebugScope dbg(S, "stages 2-3", &rseq);
 
     // ---------------- stage 2
     const size_t NTl = S->triple_ord.size();
@@ -513,7 +532,6 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     // host rows: the uploader thread fills the double buffer round by round (prover.hip, prove_stage23: same scheme -- arrival and
     // consumption are words in pinned host memory, no copy or event of the transfer in a queue of the proof)
     const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && lig_internal_uploader_available(c) && S->rounds;
-    uint32_t rseq = 0;
     const size_t rflag0 = S->rounds, uflag0 = 2 * S->rounds;
     if (rands_by_thread) {
         TRY(shard_up_flags(S));
