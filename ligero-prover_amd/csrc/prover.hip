@@ -762,6 +762,37 @@ struct Uploader {
     hipStream_t st = nullptr;
     int device = 0;
     bool ok = false;
+    // Rows in PAGEABLE host memory are never handed to hipMemcpyAsync: they go through two page-locked staging buffers of this
+    // thread (host memcpy, then a copy from page-locked memory = a DMA transfer that involves no page locking, no staging pool of
+    // the runtime and no kernel).  Round 5 root cause (profiles/r05_rows_entry_hang.md): with two processes on one GPU,
+    // hipMemcpyAsync of 2.3 MB from pageable memory -- called by this thread while the proof streams of the process held pending
+    // stream waits for exactly this upload -- did not return in ~15 % of the runs (the thread sat inside the call for as long as
+    // anyone waited); the same transfer from page-locked memory has never stalled in 280 runs.  Page-locked sources (lig_host_alloc,
+    // hipHostRegister: what a driver that wants the link rate passes) are copied directly, as before.
+    static constexpr size_t STAGE_BYTES = (size_t)8 << 20;
+    uint8_t* stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    static bool page_locked(const void* p) {
+        hipPointerAttribute_t at;
+        const hipError_t e = hipPointerGetAttributes(&at, p);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }       // unknown to the runtime: ordinary pageable memory
+        return at.type == hipMemoryTypeHost;
+    }
+    hipError_t copy_h2d(uint8_t* dst, const uint8_t* src, size_t bytes) {
+        if (page_locked(src) || !stage[0]) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        int slot = 0;
+        for (size_t off = 0; off < bytes; off += STAGE_BYTES, slot ^= 1) {
+            const size_t nb = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+            if (stage_used[slot]) { const hipError_t e = hipEventSynchronize(stage_free[slot]); if (e != hipSuccess) return e; }
+            std::memcpy(stage[slot], src + off, nb);
+            hipError_t e = hipMemcpyAsync(dst + off, stage[slot], nb, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(stage_free[slot], st);
+            if (e != hipSuccess) return e;
+            stage_used[slot] = true;
+        }
+        return hipSuccess;
+    }
     void run() {
         if (hipSetDevice(device) != hipSuccess) return;
         for (;;) {
@@ -792,9 +823,9 @@ struct Uploader {
             if (!skip && j.first.segs) {
                 for (const UploadSeg& g : *j.first.segs) {
                     if (!g.bytes || e != hipSuccess) continue;
-                    e = g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, st) : hipMemsetAsync(g.dst, 0, g.bytes, st);
+                    e = g.src ? copy_h2d(g.dst, g.src, g.bytes) : hipMemsetAsync(g.dst, 0, g.bytes, st);
                 }
-            } else if (!skip && j.first.bytes) e = hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st);
+            } else if (!skip && j.first.bytes) e = copy_h2d(j.first.dst, j.first.src, j.first.bytes);
             phase.store(2, std::memory_order_release);
             const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
             phase.store(3, std::memory_order_release);
@@ -827,6 +858,11 @@ bool lig_internal_uploader_available(lig_ctx* c) {
         int lo = 0, hi = 0;
         const bool prio = lig::knobs().upload_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
         u->ok = can && (prio ? hipStreamCreateWithPriority(&u->st, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking)) == hipSuccess;
+        if (u->ok)
+            for (int i = 0; i < 2; i++)
+                if (hipHostMalloc((void**)&u->stage[i], Uploader::STAGE_BYTES, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&u->stage_free[i], hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError(); u->stage[0] = nullptr;            // no staging: pageable sources fall back on the runtime's own path
+                }
         if (u->ok) { u->th = std::thread([u] { u->run(); }); u->th.detach(); }
     }
     return u->ok;
