@@ -531,7 +531,8 @@ static int shard_stage23(lig_shard* S, const ShardRands& rs, const uint8_t* cons
     auto rand_buf = [&](size_t cidx) -> fr* { return rs.dev ? const_cast<fr*>(rs.dev) + S->lrow0[cidx] * (size_t)k : S->randb + (cidx & 1) * CAP * (size_t)k; };
     // host rows: the uploader thread fills the double buffer round by round (prover.hip, prove_stage23: same scheme -- arrival and
     // consumption are words in pinned host memory, no copy or event of the transfer in a queue of the proof)
-    const bool rands_by_thread = rs.host && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && lig_internal_uploader_available(c) && S->rounds;
+    // (default off in the sharded entry, see shard_rows_load: event-chained copies on the side stream instead)
+    const bool rands_by_thread = rs.host && lig::knobs().shard_uploader && lig::knobs().upload_mode == 2 && lig::knobs().rands_upload_mode == 2 && lig_internal_uploader_available(c) && S->rounds;
     const size_t rflag0 = S->rounds, uflag0 = 2 * S->rounds;
     if (rands_by_thread) {
         TRY(shard_up_flags(S));
@@ -780,7 +781,12 @@ static int shard_rows_load(lig_shard* S, const void* local_msgs, bool on_device)
     S->rows_by_thread = false;
     if (!S->Rl) return LIG_OK;
     const size_t row_bytes = (size_t)c->k * 32;
-    if (!on_device && lig::knobs().upload_mode == 2 && lig_internal_uploader_available(c)) {
+    // Host rows are copied HERE, synchronously (as in round 3).  Round 4 had moved them onto the library's uploader thread with a stream
+    // memory wait per round (what lig_rows_* does on ONE GPU, where it buys the link rate): with several PROCESSES on one device -- the only
+    // way this entry runs on the one-GPU test box -- a DMA transfer that is started while the process's main stream holds a pending
+    // hipStreamWaitValue32 sometimes never completes (profiles/r05_rows_entry_hang.md: 15 % of the runs, the GPUTEST hang of round 4).
+    // LIG_SHARD_UPLOADER=1 restores the round-4 path (reproduction / a node where every rank has its own GPU).
+    if (!on_device && lig::knobs().shard_uploader && lig::knobs().upload_mode == 2 && lig_internal_uploader_available(c)) {
         TRY(shard_up_flags(S));
         S->up_seq++;
         S->up_abort.store(0, std::memory_order_release);

@@ -82,6 +82,19 @@ def main(trace, budget, f0=0.2, f1=0.8):
            "valu_busy_ms_per_proof_pmc": bud["valu_busy_ms_per_proof"], "issue_slots_used": round(busy_ms / (window / 1e6), 4),
            "idle_ms": round(idle_total, 3), "idle_attributable_to_the_running_mix_ms": round(idle_attr / 1e6, 3),
            "idle_lost_to_contention_ms": round(idle_total - idle_attr / 1e6, 3), "mixes": []}
+    # how much longer every kernel class runs next to the others than alone (the PMC pass serialises dispatches: stand-alone durations):
+    # the contention term, by class -- a class whose launches stretch is one whose waves wait for issue slots, LDS or memory that
+    # another kernel is using
+    conc = {}
+    for s_, e_, k in ev:
+        if e_ <= w0 or s_ >= w1:
+            continue
+        conc[group_of(k)] = conc.get(group_of(k), 0.0) + (min(e_, w1) - max(s_, w0))
+    alone = {}
+    for k, v in bud["kernels"].items():
+        alone[group_of(k)] = alone.get(group_of(k), 0.0) + v["standalone_ms_per_proof"]
+    out["stretch_by_class"] = [{"class": g, "standalone_ms_per_proof": round(alone.get(g, 0.0), 3), "concurrent_ms_per_proof": round(conc.get(g, 0.0) / 1e6 / proofs, 3),
+                                "stretch": round(conc.get(g, 0.0) / 1e6 / proofs / alone[g], 2) if alone.get(g) else None} for g, _ in GROUPS]
     for key, (tm, idle) in sorted(mixes.items(), key=lambda kv: -kv[1][1]):
         if tm / window < 0.01:
             continue

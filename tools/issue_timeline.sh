@@ -11,6 +11,7 @@ c=$(find /tmp/tl_pmc -name "*counter_collection.csv" | head -1); t=$(find /tmp/t
 python tools/valu_budget.py "$c" "$t" > $O/valu_budget.json
 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_tr -o tr -- python bench.py --no-cpu-baseline --no-h2d --no-verify --no-sharded-leg --quad-mix 0 --inflight 2 --steps 20 --warmup 3 > $O/bench_under_trace.json 2> $O/trace.err || true
 t2=$(find /tmp/tl_tr -name "*kernel_trace.csv" | head -1)
+gzip -c "$t2" > $O/kernel_trace.csv.gz
 python tools/issue_timeline.py "$t2" $O/valu_budget.json 0.25 0.85 > $O/issue_timeline.json
 python -c "
 import json; d=json.load(open('$O/issue_timeline.json'))
