@@ -956,25 +956,32 @@ def main():
             e2e = 1054720.0 * (wl.rows + 3) * (total_constraints / wl.constraints_per_trace if hasattr(wl, "constraints_per_trace") else a.steps) / dt / 1e9
             out["roofline"]["hbm_frac_end_to_end"] = e2e / 8000.0
             out["roofline"]["end_to_end_GBps"] = e2e
+        def newest(pattern):
+            """the newest committed profile of that kind (profiles/r0N_<pattern>), None if there is none"""
+            import glob
+            hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+            return hits[-1] if hits else None
+        budget_path = newest("valu_budget.json")
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_valu_lds_full_proof.json")) as f:
-                out["roofline"]["valu_busy_pct"] = {kname: v.get("VALUBusy") for kname, v in json.load(f).get("kernels", {}).items()
-                                                    if v.get("VALUBusy", 0) >= 20}
-                out["roofline"]["valu_busy_source"] = ("profiles/r04_pmc_valu_lds_full_proof.json (rocprofv3 --pmc VALUBusy over full proofs, one in flight; "
-                                                       "a committed measurement of this build, not taken in this run)")
-        except (OSError, ValueError):
+            with open(budget_path) as f:
+                out["roofline"]["valu_busy_pct"] = {kname: v.get("valu_busy_pct") for kname, v in json.load(f).get("kernels", {}).items()
+                                                    if v.get("valu_busy_pct", 0) >= 20}
+                out["roofline"]["valu_busy_source"] = ("profiles/%s (rocprofv3 --pmc VALUBusy --kernel-trace over full proofs, one in flight, dispatches serialised; "
+                                                       "a committed measurement, not taken in this run)" % os.path.basename(budget_path))
+        except (OSError, ValueError, TypeError):
             pass
         if a.workload == "full":
             # chip-wide: the VALU issue time ONE proof needs (sum over all its launches of stand-alone duration x VALUBusy, a committed PMC
             # pass of this build: tools/valu_budget.sh) against the time the bench takes per proof -- the fraction of issue slots in use
             try:
-                with open(os.path.join(ROOT, "profiles", "r04_valu_budget.json")) as f:
+                with open(budget_path) as f:
                     busy_ms = json.load(f)["valu_busy_ms_per_proof"]
                 ms_per_proof = 1e3 * dt / a.steps / max(1, getattr(wl, "inflight", 1))
                 out["roofline"]["valu_issue"] = {"busy_ms_per_proof": busy_ms, "measured_ms_per_proof": ms_per_proof, "frac": busy_ms / ms_per_proof,
-                                                 "source": "profiles/r04_valu_budget.json (rocprofv3 --pmc VALUBusy --kernel-trace over full proofs of this build; "
-                                                           "a committed measurement, not taken in this run), see profiles/r03_valu_budget.md (method) and DESIGN.md section 4"}
-            except (OSError, ValueError, KeyError):
+                                                 "source": "profiles/%s (rocprofv3 --pmc VALUBusy --kernel-trace over full proofs; a committed measurement, not taken in "
+                                                           "this run), see profiles/r03_valu_budget.md (method), profiles/r05_issue_timeline.md (where the idle slots are) "
+                                                           "and DESIGN.md section 4" % os.path.basename(budget_path)}
+            except (OSError, ValueError, KeyError, TypeError):
                 pass
         out["value_definition"] = ("witness matrix resident in HBM when the clock starts (the measurement contract this build is judged by reserves `value` for "
                                    "inputs resident in HBM; a PCIe-inclusive rate is reported beside it, never as `value`); SURVEY 8(d)'s H2D-inclusive figure is "

@@ -406,10 +406,10 @@ void lig_shard_destroy(lig_shard *shard);
  * lig_rows_prove on the whole trace.  Replaces the per-row callbacks of include/zkp/nonbatch_context.hpp:445-471, :654-780,
  * :924-970 when the rows of one trace live on several GPUs.
  * The sharded entry takes full-width rows only: job->elem_bytes must be NULL (LIG_E_ARG otherwise).
- * LIFETIME: local rows in HOST memory (msgs_on_device == 0) are uploaded asynchronously by the library's uploader thread, chunk by
- * chunk under the encodes: the memory passed to lig_shard_rows_begin / lig_shard_rows_restart must stay valid and unchanged until
- * lig_shard_rows_commit (or lig_shard_destroy) has returned.  Device rows are copied before the call returns.  Randomness rows
- * passed to lig_shard_rows_prove are consumed before it returns.
+ * LIFETIME: the local rows passed to lig_shard_rows_begin / lig_shard_rows_restart (host or device memory) are copied before the call
+ * returns; randomness rows passed to lig_shard_rows_prove are consumed before it returns.  (Only with LIG_SHARD_UPLOADER=1 -- the round-4
+ * path through the library's uploader thread, off by default: profiles/r05_rows_entry_hang.md -- host rows are read until
+ * lig_shard_rows_commit has returned.)
  * FAILURE: a peer that dies, leaves or stops responding makes these calls return LIG_E_STATE (lig_comm.failed / .abort), they do not hang. ==== */
 int lig_shard_rows_plan(const uint8_t *kinds, size_t n_rows, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
 int lig_shard_rows_begin(lig_ctx *ctx, const lig_rows_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);

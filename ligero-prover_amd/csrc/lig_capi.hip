@@ -320,6 +320,7 @@ const lig::Knobs& lig::knobs() {
         t.rands_upload_mode = (int)num("LIG_RANDS_UPLOAD_MODE", 2);
         t.upload_prio = num("LIG_UPLOAD_PRIO", 1) != 0;
         t.shard_uploader = num("LIG_SHARD_UPLOADER", 0) != 0;
+        t.upload_timeout_s = (int)pos("LIG_UPLOAD_TIMEOUT_S", 60);
         t.d2h_kernel = num("LIG_D2H_KERNEL", 1) != 0;
         t.shard_force_exchange = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
         t.trace = std::getenv("LIG_TRACE") != nullptr;

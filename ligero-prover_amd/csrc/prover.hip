@@ -755,6 +755,7 @@ namespace {
 struct Uploader {
     std::atomic<uint64_t> cur_bytes{0}, cur_since_us{0}, done_jobs{0};      // diagnostics
     std::atomic<int> phase{0};                                              // 0 idle, 1 copy call, 2 waiting for the copy, 3 publishing
+    std::atomic<bool> broken{false};                                        // a transfer timed out: no further jobs
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<UploadJob, std::atomic<int>*>> q;
@@ -762,37 +763,6 @@ struct Uploader {
     hipStream_t st = nullptr;
     int device = 0;
     bool ok = false;
-    // Rows in PAGEABLE host memory are never handed to hipMemcpyAsync: they go through two page-locked staging buffers of this
-    // thread (host memcpy, then a copy from page-locked memory = a DMA transfer that involves no page locking, no staging pool of
-    // the runtime and no kernel).  Round 5 root cause (profiles/r05_rows_entry_hang.md): with two processes on one GPU,
-    // hipMemcpyAsync of 2.3 MB from pageable memory -- called by this thread while the proof streams of the process held pending
-    // stream waits for exactly this upload -- did not return in ~15 % of the runs (the thread sat inside the call for as long as
-    // anyone waited); the same transfer from page-locked memory has never stalled in 280 runs.  Page-locked sources (lig_host_alloc,
-    // hipHostRegister: what a driver that wants the link rate passes) are copied directly, as before.
-    static constexpr size_t STAGE_BYTES = (size_t)8 << 20;
-    uint8_t* stage[2] = {nullptr, nullptr};
-    hipEvent_t stage_free[2] = {nullptr, nullptr};
-    bool stage_used[2] = {false, false};
-    static bool page_locked(const void* p) {
-        hipPointerAttribute_t at;
-        const hipError_t e = hipPointerGetAttributes(&at, p);
-        if (e != hipSuccess) { (void)hipGetLastError(); return false; }       // unknown to the runtime: ordinary pageable memory
-        return at.type == hipMemoryTypeHost;
-    }
-    hipError_t copy_h2d(uint8_t* dst, const uint8_t* src, size_t bytes) {
-        if (page_locked(src) || !stage[0]) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-        int slot = 0;
-        for (size_t off = 0; off < bytes; off += STAGE_BYTES, slot ^= 1) {
-            const size_t nb = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
-            if (stage_used[slot]) { const hipError_t e = hipEventSynchronize(stage_free[slot]); if (e != hipSuccess) return e; }
-            std::memcpy(stage[slot], src + off, nb);
-            hipError_t e = hipMemcpyAsync(dst + off, stage[slot], nb, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipEventRecord(stage_free[slot], st);
-            if (e != hipSuccess) return e;
-            stage_used[slot] = true;
-        }
-        return hipSuccess;
-    }
     void run() {
         if (hipSetDevice(device) != hipSuccess) return;
         for (;;) {
@@ -815,19 +785,35 @@ struct Uploader {
                     else cv.wait_for(lk, std::chrono::microseconds(20));       // every queued job waits for the GPU: poll
                 }
             }
-            const bool skip = j.first.abort && j.first.abort->load(std::memory_order_acquire);
+            const bool dead = broken.load(std::memory_order_acquire);             // jobs queued behind a transfer that timed out fail at once
+            const bool skip = dead || (j.first.abort && j.first.abort->load(std::memory_order_acquire));
             cur_bytes.store(j.first.bytes, std::memory_order_relaxed);
             cur_since_us.store((uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(clk::now().time_since_epoch()).count(), std::memory_order_relaxed);
             phase.store(1, std::memory_order_release);
-            hipError_t e = hipSuccess;
+            hipError_t e = dead ? hipErrorLaunchTimeOut : hipSuccess;
             if (!skip && j.first.segs) {
                 for (const UploadSeg& g : *j.first.segs) {
                     if (!g.bytes || e != hipSuccess) continue;
-                    e = g.src ? copy_h2d(g.dst, g.src, g.bytes) : hipMemsetAsync(g.dst, 0, g.bytes, st);
+                    e = g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, st) : hipMemsetAsync(g.dst, 0, g.bytes, st);
                 }
-            } else if (!skip && j.first.bytes) e = copy_h2d(j.first.dst, j.first.src, j.first.bytes);
+            } else if (!skip && j.first.bytes) e = hipMemcpyAsync(j.first.dst, j.first.src, j.first.bytes, hipMemcpyHostToDevice, st);
             phase.store(2, std::memory_order_release);
-            const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
+            // bounded: a transfer that does not complete (seen with several processes on one GPU, profiles/r05_rows_entry_hang.md) must
+            // not hang every stream that waits for its word -- after LIG_UPLOAD_TIMEOUT_S the job is reported as failed (the word is
+            // published, lig_rows_commit / _prove return LIG_E_HIP once their streams have drained) and this thread takes no more jobs:
+            // callers fall back on stream-ordered copies (lig_internal_uploader_available turns false)
+            hipError_t e2 = e;
+            if (e == hipSuccess) {
+                const auto t_wait = clk::now();
+                const double limit = (double)lig::knobs().upload_timeout_s;
+                for (unsigned spins = 0;; spins++) {
+                    e2 = hipStreamQuery(st);
+                    if (e2 != hipErrorNotReady) break;
+                    if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    if ((spins & 1023) == 1023 && std::chrono::duration<double>(clk::now() - t_wait).count() > limit) { e2 = hipErrorLaunchTimeOut; broken.store(true, std::memory_order_release); break; }
+                }
+                if (e2 == hipErrorNotReady) e2 = hipSuccess;
+            }
             phase.store(3, std::memory_order_release);
             // (a failed copy publishes too: no stream may hang on the flag; lig_rows_commit reports the error once stage 1 has drained)
             if (e2 != hipSuccess) { (void)hipGetLastError(); j.first.failed->store((int)e2, std::memory_order_release); }
@@ -853,19 +839,15 @@ bool lig_internal_uploader_available(lig_ctx* c) {
         // The uploader's stream must not share a HARDWARE queue with a stream that may hold a pending hipStreamWaitValue32 for the word this
         // thread publishes: HIP maps the streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues per priority class, a pending stream
         // wait occupies its queue, and a small host-to-device copy is a blit KERNEL in the copying stream's queue (tools/queue_share_probe.hip,
-        // profiles/r05_queue_share_probe.txt) -- behind the wait it would never run: the hang of the sharded rows entry in round 4.  Queues are
-        // pooled per priority class, the library's proof streams are normal priority: the uploader takes the highest.
+        // profiles/r05_queue_share_probe.txt) -- behind the wait it would never run.  (A latent deadlock found while hunting the round-4 hang
+        // of the sharded rows entry; not its cause, profiles/r05_rows_entry_hang.md.)  Queues are pooled per priority class, the library's
+        // proof streams are normal priority: the uploader takes the highest.
         int lo = 0, hi = 0;
         const bool prio = lig::knobs().upload_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
         u->ok = can && (prio ? hipStreamCreateWithPriority(&u->st, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking)) == hipSuccess;
-        if (u->ok)
-            for (int i = 0; i < 2; i++)
-                if (hipHostMalloc((void**)&u->stage[i], Uploader::STAGE_BYTES, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&u->stage_free[i], hipEventDisableTiming) != hipSuccess) {
-                    (void)hipGetLastError(); u->stage[0] = nullptr;            // no staging: pageable sources fall back on the runtime's own path
-                }
         if (u->ok) { u->th = std::thread([u] { u->run(); }); u->th.detach(); }
     }
-    return u->ok;
+    return u->ok && !u->broken.load(std::memory_order_acquire);
 }
 }  // extern "C"
 std::string lig_internal_uploader_state(int device) {
