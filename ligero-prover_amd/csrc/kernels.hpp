@@ -32,6 +32,8 @@ struct Knobs {
     int      upload_timeout_s = 60;    // LIG_UPLOAD_TIMEOUT_S  uploader thread: seconds after which a transfer that has not completed is reported as failed
     bool     shard_uploader = false;   // LIG_SHARD_UPLOADER=1  lig_shard_rows_*: host rows / randomness rows through the uploader thread + stream waits (round 4; hangs with several processes per GPU)
     int      rands_upload_mode = 2;    // LIG_RANDS_UPLOAD_MODE  caller randomness rows from host: 2 uploader thread, 1: event-chained copies on the side stream (round 3)
+    bool     spin_wait = true;         // LIG_SPIN_WAIT=0    the proof's host waits block in the runtime instead of polling
+    int      spin_wait_ms = 50;        // LIG_SPIN_WAIT_MS   polling gives way to the blocking wait after this long
     bool     d2h_kernel = true;        // LIG_D2H_KERNEL=0   proof downloads by hipMemcpyAsync instead of copy kernels
     bool     shard_force_exchange = false;   // LIG_SHARD_FORCE_EXCHANGE  pack + all-to-all with one rank too (tests)
     bool     trace = false;            // LIG_TRACE          synchronised phase timeline on stderr

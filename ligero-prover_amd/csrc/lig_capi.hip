@@ -322,6 +322,8 @@ const lig::Knobs& lig::knobs() {
         t.shard_uploader = num("LIG_SHARD_UPLOADER", 0) != 0;
         t.upload_timeout_s = (int)pos("LIG_UPLOAD_TIMEOUT_S", 60);
         t.d2h_kernel = num("LIG_D2H_KERNEL", 1) != 0;
+        t.spin_wait = num("LIG_SPIN_WAIT", 1) != 0;
+        t.spin_wait_ms = (int)pos("LIG_SPIN_WAIT_MS", 50);
         t.shard_force_exchange = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
         t.trace = std::getenv("LIG_TRACE") != nullptr;
         t.fault_comm = (int)num("LIG_FAULT_COMM", 0);

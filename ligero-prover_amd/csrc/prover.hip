@@ -103,6 +103,30 @@ struct lig_trace {
     uint8_t* h_small = nullptr;                            // pinned: the device-side sum (32 B) | 3 decoded accumulators (3 x n x 32)
 };
 
+// Host waits of a proof (root of stage 1, the three accumulators, the decodes, the envelope).  The runtime's blocking waits sleep on an
+// interrupt: every wake-up costs tens of microseconds during which the GPU has nothing of this proof to run.  LIG_SPIN_WAIT=1 (default)
+// polls instead (the calling thread yields between polls for LIG_SPIN_WAIT_MS, then falls back on the blocking wait): A/B in
+// profiles/r05_spin_wait_ab.md.
+static hipError_t wait_stream(hipStream_t st) {
+    if (!lig::knobs().spin_wait) return hipStreamSynchronize(st);
+    const auto t0 = clk::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::yield();
+        if ((spins & 255) == 255 && ms_since(t0) > (double)lig::knobs().spin_wait_ms) return hipStreamSynchronize(st);
+    }
+}
+static hipError_t wait_event(hipEvent_t ev) {
+    if (!lig::knobs().spin_wait) return hipEventSynchronize(ev);
+    const auto t0 = clk::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::yield();
+        if ((spins & 255) == 255 && ms_since(t0) > (double)lig::knobs().spin_wait_ms) return hipEventSynchronize(ev);
+    }
+}
 static void uploader_drain(lig_trace* T);      // (below, with the uploader thread)
 static void rand_drain(lig_trace* T);
 static int ensure_up_flags(lig_ctx* c, lig_trace* T);
@@ -371,7 +395,7 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     lig::launch_sha_final(s, T->sha_state, n, absorbed, leaf_level, k);      // plane-major instances -> leaves in column order, written in place
     TRY(lig_merkle_build(c, leaf_level, n, T->nodes));
     TRY(lig_internal_download(c, T->h_nodes, T->nodes, 32, s));              // the root now ...
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(s));
     if (streamed && T->up_by_thread) {
         // every chunk has been waited for by now; a copy the uploader thread could not make leaves garbage rows behind
         if (const int e = T->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("rows upload failed: ") + hipGetErrorString((hipError_t)e));
@@ -586,7 +610,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         Sha256 h2;
         h2.add("LigetronStage2", 15).add(info->root, 32);
         for (int a3 = 0; a3 < 3; a3++) {
-            HIP_TRY(c, hipEventSynchronize(T->ev_acc[a3]));
+            HIP_TRY(c, wait_event(T->ev_acc[a3]));
             h2.add(enc + (size_t)a3 * vec_bytes, vec_bytes);
         }
         h2.finish(info->stage2_seed);
@@ -617,7 +641,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     if (lay.total > T->h_proof_cap) FAIL(c, LIG_E_NOMEM, "proof buffer too small");
     TRY(lig_internal_download(c, T->h_proof + lay.samples_off, T->samples, smp_bytes, s));   // opened columns land in place (any byte offset)
     for (int a3 = 0; a3 < 3; a3++) std::memcpy(T->h_proof + lay.vec_off[a3], enc + (size_t)a3 * vec_bytes, vec_bytes);     // 3 MiB, under the 13 MB download
-    HIP_TRY(c, hipEventSynchronize(c->ev_join));          // decoded accumulators are on the host
+    HIP_TRY(c, wait_event(c->ev_join));          // decoded accumulators are on the host
     auto is_zero = [](const H::Fr& v) { return !(v.v[0] | v.v[1] | v.v[2] | v.v[3]); };
     info->valid_code = 1;
     for (uint32_t i = k; i < n; i++) if (!is_zero(dec[i])) info->valid_code = 0;
@@ -629,7 +653,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     }
     info->valid_quad = 1;
     for (uint32_t i = 0; i < l; i++) if (!is_zero(dec[2 * (size_t)n + i])) info->valid_quad = 0;
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, wait_stream(s));
     *proof = T->h_proof;
     *proof_len = lay.total;
     mark("serialize");

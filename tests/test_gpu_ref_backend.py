@@ -112,3 +112,46 @@ def test_rows_entry_on_the_reference_backends_row_stream(amd, name, pads):
         assert [v.valid_merkle, v.valid_code, v.valid_linear, v.valid_quad, v.code_equal, v.linear_equal, v.quad_equal, v.accept] == [1] * 8
     finally:
         c.close()
+
+
+SHARDED_REF_WORKER = '''
+import hashlib, importlib.util, json, os, sys
+import numpy as np
+root, name = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.join(root, "tests"))
+def load(mod, rel):
+    spec = importlib.util.spec_from_file_location(mod, os.path.join(root, "ligero-prover_amd", rel))
+    m = importlib.util.module_from_spec(spec); sys.modules[mod] = m; spec.loader.exec_module(m); return m
+pkg = load("ligero_prover_amd", "__init__.py")
+dist = load("lig_dist", "dist.py")
+z = np.load(os.path.join(root, "tests", "golden", "ref_rows_%s.npz" % name))
+m = json.loads(str(z["meta"]))
+g = dist.Group("gloo")
+ctx = pkg.Context(m["l"], m["k"], m["n"], device=0)
+kinds, vals, rands = z["kinds"], z["vals"], z["rands"]
+rounds, b = pkg.shard_rows_plan(kinds, g.world)
+mine = pkg.local_rows_of(b, g.rank, g.world)
+comm = g.make_comm(pkg, ctx)
+sh = ctx.shard_rows_begin(kinds, vals[mine] if len(mine) else np.zeros((0, m["k"], 8), np.uint32), g.rank, g.world, comm,
+                          encoding_seed=bytes.fromhex(m["encoding_seed"]), generated_at=m["generated_at"])
+root_, seed1 = ctx.shard_rows_commit(sh)
+proof, info = ctx.shard_rows_prove(sh, rands[mine] if len(mine) else np.zeros((0, m["k"], 8), np.uint32), z["constsum"].tobytes())
+ctx.shard_destroy(sh)
+print(json.dumps({"rank": g.rank, "local": len(mine), "root": root_.hex(), "seed1": seed1.hex(), "sha": hashlib.sha256(proof).hexdigest(),
+                  "valid": [info.valid_code, info.valid_linear, info.valid_quad]}))
+g.close(); ctx.close()
+'''
+
+
+@pytest.mark.parametrize("name,world", [("i32_add_320", 2), ("mul_add_320", 4)])
+def test_reference_row_stream_sharded_over_ranks(tmp_path, name, world):
+    """the reference backend's row stream (configs[0]; real callback order: triples and linear rows interleaved) as ONE trace over W ranks
+    (processes on the one GPU, comm_ipc): every rank's envelope is the one the oracle computes from the unsharded stream"""
+    import multirank as mr
+    m = load_rows(name)["meta"]
+    script = tmp_path / "sharded_ref_worker.py"
+    script.write_text(SHARDED_REF_WORKER)
+    outs = [mr.last_json(o) for o, _ in mr.run_ranks(mr.python_argv(script, os.path.dirname(os.path.dirname(GOLD)), name), world, mr.rendezvous_env(world, "ipc"))]
+    assert sorted(o["rank"] for o in outs) == list(range(world)) and sum(o["local"] for o in outs) == m["rows"]
+    for o in outs:
+        assert o["valid"] == [1, 1, 1] and o["root"] == m["oracle_root"] and o["seed1"] == m["oracle_stage1_seed"] and o["sha"] == m["oracle_proof_sha256"], o
