@@ -29,6 +29,7 @@ struct Knobs {
     bool     early_code = true;        // LIG_EARLY_CODE=0   accumulate the code test inside the row loop
     int      upload_mode = 2;          // LIG_UPLOAD_MODE    2: uploader thread, 1: per-context copy stream + events
     bool     upload_prio = true;       // LIG_UPLOAD_PRIO=0  the uploader thread's stream at normal priority (shares the proof streams' hardware-queue pool: A/B only)
+    bool     fault_upload = false;     // LIG_FAULT_UPLOAD   tests: the uploader thread's first transfer never completes (exercises LIG_UPLOAD_TIMEOUT_S)
     int      upload_timeout_s = 60;    // LIG_UPLOAD_TIMEOUT_S  uploader thread: seconds after which a transfer that has not completed is reported as failed
     bool     shard_uploader = false;   // LIG_SHARD_UPLOADER=1  lig_shard_rows_*: host rows / randomness rows through the uploader thread + stream waits (round 4; hangs with several processes per GPU)
     int      rands_upload_mode = 2;    // LIG_RANDS_UPLOAD_MODE  caller randomness rows from host: 2 uploader thread, 1: event-chained copies on the side stream (round 3)

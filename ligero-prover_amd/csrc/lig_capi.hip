@@ -324,6 +324,7 @@ const lig::Knobs& lig::knobs() {
         t.upload_prio = num("LIG_UPLOAD_PRIO", 1) != 0;
         t.shard_uploader = num("LIG_SHARD_UPLOADER", 0) != 0;
         t.upload_timeout_s = (int)pos("LIG_UPLOAD_TIMEOUT_S", 60);
+        t.fault_upload = num("LIG_FAULT_UPLOAD", 0) != 0;
         t.d2h_kernel = num("LIG_D2H_KERNEL", 1) != 0;
         t.spin_wait = num("LIG_SPIN_WAIT", 1) != 0;
         t.spin_wait_ms = (int)pos("LIG_SPIN_WAIT_MS", 50);

@@ -827,11 +827,12 @@ struct Uploader {
             // published, lig_rows_commit / _prove return LIG_E_HIP once their streams have drained) and this thread takes no more jobs:
             // callers fall back on stream-ordered copies (lig_internal_uploader_available turns false)
             hipError_t e2 = e;
+            const bool injected = lig::knobs().fault_upload && !skip && done_jobs.load() == 0;      // tests (LIG_FAULT_UPLOAD): the first transfer "never completes"
             if (e == hipSuccess) {
                 const auto t_wait = clk::now();
                 const double limit = (double)lig::knobs().upload_timeout_s;
                 for (unsigned spins = 0;; spins++) {
-                    e2 = hipStreamQuery(st);
+                    e2 = injected ? hipErrorNotReady : hipStreamQuery(st);
                     if (e2 != hipErrorNotReady) break;
                     if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
                     if ((spins & 1023) == 1023 && std::chrono::duration<double>(clk::now() - t_wait).count() > limit) { e2 = hipErrorLaunchTimeOut; broken.store(true, std::memory_order_release); break; }

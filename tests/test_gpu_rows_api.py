@@ -410,3 +410,51 @@ def test_rows_push_rands_sparse_ships_only_rows_that_have_randomness(amd):
         c.host_free(ptr)
     finally:
         c.close()
+
+
+def test_a_transfer_that_never_completes_is_an_error_not_a_hang(tmp_path):
+    """round 5: the uploader thread bounds its wait for a host-to-device transfer (LIG_UPLOAD_TIMEOUT_S).  With the first transfer made to
+    "never complete" (LIG_FAULT_UPLOAD) lig_rows_commit returns an error within seconds -- the streams that wait for the rows' arrival word
+    are released -- and the next proof of the process, its uploads on stream-ordered copies from then on, equals the oracle's"""
+    import subprocess
+    import sys
+    import textwrap
+    script = tmp_path / "stuck_upload.py"
+    script.write_text(textwrap.dedent('''
+        import ctypes as C, json, os, sys, time
+        root = sys.argv[1]
+        sys.path.insert(0, os.path.join(root, "tests"))
+        import hip_lib, oracle_lib as ol
+        amd = hip_lib.load()
+        l, k, n = 320, 512, 2048
+        job = ol.make_job(l, k, n, 192, 320 * 300 + 7, 330, generated_at=9, threads=4)
+        pr = ol.Proof()
+        assert ol.lib().lo_prove(C.byref(job), C.byref(pr)) == 0
+        want = bytes(pr.proof[:pr.proof_len])
+        rows, _, _, _ = ol.form_rows(job)
+        kinds = ol.row_kinds(job).copy()
+        c = amd.Context(l, k, n)
+        out = {}
+        t0 = time.time()
+        tr, keep = c.rows_begin(kinds, rows, generated_at=9)
+        try:
+            c.rows_commit(tr)
+            out["first"] = "no error"
+        except amd.LigError as e:
+            out["first"] = str(e)
+        out["seconds"] = time.time() - t0
+        c.trace_destroy(tr)
+        tr, keep = c.rows_begin(kinds, rows, generated_at=9)           # the uploader is out of service: stream-ordered copies
+        root_, seed1 = c.rows_commit(tr)
+        rands, cs = ol.rand_rows(job, seed1)
+        proof, info = c.rows_prove(tr, rands, cs)
+        out["second_equals_oracle"] = proof == want
+        c.trace_destroy(tr); c.close()
+        print(json.dumps(out))
+    '''))
+    p = subprocess.run([sys.executable, str(script), os.path.dirname(os.path.dirname(GOLD))], env=dict(os.environ, LIG_FAULT_UPLOAD="1", LIG_UPLOAD_TIMEOUT_S="2"),
+                       capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert "upload failed" in out["first"] and out["seconds"] < 20, out
+    assert out["second_equals_oracle"] is True, out
