@@ -1027,6 +1027,10 @@ def main():
             sh["attempts"] = attempts
             sh["answers"] = ("strong scaling of ONE trace (north_star's '>= 6x further at 8 GPUs' read as latency of one proof); the per-column hash chain does "
                              "not shorten with W, see DESIGN.md section 7 for the per-W prediction; `value` above (independent traces) is the throughput answer")
+            # so that a run on a real node cannot be mistaken for this box's stand-ins: how many DEVICES the ranks had
+            sh["devices"] = {"distinct": bool(pre.get("distinct_devices")), "pci_bus_ids": pre.get("pci_bus_ids"),
+                             "note": "ranks on distinct GPUs" if pre.get("distinct_devices") else "ALL ranks shared one GPU (test stand-in: no xGMI link carried anything)"}
+            out["answers"] = {"value": "throughput: independent traces, one per GPU, no collective (weak scaling)", "sharded": sh["answers"]}
             out["sharded"] = sh
             for lg in sizes:
                 if lg != main_size:

@@ -236,6 +236,8 @@ def test_bench_py_gpus_2_on_one_gpu_runs_the_sharded_leg_with_real_peers(tmp_pat
     assert out["sharded_2p22"]["all_ranks_same_envelope"] is True and out["sharded_2p22"]["ranks"] == 2
     pre = out["preflight"]
     assert len(pre["pci_bus_ids"]) == 2 and pre["distinct_devices"] is False         # (both ranks share the one device here, and the line says so)
+    assert sh["devices"]["distinct"] is False and "shared one GPU" in sh["devices"]["note"] and sh.get("rccl_ranks") in (None, 0)
+    assert set(out["answers"]) == {"value", "sharded"} and "weak" in out["answers"]["value"] and "ONE trace" in out["answers"]["sharded"]
     assert pre["hsa_enable_ipc_mode_legacy"] == "0" and pre["rccl"]["available"] is True
 
 
