@@ -370,6 +370,7 @@ struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
 // what a watchdog prints when it declares the communicator dead while a sharded call is in progress
 static std::string shard_debug(lig_shard* S, const char* stage, uint32_t rseq) {
     lig_ctx* c = S->c;
+    (void)hipSetDevice(c->device);                  // (called from a communicator's watchdog thread)
     auto q = [](hipStream_t st) { const hipError_t e = hipStreamQuery(st); (void)hipGetLastError(); return e == hipSuccess ? "drained" : e == hipErrorNotReady ? "BUSY" : "error"; };
     std::string o = std::string("[lig_shard] rank ") + std::to_string(S->rank) + " in " + stage + ": streams main " + q(c->stream) + ", side " + q(c->stream2) + ", copy " + q(c->stream3);
     o += "; rows upload seq " + std::to_string(S->up_seq) + ", randomness seq " + std::to_string(rseq) + ", pending " + std::to_string(S->up_pending.load()) + ", flag words [arrived rows | arrived rands | consumed]:";
