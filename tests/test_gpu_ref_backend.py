@@ -155,3 +155,44 @@ def test_reference_row_stream_sharded_over_ranks(tmp_path, name, world):
     assert sorted(o["rank"] for o in outs) == list(range(world)) and sum(o["local"] for o in outs) == m["rows"]
     for o in outs:
         assert o["valid"] == [1, 1, 1] and o["root"] == m["oracle_root"] and o["seed1"] == m["oracle_stage1_seed"] and o["sha"] == m["oracle_proof_sha256"], o
+
+
+def test_live_reference_row_former_feeds_the_hip_prover_at_configs1_scale(amd):
+    """oracle/_ref/libref_backend.so travels with the snapshot (built in the build container from the reference's own sources): the reference's
+    witness_manager + ligetron_backend form a 200-row stream at k = 8192 (400 000 multiply-add constraints with constants: 50 linear rows and
+    50 quadratic triples in the real emission order) ON THIS BOX, the HIP rows entry commits to it, the reference's stage-2 replay -- keyed by
+    the seed the HIP path produced -- delivers the randomness rows and constsum(), and the envelope must be the oracle's over the same stream.
+    No fixture in between: reference row former -> HIP prover -> HIP verifier."""
+    import ref_backend_lib as rb
+    if rb.load() is None:
+        pytest.skip("oracle/_ref/libref_backend.so is not present on this box")
+    l, k, n, t, reps, gen = 8000, 8192, 32768, 192, 400000, 21
+    key = bytes(range(32))
+    g1 = rb.guest("mul_add", l, k, key, reps=reps)
+    kinds, vals = g1["kinds"], g1["vals"]
+    assert len(kinds) == 200 and np.bincount(kinds).tolist() == [50, 50, 50, 50] and not g1["rands"].any()
+    c = amd.Context(l, k, n)
+    try:
+        tr, keep = c.rows_begin(kinds, vals, encoding_seed=key, generated_at=gen)
+        root, seed1 = c.rows_commit(tr)
+        g2 = rb.guest("mul_add", l, k, key, wit_key=seed1, reps=reps)            # the reference's own stage-2 run of the guest
+        assert np.array_equal(g2["vals"], vals) and np.array_equal(g2["kinds"], kinds)
+        proof, info = c.rows_prove(tr, g2["rands"], g2["constsum"])
+        assert [info.valid_code, info.valid_linear, info.valid_quad] == [1, 1, 1]
+        c.trace_destroy(tr)
+        want = ol.prove_rows(l, k, n, t, kinds, vals, g1["mask_code"], g1["mask_lin"], g1["mask_quad"], g2["rands"], g2["constsum"], generated_at=gen, threads=8)
+        assert want["root"] == root and want["stage1_seed"] == seed1 and want["valid"] == [1, 1, 1]
+        assert proof == want["proof"]
+        vt, vseed, vinfo = c.rows_verify_begin(kinds, proof)
+        assert vt is not None and vseed == seed1
+        v = c.rows_verify_finish(vt, g2["rands"], g2["constsum"])
+        assert v.accept == 1
+        # the same rows with the pads wiped and drawn by the library: the device sampler at the positions the emission order implies
+        wiped = vals.copy()
+        wiped[:, l:] = 0xA5A5A5A5
+        tr, keep = c.rows_begin(kinds | amd.ROW_DRAW_PAD, wiped, encoding_seed=key, generated_at=gen)
+        root2, seed2 = c.rows_commit(tr)
+        assert root2 == root and seed2 == seed1
+        c.trace_destroy(tr)
+    finally:
+        c.close()
