@@ -129,6 +129,7 @@ namespace {
 
 struct stage1_policy { static constexpr bool pad_encoding_random = true, enable_code_check = false, enable_linear_check = false, enable_quadratic_check = false; };   // nonbatch_context.hpp:39-44
 struct stage2_policy { static constexpr bool pad_encoding_random = true, enable_code_check = true, enable_linear_check = true, enable_quadratic_check = true; };      // :46-51
+struct verifier_policy { static constexpr bool pad_encoding_random = false, enable_code_check = true, enable_linear_check = true, enable_quadratic_check = true; };   // :60-65
 
 struct Recording {
     size_t k = 0;
@@ -293,10 +294,13 @@ Recording* run_guest(int which, size_t l, size_t k, const uint8_t enc_key[32], c
 
 extern "C" {
 
-// stage2 == 0: the stage-1 policy (rows, pads, masks).  stage2 != 0: the stage-2 policy with the three witness engines keyed by `wit_key`
-// (= the stage-1 seed): the same rows plus every row's randomness row and the constant sum.  Returns NULL on a guest error.
+// stage2 == 0: the stage-1 policy (rows, pads, masks).  stage2 == 1: the stage-2 policy with the three witness engines keyed by `wit_key`
+// (= the stage-1 seed): the same rows plus every row's randomness row and the constant sum.  stage2 == 2: the VERIFIER's policy
+// (nonbatch_context.hpp:60-65: no pads drawn, all checks on) -- the public data the verifier derives by running the guest itself.
+// Returns NULL on a guest error.
 void* ref_guest_run(int which, uint64_t l, uint64_t k, const uint8_t enc_key[32], const uint8_t* wit_key, int stage2, uint64_t reps) {
     try {
+        if (stage2 == 2) return run_guest<verifier_policy>(which, l, k, enc_key, wit_key, reps);
         return stage2 ? run_guest<stage2_policy>(which, l, k, enc_key, wit_key, reps) : run_guest<stage1_policy>(which, l, k, enc_key, nullptr, reps);
     } catch (const std::exception& e) {
         std::cerr << "ref_guest_run: " << e.what() << std::endl;

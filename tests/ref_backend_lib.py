@@ -89,11 +89,11 @@ def limbs_roundtrip(data, count, limb_size, limb_count, out_limb_size, out_limb_
 GUESTS = dict(i32_add=0, mul_add=1)
 
 
-def guest(which, l, k, enc_key, wit_key=None, reps=0):
+def guest(which, l, k, enc_key, wit_key=None, reps=0, verifier=False):
     """the row stream the reference's witness_manager emits for a guest: stage-1 policy (wit_key None) or stage-2 policy.
     -> dict(kinds (R,), vals (R,k,8), rands (R,k,8), mask_code (k,8), mask_lin (2k,8), mask_quad (2k,8), constsum bytes)"""
     L = load()
-    h = L.ref_guest_run(GUESTS[which], l, k, bytes(enc_key), bytes(wit_key) if wit_key is not None else None, int(wit_key is not None), reps)
+    h = L.ref_guest_run(GUESTS[which], l, k, bytes(enc_key), bytes(wit_key) if wit_key is not None else None, (2 if verifier else 1) if wit_key is not None else 0, reps)
     if not h:
         raise RuntimeError("the reference guest failed")
     try:

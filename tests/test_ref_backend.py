@@ -227,3 +227,15 @@ def test_live_field_operations_on_random_operands():
         w = [np.zeros(8, dtype=np.uint32) for _ in range(3)]
         ol.lib().lo_omegas(k, *[ol.ptr(x) for x in w])
         assert np.array_equal(rb.omegas(k), np.stack(w))
+
+
+@live
+def test_live_verifier_policy_derives_the_provers_public_data():
+    """the reference's verifier runs the guest itself (verifier_random_policy: no pads, all checks on) to obtain the per-row randomness rows and
+    the constant sum it checks the proof against; they must be the ones the prover's stage-2 run produced -- the inputs of lig_rows_verify_*"""
+    key, seed1 = bytes(range(32)), hashlib.sha256(b"some stage-1 seed").digest()
+    for which, l, k, reps in (("i32_add", 320, 512, 0), ("mul_add", 320, 512, 700)):
+        p = rb.guest(which, l, k, key, wit_key=seed1, reps=reps)
+        v = rb.guest(which, l, k, key, wit_key=seed1, reps=reps, verifier=True)
+        assert np.array_equal(p["kinds"], v["kinds"]) and np.array_equal(p["rands"], v["rands"]) and p["constsum"] == v["constsum"]
+        assert np.array_equal(p["vals"][:, :l], v["vals"][:, :l]) and not v["vals"][:, l:].any() and p["vals"][:, l:].any()      # no pads on the verifier's side
