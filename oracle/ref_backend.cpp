@@ -33,6 +33,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <sstream>
 #include <iostream>
 #include <variant>
@@ -150,6 +151,11 @@ template <class Policy>
 struct Guest {
     zkp::ligetron_backend<field, Policy> backend;
     Recording rec;
+    // where the rows go: recorded (default), or handed to a consumer (section 4: the HIP row-batching shim)
+    using row_t = std::pair<vm::mpz_vector&, vm::mpz_vector&>;
+    std::function<void(row_t)> on_linear;
+    std::function<void(row_t, row_t, row_t)> on_quadratic;
+    std::function<void(vm::mpz_vector&, vm::mpz_vector&, vm::mpz_vector&)> on_masks;
     Guest(size_t l, size_t k, const uint8_t enc_key[32], const uint8_t wit_key[32]) : backend(l, k) {
         rec.k = k;
         unsigned char key[32], iv[16] = {0};                                              // params::any_iv (include/params.hpp:42)
@@ -162,9 +168,13 @@ struct Guest {
             backend.manager().quadratic_random_engine().init(key, iv);
         }
         backend.manager()
-            .register_linear_callback([this](auto row) { rec.row(0, row.first, row.second); })
-            .register_quadratic_callback([this](auto x, auto y, auto z) { rec.row(1, x.first, x.second); rec.row(2, y.first, y.second); rec.row(3, z.first, z.second); })
+            .register_linear_callback([this](auto row) { if (on_linear) on_linear(row); else rec.row(0, row.first, row.second); })
+            .register_quadratic_callback([this](auto x, auto y, auto z) {
+                if (on_quadratic) { on_quadratic(x, y, z); return; }
+                rec.row(1, x.first, x.second); rec.row(2, y.first, y.second); rec.row(3, z.first, z.second);
+            })
             .register_mask_callback([this](vm::mpz_vector& c, vm::mpz_vector& lin, vm::mpz_vector& q) {
+                if (on_masks) { on_masks(c, lin, q); return; }
                 const size_t k = rec.k;
                 rec.masks.resize(5 * k * 32);
                 c.export_limbs(rec.masks.data(), k * 4, sizeof(uint64_t), 4);
@@ -320,3 +330,78 @@ void ref_guest_read(const void* h, uint8_t* kinds, uint8_t* vals, uint8_t* rands
 void ref_guest_free(void* h) { delete static_cast<Recording*>(h); }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// 4. (libref_hip_guest.so, -DREF_WITH_HIP_SHIM) the reference's constraint backend IN FRONT OF THE HIP BACKEND, through the shim a maintainer
+// would add (include/lig_hip_row_batcher.hpp): witness_manager's callbacks export their rows' limbs straight into the
+// batcher's page-locked slots (mpz_vector::export_limbs, as nonbatch_context.hpp:447 does into its own vector), two runs of the guest
+// (stage-1 policy -> commit -> stage-2 policy keyed by the seed of the commitment -> prove), constsum() as the public constant.
+// Runs on the GPU box (the library travels prebuilt); tests/test_gpu_ref_backend.py compares the envelope with the oracle's over the same stream.
+#ifdef REF_WITH_HIP_SHIM
+#include "../include/lig_hip_row_batcher.hpp"
+
+namespace {
+template <class Policy>
+void feed_batcher(Machine<Policy>& m, ligero::hip_row_batcher& b, size_t k, bool with_rands) {
+    using row_t = typename Guest<Policy>::row_t;
+    auto slot_row = [&b, k, with_rands](uint8_t kind, row_t row) {
+        uint64_t* slot = b.next_slot();                 // pass 1: the next message row; pass 2: the next row's randomness row (packed)
+        vm::mpz_vector& src = with_rands ? row.second : row.first;
+        const bool has = !with_rands || src.size() != 0;
+        if (has && slot) src.export_limbs(slot, k * 4, sizeof(uint64_t), 4);
+        b.commit_slot(kind, has);
+    };
+    m.on_linear = [slot_row](row_t row) { slot_row(LIG_ROW_LINEAR, row); };
+    m.on_quadratic = [slot_row](row_t x, row_t y, row_t z) { slot_row(LIG_ROW_QX, x); slot_row(LIG_ROW_QY, y); slot_row(LIG_ROW_QZ, z); };
+    m.on_masks = [&b](vm::mpz_vector& c, vm::mpz_vector& lin, vm::mpz_vector& q) { b.mask_callback(c.size(), lin.size(), q.size()); };
+}
+template <class Policy>
+void run_into(Machine<Policy>& m, int which, size_t reps) {
+    if (which == 0) guest_i32_add(m);
+    else if (which == 1) guest_mul_add(m, reps);
+    else throw std::invalid_argument("unknown guest");
+    m.finish();
+}
+}  // namespace
+
+extern "C" int ref_guest_prove_hip(int which, uint64_t l, uint64_t k, const uint8_t enc_key[32], int64_t generated_at, uint64_t reps,
+                                   uint8_t root[32], uint8_t seed1[32], uint8_t constsum[32], uint8_t* proof_out, size_t cap, size_t* proof_len,
+                                   uint64_t* rows_out, int valid[3], char* err, size_t errcap) {
+    auto fail = [&](const std::string& why) { if (err && errcap) { std::strncpy(err, why.c_str(), errcap - 1); err[errcap - 1] = 0; } return 1; };
+    lig_ctx* ctx = nullptr;
+    if (lig_ctx_create(&ctx, 0, (uint32_t)l, (uint32_t)k, (uint32_t)(4 * k)) != LIG_OK) { const std::string w = ctx ? lig_last_error(ctx) : "lig_ctx_create"; if (ctx) lig_ctx_destroy(ctx); return fail(w); }
+    int rc = 0;
+    try {
+        ligero::hip_proof_meta meta;
+        std::memcpy(meta.encoding_seed, enc_key, 32);
+        meta.generated_at = generated_at;
+        ligero::hip_row_batcher b(ctx, meta);
+        {   // run 1 of the guest: stage-1 policy (rows with their pads; the masks are formed by the library from the same stream)
+            Machine<stage1_policy> m(l, k, enc_key, nullptr);
+            feed_batcher(m, b, k, false);
+            run_into(m, which, reps);
+        }
+        b.commit(root, seed1);
+        uint8_t cs[32];
+        {   // run 2: stage-2 policy, the three witness engines keyed by the seed the HIP backend derived from its commitment
+            Machine<stage2_policy> m(l, k, enc_key, seed1);
+            feed_batcher(m, b, k, true);
+            run_into(m, which, reps);
+            std::memcpy(cs, m.rec.constsum, 32);
+        }
+        std::memcpy(constsum, cs, 32);
+        size_t len = 0;
+        lig_proof_info info;
+        const uint8_t* proof = b.prove(cs, &len, &info);
+        *proof_len = len;
+        *rows_out = b.rows();
+        valid[0] = info.valid_code; valid[1] = info.valid_linear; valid[2] = info.valid_quad;
+        if (len > cap) rc = fail("proof buffer too small");
+        else std::memcpy(proof_out, proof, len);
+    } catch (const std::exception& e) {
+        rc = fail(e.what());
+    }
+    lig_ctx_destroy(ctx);
+    return rc;
+}
+#endif

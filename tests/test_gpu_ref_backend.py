@@ -196,3 +196,31 @@ def test_live_reference_row_former_feeds_the_hip_prover_at_configs1_scale(amd):
         c.trace_destroy(tr)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("name", ["i32_add_320", "i32_add_8000", "mul_add_320"])
+def test_reference_constraint_backend_drives_the_hip_backend_through_the_shim(name):
+    """the binding a maintainer adds, compiled and run: oracle/_ref/libref_hip_guest.so = the reference's witness_manager + ligetron_backend
+    (from /root/reference, built in the build container) whose linear / quadratic / mask callbacks export their rows straight into
+    ligero::hip_row_batcher's slots (include/lig_hip_row_batcher.hpp), two runs of the guest around commit(), constsum() into prove() --
+    all in one process with liblig_hip.so.  configs[0] (tests/i32_add.wat) end to end below the interpreter: root, seed, constant and
+    envelope equal the fixture's (the oracle over the recorded stream)."""
+    import ctypes as C
+    so = os.path.join(os.path.dirname(os.path.dirname(GOLD)), "oracle", "_ref", "libref_hip_guest.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_hip_guest.so is not present on this box")
+    f = load_rows(name)
+    m = f["meta"]
+    L = C.CDLL(so)
+    L.ref_guest_prove_hip.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int * 3), C.c_char_p, C.c_size_t]
+    root, seed1, cs = (np.zeros(32, dtype=np.uint8) for _ in range(3))
+    cap = 64 << 20
+    proof = np.zeros(cap, dtype=np.uint8)
+    ln, rows, valid, err = C.c_size_t(), C.c_uint64(), (C.c_int * 3)(), C.create_string_buffer(512)
+    rc = L.ref_guest_prove_hip({"i32_add": 0, "mul_add": 1}[m["guest"]], m["l"], m["k"], bytes.fromhex(m["encoding_seed"]), m["generated_at"], m["reps"],
+                               root.ctypes.data, seed1.ctypes.data, cs.ctypes.data, proof.ctypes.data, cap, C.byref(ln), C.byref(rows), C.byref(valid), err, 512)
+    assert rc == 0, err.value.decode()
+    assert rows.value == m["rows"] and list(valid) == [1, 1, 1]
+    assert root.tobytes().hex() == m["oracle_root"] and seed1.tobytes().hex() == m["oracle_stage1_seed"] and cs.tobytes() == f["constsum"]
+    assert hashlib.sha256(proof[:ln.value].tobytes()).hexdigest() == m["oracle_proof_sha256"] and ln.value == m["oracle_proof_len"]
