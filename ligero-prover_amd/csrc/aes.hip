@@ -207,7 +207,8 @@ static constexpr size_t BIG_FILL = (size_t)1 << 20;      // below this the 64 Ki
 #define LIG_AES_REP 4
 #endif
 static constexpr int REP = LIG_AES_REP;
-static constexpr uint32_t BIG_BLOCKS = 256u * (REP >= 4 ? 2u : REP == 3 ? 4u : 8u);     // persistent workgroups: as many as the LDS of 256 CUs holds
+static constexpr uint32_t BIG_BLOCKS_MAX = 256u * (REP >= 4 ? 2u : REP == 3 ? 4u : 8u);     // persistent workgroups: as many as the LDS of 256 CUs holds
+#define BIG_BLOCKS (lig::knobs().aes_blocks ? lig::knobs().aes_blocks : BIG_BLOCKS_MAX)
 static inline uint32_t small_blocks(size_t total, size_t cap) { size_t b = (total + 255) / 256; return (uint32_t)(b > cap ? cap : b); }
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k) {
     const size_t total = rows * k;

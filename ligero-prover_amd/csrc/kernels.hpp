@@ -19,6 +19,7 @@ struct Knobs {
     bool     encode_generic = false;   // LIG_ENCODE_GENERIC radix-2 row path even where the tiled encoder exists (tests)
     uint32_t sha_block = 256;          // LIG_SHA_BLOCK      workgroup size of the column hash
     int      sha_ws = 2;               // LIG_SHA_WS         column hash: 0 one wave per 64 columns; 1 / 2 / 4 wave-specialised (producer + consumer waves), groups per workgroup
+    uint32_t aes_blocks = 0;           // LIG_AES_BLOCKS     persistent workgroups of the big sampler launches (0: two per CU)
     int      sha_gate = 1;             // LIG_SHA_GATE       place every chunk's hash before the encode stream goes on
     size_t   sha_gate_rows = 2;        // LIG_SHA_GATE_ROWS  rows hashed before the encode stream is released
     int      sha_prio = 0;             // LIG_SHA_PRIO       1: the side stream (column hash, samplers) is a high-priority stream

@@ -309,6 +309,7 @@ const lig::Knobs& lig::knobs() {
         t.sha_block = (uint32_t)pos("LIG_SHA_BLOCK", 256);
         { const long v = num("LIG_SHA_WS", 2); t.sha_ws = (v == 0 || v == 1 || v == 4) ? (int)v : 2; }
         t.sha_gate = (int)num("LIG_SHA_GATE", 1);
+        { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
