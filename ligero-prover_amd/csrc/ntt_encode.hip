@@ -70,10 +70,23 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
 #ifndef LIG_K2_WAVES
 #define LIG_K2_WAVES 3
 #endif
+// EXPERIMENT (-DLIG_K2_CB_GLOBAL, not the default; profiles/r05_tile_cb_global_ab.md): the coefficients between the inverse and the
+// forward transforms go through the workgroup's own Y tile (dead once loaded; L2-resident) instead of staying in 36 registers
+// across the coset loop -- the full kernel then needs the half kernel's registers and runs 4 waves per SIMD (-DLIG_K2_WAVES=4).
+#ifdef LIG_K2_CB_GLOBAL
+#define LIG_K2_Y_QUAL
+#else
+#define LIG_K2_Y_QUAL __restrict__
+#endif
 template <int LOG2B, bool FULL>
-__global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_encode_tiles(const fr* __restrict__ Y, fr* __restrict__ Z,
+__global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_encode_tiles(const fr* LIG_K2_Y_QUAL Y, fr* LIG_K2_Y_QUAL Z,
                                                                    const f29wt tw_inv, const f29wt tw_fwd, const f29wt twist, const f29wt seam_fwd) {
     constexpr uint32_t B = 1u << LOG2B, T = B / 4, NC = FULL ? 3 : 1;
+#ifdef LIG_K2_CB_GLOBAL
+    constexpr bool CBG = FULL;
+#else
+    constexpr bool CBG = false;
+#endif
     __shared__ TileLds<LOG2B> L;
 #ifdef LIG_K2_SETPRIO            // A/B (profiles/r04_tile_setprio_ab.md): tile waves ahead of the other streams' waves in the SIMD's arbiter
     __builtin_amdgcn_s_setprio(LIG_K2_SETPRIO);
@@ -87,12 +100,19 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
 #pragma unroll
     for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + pos(q)));
     tile_dft<LOG2B>(x, tw_inv, L, t);
-    __syncthreads();                                   // every wave is done reading the last exchange of the transform
+    fr* const cg = const_cast<fr*>(y);
+    if constexpr (CBG) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) lds_put(L, t + q * T, f29_reduce_2p(x[q]));      // < 2p, normalised
-    __syncthreads();
+        for (int q = 0; q < 4; q++) fr_store(cg + t + q * T, pack29(f29_reduce_2p(x[q])));      // < 2p, 8 x u32
+        __syncthreads();                               // the stores are visible to the workgroup; the exchange buffer is free
+    } else {
+        __syncthreads();                               // every wave is done reading the last exchange of the transform
 #pragma unroll
-    for (int q = 0; q < 4; q++) cb[q] = lds_get(L, pos(q));
+        for (int q = 0; q < 4; q++) lds_put(L, t + q * T, f29_reduce_2p(x[q]));      // < 2p, normalised
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) cb[q] = lds_get(L, pos(q));
+    }
 #pragma unroll 1
     for (uint32_t ci = 0; ci < NC; ci++) {
         const uint32_t r = FULL ? ci + 1 : 2;
@@ -101,8 +121,13 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
         // hoisted into 64-bit register pairs that do not fit next to the coefficients and end up in scratch memory
         uint32_t tt = t;
         asm volatile("" : "+v"(tt));
+        if constexpr (CBG) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = f29_mulw(cb[q], f29_load_w(tws + (q * T + tt)));   // w_n^(r*(j1 + 8*pos))
+            for (int q = 0; q < 4; q++) x[q] = f29_mulw(unpack29(fr_load(cg + (__brev(4 * tt + q) >> (32 - LOG2B)))), f29_load_w(tws + (q * T + tt)));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = f29_mulw(cb[q], f29_load_w(tws + (q * T + tt)));   // w_n^(r*(j1 + 8*pos))
+        }
         __syncthreads();                               // the exchange buffer is free again (ownership change / previous coset)
         tile_dft<LOG2B>(x, tw_fwd, L, tt);
         fr* z = Z + ((row * NC + ci) * 8 + j1) * (size_t)B;
