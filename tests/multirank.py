@@ -6,7 +6,9 @@ What round 4 taught this file (one hang of a world-2 test 
   * all ranks are watched together: the first rank that exits non-zero ends the run (the others get a few seconds to fail by
     themselves -- their error text is the interesting one -- and are then killed, whole process group);
   * a timeout kills ALL ranks (no orphan keeps the GPU) and the assertion carries EVERY rank's stderr tail;
-  * timeouts are sized to the test (default 120 s: the slowest of them takes 20 s on the target box).
+  * timeouts are sized to the box, not to the test (default 300 s: the slowest multi-rank test takes 12 s on the target box, but a box
+    whose page cache has just been dropped imports torch in a minute or two per process; a real hang is ended by the watchdogs of the
+    library in seconds and by this timeout at the latest, and `pytest.ini` caps every test at 420 s).
 """
 import itertools
 import os
@@ -58,7 +60,7 @@ def _kill_group(p):
             pass
 
 
-def run_ranks(argv, world, env, timeout=120.0, grace=8.0, tail=3000):
+def run_ranks(argv, world, env, timeout=300.0, grace=8.0, tail=3000):
     """argv (a list: the same for every rank; or a function rank -> list) as `world` processes with RANK / LOCAL_RANK = 0 .. world-1.
     Returns [(stdout, stderr)] in rank order when every rank exits 0; raises RankFailure with every rank's state otherwise."""
     tmp = tempfile.mkdtemp(prefix="lig_ranks_")

@@ -217,6 +217,6 @@ def test_sharded_row_batcher_gives_the_oracle_envelope_on_every_rank(world, n_li
     import multirank as mr
     name = "/lig_sb_" + mr.fresh_tag()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    outs = mr.run_ranks(lambda r: [exe, str(r), str(world), name, str(n_lin), str(n_quad)], world, env, timeout=120)
+    outs = mr.run_ranks(lambda r: [exe, str(r), str(world), name, str(n_lin), str(n_quad)], world, env, timeout=300)
     for r, (o, e) in enumerate(outs):
         assert ("rank %d: equal 1 " % r) in o, (o, e[-2000:])

@@ -30,7 +30,7 @@ def test_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     import multirank as mr
-    res = mr.run_ranks(mr.python_argv(script, ROOT), 2, mr.rendezvous_env(2), timeout=120)
+    res = mr.run_ranks(mr.python_argv(script, ROOT), 2, mr.rendezvous_env(2), timeout=300)
     outs = [__import__("json").loads(o.strip().splitlines()[-1]) for o, _ in res]
     outs.sort(key=lambda d: d["rank"])
     assert [o["world"] for o in outs] == [2, 2]

@@ -53,7 +53,7 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def run_world(tmp_path, world, l, k, n, n_lin, n_quad, batch=False, comm=None, timeout=120):
+def run_world(tmp_path, world, l, k, n, n_lin, n_quad, batch=False, comm=None, timeout=300):
     """comm=None: host-synchronous gloo callbacks; comm="ipc": the stream-ordered process-to-process communicator
     (csrc/comm_ipc.hip) -- the double-buffered exchange pipeline of lig_shard_prove with real peers on the one GPU.
     Every invocation has its own rendezvous port and communicator tag; all ranks are watched (tests/multirank.py)."""
@@ -382,7 +382,7 @@ ROWS_WORKER = textwrap.dedent('''
 ''')
 
 
-def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, batch, mode, comm, timeout=120, **env):
+def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, batch, mode, comm, timeout=300, **env):
     script = tmp_path / "shard_rows_worker.py"
     script.write_text(ROWS_WORKER)
     outs = mr.run_ranks(mr.python_argv(script, ROOT, l, k, n, n_lin, n_quad, "1" if batch else "0", mode), world, mr.rendezvous_env(world, comm, **env), timeout=timeout)
@@ -482,7 +482,7 @@ def test_a_failing_peer_makes_the_sharded_call_return_an_error_instead_of_hangin
         files.append((fo, fe))
         procs.append(subprocess.Popen(mr.python_argv(script, ROOT, how), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=fo, stderr=fe, start_new_session=True))
     try:
-        rc0 = procs[0].wait(timeout=120)
+        rc0 = procs[0].wait(timeout=300)
     finally:
         for p in procs:
             mr._kill_group(p)
