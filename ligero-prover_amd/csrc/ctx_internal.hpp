@@ -74,9 +74,12 @@ inline void lig_internal_comm_unregister(lig_ctx* c, void* obj) {
 // watchdog has to end the process).  Used to show that bench.py's transport ladder falls through to the next rung.
 int lig_internal_comm_fault(lig_ctx* c, bool stream_ordered);
 
-// mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes)
+// mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes) /
+// ENC_ZRES (4, rows x 3k, cosets 1..3 as the tile kernel's Z tiles: no last radix-8 pass; fast encoder only)
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr);
-int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on = nullptr);
+// cw2_z: the rows of cw2 are Z tiles of coset 2 (lig::ENC_ZRES) instead of coset values
+int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on = nullptr,
+                            bool cw2_z = false);
 int lig_internal_extend_2k(lig_ctx* c, void* buf);
 // decode_ntt_device of `src` (n elements, left intact) into `dst` (n elements, != src), on the context stream
 int lig_internal_decode_to(lig_ctx* c, const void* src, void* dst);

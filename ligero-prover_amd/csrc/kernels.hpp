@@ -38,6 +38,7 @@ struct Knobs {
     int      spin_wait_ms = 50;        // LIG_SPIN_WAIT_MS   polling gives way to the blocking wait after this long
     bool     d2h_kernel = true;        // LIG_D2H_KERNEL=0   proof downloads by hipMemcpyAsync instead of copy kernels
     bool     shard_force_exchange = false;   // LIG_SHARD_FORCE_EXCHANGE  pack + all-to-all with one rank too (tests)
+    bool     zres = false;             // LIG_ZRES=1         stage 1 keeps the encoder's Z tiles instead of codeword planes: K3 inside the column hash (round 6 A/B)
     bool     trace = false;            // LIG_TRACE          synchronised phase timeline on stderr
     int      fault_comm = 0;           // LIG_FAULT_COMM     tests: 1 = the stream-ordered all-to-all of the library's communicators
                                        //                    fails on first use, 2 = the host-synchronous one fails as well
@@ -104,8 +105,12 @@ bool encode_fast_supported(uint32_t k);
 // mode ENC_DOT: like ENC_HALF, but the k coset values of row r are not stored: their products with cw2[r] (rows of another
 //   matrix on the same coset, cw2_stride elements apart) are added, per group of group_rows rows, to part[group][k]
 //   (group partials in the format of k_rlc_partial's lin_part: plain values < 2p; `out` is unused).
-enum { ENC_FULL = 0, ENC_HALF = 1, ENC_PLANAR = 2, ENC_DOT = 3 };
-struct EncodeDot { const fr* cw2; size_t cw2_stride; uint32_t group_rows; fr* part; };
+// mode ENC_ZRES (round 6, LIG_ZRES): out = rows x 3k like ENC_PLANAR, but holding the Z tiles of the three computed cosets as the
+//   tile kernel leaves them (element ((ci*8 + j1) << log2B) + q2 of a row, ci = coset - 1): the last radix-8 pass is NOT run; its
+//   consumers (the column hash, the coset-2 dot, the column gather) take the radix-8 outputs they need from the tiles themselves.
+// mode ENC_DOT with dot->cw2_z: cw2 rows are such Z tiles (of coset 2) instead of coset values.
+enum { ENC_FULL = 0, ENC_HALF = 1, ENC_PLANAR = 2, ENC_DOT = 3, ENC_ZRES = 4 };
+struct EncodeDot { const fr* cw2; size_t cw2_stride; uint32_t group_rows; fr* part; bool cw2_z = false; };
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y,
                       fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, int mode = ENC_FULL, const EncodeDot* dot = nullptr);
 
@@ -126,6 +131,8 @@ void launch_eltwise(hipStream_t s, int op, const fr* x, const fr* y, fr* out, si
 void launch_powmod(hipStream_t s, const fr* table32, const uint32_t* exp, const fr* coeff, fr* out, size_t count, int add);
 void launch_gather_rows(hipStream_t s, const fr* cw, size_t row_stride, size_t rows, const uint32_t* idx, uint32_t count, fr* out);
 void launch_gather_rows_planar(hipStream_t s, CwView cw, size_t rows, const uint32_t* idx, uint32_t count, fr* out);
+// the same over a CwView whose `planes` are Z tiles (ENC_ZRES): every opened element of cosets 1..3 is one radix-8 output (ntt_encode.hip)
+bool launch_gather_rows_z(hipStream_t s, const EncodePlan& ep, CwView cw, size_t rows, const uint32_t* idx, uint32_t count, fr* out);
 void launch_rlc_rows(hipStream_t s, const fr* U, const fr* Rn, size_t rows, uint32_t n, const fr* rc_dev,
                      fr* code, fr* lin, const uint32_t* triples_dev, const fr* rq_dev, size_t n_triples, fr* quad);
 
@@ -139,6 +146,8 @@ void launch_sha_init(hipStream_t s, uint32_t* state, size_t n_inst);
 // interleaved rows (msgs == nullptr) or a CwView {msgs, planes = rows} (sha.hip); launch_sha_final then needs the same plane_k
 void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const fr* rows, size_t row_stride,
                             size_t nrows, uint64_t rows_before, uint32_t plane_k = 0, const fr* msgs = nullptr);
+// rows whose cosets 1..3 are Z tiles (ENC_ZRES): the encoder's last radix-8 pass runs inside the hash's producer waves (sha.hip)
+bool launch_sha_update_rows_z(hipStream_t s, uint32_t* state, const EncodePlan& ep, const fr* z, size_t nrows, uint64_t rows_before, const fr* msgs);
 void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests, uint32_t plane_k = 0);
 void launch_merkle_build(hipStream_t s, const uint32_t* leaves, size_t n_leaves, uint32_t* nodes);
 

@@ -331,6 +331,7 @@ const lig::Knobs& lig::knobs() {
         t.spin_wait_ms = (int)pos("LIG_SPIN_WAIT_MS", 50);
         t.shard_force_exchange = std::getenv("LIG_SHARD_FORCE_EXCHANGE") != nullptr;
         t.trace = std::getenv("LIG_TRACE") != nullptr;
+        t.zres = num("LIG_ZRES", 0) != 0;
         t.fault_comm = (int)num("LIG_FAULT_COMM", 0);
         t.ipc_stall_s = (int)pos("LIG_IPC_STALL_S", 60);
         t.comm_timeout_s = (int)pos("LIG_COMM_TIMEOUT_S", 300);
@@ -558,8 +559,9 @@ int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ens
 // (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
 int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on) {
     const bool half = mode == lig::ENC_HALF;
-    const size_t out_stride = half ? (size_t)c->k : mode == lig::ENC_PLANAR ? 3 * (size_t)c->k : (size_t)c->n;
+    const size_t out_stride = half ? (size_t)c->k : (mode == lig::ENC_PLANAR || mode == lig::ENC_ZRES) ? 3 * (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
+    if (mode == lig::ENC_ZRES && !c->fast) return LIG_E_STATE;       // Z tiles exist only in the tiled encoder
     if (c->fast) {
         // rows per launch group: the Y/Z scratch (1 MiB/row) should stay inside the 256 MiB L3 so that K3's
         // re-read of Z does not go to HBM.  LIG_ENCODE_CHUNK overrides for experiments.
@@ -628,12 +630,12 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
 // stage-2 linear test on the coset w_n^2 <w_n^4>: for every row r the coset values of rands[r] (k values, never stored) times
 // cw2[r] (k values of another matrix on the same coset, rows cw2_stride elements apart), summed per group of group_rows rows
 // into part[group][k] (added to what is there).  Fast encoder only; rows <= the reserved scratch.
-int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on) {
+int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on, bool cw2_z) {
     if (!c->fast) return LIG_E_STATE;
     hipStream_t st = on ? on : c->stream;
     int rc = ensure_scratch(c, rows);
     if (rc != LIG_OK) return rc;
-    const lig::EncodeDot dot{(const fr*)cw2, cw2_stride, group_rows, (fr*)part};
+    const lig::EncodeDot dot{(const fr*)cw2, cw2_stride, group_rows, (fr*)part, cw2_z};
     lig::encode_rows_fast(st, c->ep, (const fr*)rands, nullptr, c->scratch_y, c->scratch_z, rows, nullptr, nullptr, lig::ENC_DOT, &dot);
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;

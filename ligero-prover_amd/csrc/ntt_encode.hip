@@ -240,6 +240,88 @@ __global__ void __launch_bounds__(256, 2) k_encode_out_dot(const fr* __restrict_
     }
 }
 
+// The same with the codeword side given as Z tiles (ENC_ZRES: K3 was never run for the resident matrix): per row one more radix-8
+// butterfly -- across cwz[r][0..8)[q2], the coset-2 tiles of U_r -- whose eight outputs wait in LDS (this thread's own 256 bytes; no
+// synchronisation: written and read by the same thread) while the butterfly of the randomness row runs in the same registers.
+template <int LOG2B>
+__global__ void __launch_bounds__(256, 2) k_encode_out_dot_z(const fr* __restrict__ Z, const f29wt w8, const fr* __restrict__ cwz,
+                                                             size_t cws, size_t rows, uint32_t group_rows, fr* __restrict__ part) {
+    constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
+    __shared__ uint4 park[16][256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q2 >= B) return;
+    const size_t r0 = (size_t)blockIdx.y * group_rows;
+    const size_t r1 = r0 + group_rows < rows ? r0 + group_rows : rows;
+    f29 acc[8];
+#pragma unroll
+    for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_zero();
+    int since = 0;
+    for (size_t r = r0; r < r1; r++) {
+        const fr* z = Z + (r * 8) * (size_t)B + q2;
+        const fr* uz = cwz + r * cws + q2;
+        f29 a[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(uz + (size_t)brev3(p) * B));
+        radix8_dit<false>(a, w8);
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) {
+            const fr c = pack29(f29_reduce_2p(a[q1]));                            // U_r on the coset, < 2p
+            park[2 * q1][tid] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+            park[2 * q1 + 1][tid] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
+        radix8_dit<false>(a, w8);                                                 // limbs < 2^31 + 8, value < 28p
+#pragma unroll
+        for (int q1 = 0; q1 < 8; q1++) {
+            const uint4 lo = park[2 * q1][tid], hi = park[2 * q1 + 1][tid];
+            fr c;
+            c.v[0] = lo.x; c.v[1] = lo.y; c.v[2] = lo.z; c.v[3] = lo.w; c.v[4] = hi.x; c.v[5] = hi.y; c.v[6] = hi.z; c.v[7] = hi.w;
+            acc[q1] = f29_add(acc[q1], f29_montmul(a[q1], unpack29(c)));           // each term < 28p * 2p / 2^261 + p < 1.4p
+        }
+        if (++since == 6) {
+#pragma unroll
+            for (int q1 = 0; q1 < 8; q1++) acc[q1] = f29_qnorm(acc[q1]);
+            since = 0;
+        }
+    }
+    fr* out = part + (size_t)blockIdx.y * K + q2;
+#pragma unroll
+    for (int q1 = 0; q1 < 8; q1++) {
+        f29 v = f29_montmul(f29_qnorm(acc[q1]), f29_const_r2());
+        v = f29_reduce_2p(f29_add(v, unpack29(fr_load(out + (size_t)B * q1))));
+        fr_store(out + (size_t)B * q1, pack29(v));
+    }
+}
+
+// Column gather over a resident matrix of Z tiles (ENC_ZRES): out[r*count + i] = codeword element idx[i] of row r.  Coset 0 from the
+// message row (reversed); an element of cosets 1..3 is output q1 of the radix-8 butterfly across Z[r][coset-1][0..8)[q2], reduced
+// exactly as K3 would have (canonical residues are unique: the same bytes as the planar matrix).
+template <int LOG2B>
+__global__ void __launch_bounds__(256) k_gather_rows_z(CwView cw, const f29wt w8, size_t rows, const uint32_t* __restrict__ idx, uint32_t count,
+                                                       fr* __restrict__ out) {
+    constexpr uint32_t B = 1u << LOG2B, K = 8u * B;
+    const size_t total = rows * count;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = t / count;
+        const uint32_t col = idx[(uint32_t)(t - r * count)];
+        const uint32_t cs = col & 3u, q = col >> 2;
+        if (cs == 0) { fr_store(out + t, fr_load(cw.msgs + r * K + ((K - q) & (K - 1)))); continue; }
+        const uint32_t q2 = q & (B - 1), q1 = q >> LOG2B;
+        const fr* z = cw.planes + r * 3 * (size_t)K + (size_t)(cs - 1) * K + q2;
+        f29 a[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) a[p] = unpack29(fr_load(z + (size_t)brev3(p) * B));
+        radix8_dit(a, w8);
+        f29 v = a[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++)
+            if (q1 == (uint32_t)i) v = a[i];
+        fr_store(out + t, pack29(f29_canon(v)));
+    }
+}
+
 // tile length B = k/8 = 64 .. 4096: 36 bytes of LDS per element, i.e. 2.25 .. 144 KiB per workgroup of B/4 threads
 bool encode_fast_supported(uint32_t k) { return k >= 512 && k <= 32768 && (k & (k - 1)) == 0; }
 
@@ -260,12 +342,18 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
         // registers allow (3) and leave room for the waves of the other stream's kernels
         const uint32_t dyn = lig::knobs().k2_dyn_lds;
         if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
-        else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
+        else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, mode == ENC_ZRES ? cw : Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
     }
     if (ev1) (void)hipEventRecord(ev1, s);
+    if (mode == ENC_ZRES) return;                       // the tiles ARE the output: no last pass
     if (!(kmask & 8)) return;
     if (mode == 3) {
         const uint32_t groups = (uint32_t)((rows + dot->group_rows - 1) / dot->group_rows);
+        if (dot->cw2_z) {
+            hipLaunchKernelGGL(k_encode_out_dot_z<LOG2B>, dim3((B + 255) / 256, groups), dim3(B < 256 ? B : 256), 0, s, Z, ep.w8_fwd, dot->cw2, dot->cw2_stride, rows,
+                               dot->group_rows, dot->part);
+            return;
+        }
         hipLaunchKernelGGL(k_encode_out_dot<LOG2B>, dim3((B + 255) / 256, groups), dim3(B < 256 ? B : 256), 0, s, Z, ep.w8_fwd, dot->cw2, dot->cw2_stride, rows,
                            dot->group_rows, dot->part);
         return;
@@ -275,6 +363,18 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     if (mode == 0) hipLaunchKernelGGL((k_encode_out<LOG2B, 0>), g3, dim3(bs13), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
     else if (mode == 1) hipLaunchKernelGGL((k_encode_out<LOG2B, 1>), g3, dim3(bs13), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
     else hipLaunchKernelGGL((k_encode_out<LOG2B, 2>), g3, dim3(bs13), 0, s, Z, cw, ep.w8_fwd, msgs, rows);
+}
+
+bool launch_gather_rows_z(hipStream_t s, const EncodePlan& ep, CwView cw, size_t rows, const uint32_t* idx, uint32_t count, fr* out) {
+    if (!rows || !count) return true;
+    const size_t total = rows * count;
+    const dim3 grid((uint32_t)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096));
+    switch (ep.log2B) {
+#define LIG_GZ(L) case L: hipLaunchKernelGGL(k_gather_rows_z<L>, grid, dim3(256), 0, s, cw, ep.w8_fwd, rows, idx, count, out); return true;
+        LIG_GZ(6) LIG_GZ(7) LIG_GZ(8) LIG_GZ(9) LIG_GZ(10) LIG_GZ(11) LIG_GZ(12)
+#undef LIG_GZ
+        default: return false;
+    }
 }
 
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,

@@ -82,6 +82,8 @@ struct lig_trace {
     lig_proof_info info1;               // stage-1 results kept between lig_rows_commit and lig_rows_prove
     size_t R = 0, RB = 0, n_init = 0;   // all rows, leading rows committed by the batch program, of those: init rows
     fr* msgs = nullptr;                 // R x k witness matrix (pads are re-drawn by every prove)
+    bool zres = false;                  // LIG_ZRES: `cw` holds the encoder's Z tiles (lig::ENC_ZRES) instead of planes -- K3 runs inside the column hash,
+                                        // stage 2 / 3 take single radix-8 outputs from the tiles (linear rows only: a trace with quadratic triples keeps planes)
     fr* cw = nullptr;                   // R x 3k: cosets 1..3 of every codeword as planes (lig::ENC_PLANAR), resident across the stages;
                                         // coset 0 of a codeword is its message row reversed and is read from `msgs` (lig::CwView)
     fr* maskcw = nullptr;               // 3 x n: the mask rows' codewords, reference layout
@@ -256,6 +258,7 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     const uint32_t k = c->k, n = c->n, t = 192;
     const size_t R = T->R = T->rows.size();
     T->triples = quad_terms(T->rows);
+    T->zres = lig::knobs().zres && c->fast && T->triples.empty();
     const size_t chunk = lig_tune::CHUNK, groups = (chunk + lig_tune::GROUP - 1) / lig_tune::GROUP;
     auto dm = [&](void** p, size_t bytes) -> int { HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16)); HIP_TRY(c, hipMemsetAsync(*p, 0, bytes, c->stream)); return LIG_OK; };
     TRY(dm((void**)&T->msgs, (R ? R : 1) * (size_t)k * 32));
@@ -365,12 +368,23 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
                 lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
             }
         }
-        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, lig::ENC_PLANAR, s_enc));
+        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, T->zres ? lig::ENC_ZRES : lig::ENC_PLANAR, s_enc));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
         const int gate = lig::knobs().sha_gate;
         const size_t g = lig::knobs().sha_gate_rows;
-        if (gate && nb > 2 * g) {
+        if (T->zres) {
+            // (same placement rule as below; the gate is a whole batch of the in-hash butterflies: 8 rows)
+            const size_t gz = g < 8 ? 8 : g;
+            if (gate && nb > 2 * gz) {
+                lig::launch_sha_update_rows_z(s_sha, T->sha_state, c->ep, T->cw + b * k3, gz, absorbed, T->msgs + b * k);
+                HIP_TRY(c, hipEventRecord(T->ev_gate, s_sha));
+                lig::launch_sha_update_rows_z(s_sha, T->sha_state, c->ep, T->cw + (b + gz) * k3, nb - gz, absorbed + gz, T->msgs + (b + gz) * k);
+                HIP_TRY(c, hipStreamWaitEvent(s_enc, T->ev_gate, 0));
+            } else {
+                lig::launch_sha_update_rows_z(s_sha, T->sha_state, c->ep, T->cw + b * k3, nb, absorbed, T->msgs + b * k);
+            }
+        } else if (gate && nb > 2 * g) {
             // the hash waves must be placed while the chip is idle (one per SIMD, evenly): hash the first two rows, let the
             // encode stream wait for that, and queue the rest of the chunk right behind it on the hash stream
             lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, g, absorbed, k, T->msgs + b * k);
@@ -556,7 +570,7 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         if (c->fast) {
             // coset-2 values of the randomness rows times the coset-2 plane of the codewords, summed per group of rows inside the
             // encoder's output kernel: the values themselves are never written
-            TRY(lig_internal_encode_dot(c, rb, nb, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, lig_tune::DOT_GROUP, p_linC));
+            TRY(lig_internal_encode_dot(c, rb, nb, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, lig_tune::DOT_GROUP, p_linC, nullptr, T->zres));
         } else {
             TRY(lig_internal_encode_rows(c, rb, rhalf, nb, lig::ENC_HALF));
             lig::launch_rlc_accumulate29(s, T->cw + b * 3 * (size_t)k + k, 3 * (size_t)k, 1, rhalf, k, nb, k, nullptr, nullptr, p_linC, lig_tune::DOT_GROUP);
@@ -631,7 +645,8 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
     // runs while the host derives the decommitment (the Merkle nodes were downloaded in stage 1) and lays out the envelope;
     // the opened columns then land in place while the host evaluates the self-check predicates.
     TRY(lig_sample_init(c, idx.data(), idx.size()));
-    lig::launch_gather_rows_planar(s, view, R, c->sample_idx, t, T->samples);
+    if (T->zres) lig::launch_gather_rows_z(s, c->ep, view, R, c->sample_idx, t, T->samples);
+    else lig::launch_gather_rows_planar(s, view, R, c->sample_idx, t, T->samples);
     lig::launch_gather_rows(s, T->maskcw, n, 3, c->sample_idx, t, T->samples + R * (size_t)t);
     const size_t n_nodes = lig_merkle_nodes(n);
     const std::vector<uint8_t> sib = decommit(T->h_nodes, (n_nodes + 1) / 2, idx);

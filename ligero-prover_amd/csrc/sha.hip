@@ -12,7 +12,9 @@
 // Message word order (shader/sha256.wgsl:148-163): every u32 limb is fed most-significant byte first, limbs
 // least-significant first, so the 16 message words of a block are exactly the 8 limbs of row 2q followed by
 // the 8 limbs of row 2q+1.  The leaf is the 8 state words stored as native u32 (:226-228).
+#include "fr29.hpp"
 #include "kernels.hpp"
+#include "tile_dft.hpp"
 #include <cstdlib>
 
 namespace lig {
@@ -255,6 +257,177 @@ __global__ void __launch_bounds__(GROUPS * 128) k_sha_update_rows_ws(uint32_t* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Column hash straight from the encoder's Z matrix (round 6, LIG_ZRES=1): the last radix-8 pass of the row encoder (K3,
+// ntt_encode.hip) runs INSIDE the hash's producer wave, so the codeword planes of stage 1 are never written to HBM and never
+// read back (-1.5 MB of traffic per committed row); the Z tiles K2 wrote stay resident in their place and stages 2 / 3 take
+// single radix-8 outputs from them (k_encode_out_dot_z, k_gather_rows_z).
+//
+// K3's unit of work is (row, coset, q2) -> the 8 columns q2 + B*q1; the hash's is (column) x all rows.  A group of 64 columns
+// of plane r >= 1 is therefore 8 consecutive q2 x all 8 q1 (column-lane = q1*8 + q2'), and its producer wave works in batches
+// of 8 rows: butterfly-lane = (row-in-batch, q2'), 8 canonical outputs each -> a 16 KiB LDS stage (wave-private: the transpose
+// from (row, q2') x q1 to (q1, q2') x row is LDS write + read of the same wave, ordered by a wave-local fence) -> per row the
+// column-lane picks up its element and, every second row, expands the message schedule of a block exactly as the producer of
+// k_sha_update_rows_ws does.  The loads of the next batch are issued before the four schedule expansions of the current one.
+// Plane 0 (coset 0 = the message row reversed) keeps the contiguous column-lanes and the plain producer.  The consumer wave is
+// the one of k_sha_update_rows_ws: rounds only.  Handles every (nrows, rows_before) combination (a pending half block is
+// picked up from / left in the state like everywhere else).
+template <int LOG2B, int GROUPS>
+__global__ void __launch_bounds__(GROUPS * 128) k_sha_update_rows_z(uint32_t* __restrict__ st, const fr* __restrict__ Z, size_t nrows, uint64_t rows_before,
+                                                                     const fr* __restrict__ msgs, const f29wt w8) {
+    constexpr uint32_t B = 1u << LOG2B, K = 8u * B, GPP = B / 8;      // groups per plane (k / 64)
+    constexpr size_t n_inst = 4 * (size_t)K;
+    __shared__ uint4 ring[GROUPS][16][64];
+    __shared__ uint4 stage[GROUPS][16][64];
+    __shared__ uint32_t ready[GROUPS], taken[GROUPS];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool producer = wave >= GROUPS;
+    const uint32_t g = producer ? wave - GROUPS : wave;
+    if (threadIdx.x < GROUPS) { ready[threadIdx.x] = 0; taken[threadIdx.x] = 0; }
+    __syncthreads();
+    const uint32_t group = blockIdx.x * GROUPS + g;
+    if (group >= 4 * GPP) return;
+    const uint32_t plane = group / GPP, gi = group - plane * GPP;
+    const uint32_t q = plane == 0 ? gi * 64 + lane : 8 * gi + (lane & 7u) + B * (lane >> 3);
+    const size_t j = (size_t)plane * K + q;
+    const size_t pend = (size_t)(rows_before & 1);
+    const size_t total = nrows + pend;
+    const uint32_t nblocks = (uint32_t)(total / 2);
+    uint4 (*slot)[64] = ring[g];
+
+    if (producer) {
+        // block b of this group: expand the schedule of w[0..16), add K, hand the 64 words to the consumer
+        auto publish = [&](uint32_t (&w)[64], uint32_t b) {
+#pragma unroll
+            for (int i = 16; i < 64; i++) {
+                const uint32_t w15 = w[i - 15], w2 = w[i - 2];
+                w[i] = (w[i - 16] + xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3) + w[i - 7]) + xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+            }
+#pragma unroll
+            for (int i = 0; i < 64; i++) w[i] += SHA_K[i];
+            while (__builtin_amdgcn_readfirstlane(lds_acquire(&taken[g])) < b) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int i = 0; i < 16; i++) slot[i][lane] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+            lds_release(&ready[g], b + 1);
+        };
+        fr half = fr_zero();
+        bool have_half = pend != 0;
+        if (have_half) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) half.v[i] = st[(size_t)(8 + i) * n_inst + j];
+        }
+        uint32_t b = 0;
+        if (plane == 0) {
+            const fr* p0 = msgs + ((K - q) & (K - 1));
+            fr nx = fr_load(p0);
+            for (size_t r = 0; r < nrows; r++) {
+                const fr e = nx;
+                if (r + 1 < nrows) nx = fr_load(p0 + (r + 1) * (size_t)K);
+                if (have_half) {
+                    uint32_t w[64];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { w[i] = half.v[i]; w[8 + i] = e.v[i]; }
+                    publish(w, b++);
+                    have_half = false;
+                } else {
+                    half = e;
+                    have_half = true;
+                }
+            }
+        } else {
+            uint4 (*stg)[64] = stage[g];
+            const uint32_t rho = lane >> 3;
+            const fr* zb = Z + (size_t)(plane - 1) * K + 8 * gi + (lane & 7u);      // + row * 3K + p * B
+            fr in[8];
+            auto load_batch = [&](size_t m0) {
+                const size_t row = m0 + rho;
+                // the base is made opaque HERE: otherwise the loads of the next batch are hoisted above the butterfly of the current one
+                // (read-only, no-alias memory) and 64 more registers are live across it
+                const fr* zr = zb + row * (3 * (size_t)K);
+                asm volatile("" : "+v"(zr) : : "memory");
+                if (row < nrows) {
+#pragma unroll
+                    for (int p = 0; p < 8; p++) in[p] = fr_load(zr + (size_t)brev3(p) * B);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 8; p++) in[p] = fr_zero();
+                }
+            };
+            load_batch(0);
+#pragma unroll 1
+            for (size_t m0 = 0; m0 < nrows; m0 += 8) {
+                {
+                    f29 a[8];
+#pragma unroll
+                    for (int p = 0; p < 8; p++) a[p] = unpack29(in[p]);
+                    radix8_dit(a, w8);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the previous batch's stage reads are done (same wave, in order)
+#pragma unroll
+                    for (int q1 = 0; q1 < 8; q1++) {
+                        const fr c = pack29(f29_canon(a[q1]));
+                        stg[2 * rho][q1 * 8 + (lane & 7u)] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+                        stg[2 * rho + 1][q1 * 8 + (lane & 7u)] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                load_batch(m0 + 8);              // in flight under the schedule expansions below (unconditional: rows past the end load
+                                                 // nothing, and `in` is dead across the butterfly instead of loop-carried)
+                const uint32_t cnt = nrows - m0 < 8 ? (uint32_t)(nrows - m0) : 8u;
+#pragma unroll 1
+                for (uint32_t s = 0; s < cnt; s++) {
+                    const uint4 lo = stg[2 * s][lane], hi = stg[2 * s + 1][lane];
+                    if (have_half) {
+                        uint32_t w[64];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) w[i] = half.v[i];
+                        w[8] = lo.x; w[9] = lo.y; w[10] = lo.z; w[11] = lo.w; w[12] = hi.x; w[13] = hi.y; w[14] = hi.z; w[15] = hi.w;
+                        publish(w, b++);
+                        have_half = false;
+                    } else {
+                        half.v[0] = lo.x; half.v[1] = lo.y; half.v[2] = lo.z; half.v[3] = lo.w;
+                        half.v[4] = hi.x; half.v[5] = hi.y; half.v[6] = hi.z; half.v[7] = hi.w;
+                        have_half = true;
+                    }
+                }
+            }
+        }
+        if (have_half && nrows) {         // odd tail: keep the element for the next call / final
+#pragma unroll
+            for (int i = 0; i < 8; i++) st[(size_t)(8 + i) * n_inst + j] = half.v[i];
+        }
+        return;
+    }
+
+    // ---- consumer (as in k_sha_update_rows_ws)
+    if (!nblocks) return;
+    uint32_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = st[(size_t)i * n_inst + j];
+    uint32_t ka[64], kb[64];
+    auto fetch = [&](uint32_t (&dst)[64], uint32_t upto) {
+        while (__builtin_amdgcn_readfirstlane(lds_acquire(&ready[g])) < upto) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const uint4 v = slot[i][lane]; dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w; }
+    };
+    auto block = [&](const uint32_t (&cur)[64], uint32_t (&nxt)[64], uint32_t b) {
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], gg = h[6], hh = h[7];
+        sha256_rounds<0, 16>(a, bb, c, d, e, f, gg, hh, cur);
+        const bool more = b + 1 < nblocks;
+        if (more) fetch(nxt, b + 2);
+        sha256_rounds<16, 64>(a, bb, c, d, e, f, gg, hh, cur);
+        if (more) lds_release(&taken[g], b + 2);
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += gg; h[7] += hh;
+    };
+    fetch(ka, 1);
+    lds_release(&taken[g], 1);
+    for (uint32_t b = 0; b < nblocks; b += 2) {
+        block(ka, kb, b);
+        if (b + 1 < nblocks) block(kb, ka, b + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) st[(size_t)i * n_inst + j] = h[i];
+}
+
 // padding + length (shader/sha256.wgsl:180-224); does not modify the state
 // pk != 0: plane-major instances (see k_sha_update_rows): instance j = r*pk + q is leaf 4q + r
 __global__ void k_sha_final(const uint32_t* __restrict__ st, size_t n_inst, uint64_t rows_total, uint32_t* __restrict__ digests, uint32_t pk) {
@@ -303,6 +476,27 @@ void launch_sha_update_rows(hipStream_t s, uint32_t* state, size_t n_inst, const
     }
     hipLaunchKernelGGL(k_sha_update_rows, dim3((uint32_t)((n_inst + bs - 1) / bs)), dim3(bs), 0, s, state, n_inst, rows, row_stride,
                        nrows, rows_before, plane_k, msgs);
+}
+// column hash of `nrows` rows whose cosets 1..3 are Z tiles (rows x 3k, the layout k_encode_tiles writes) and whose coset 0 is the
+// message row; plane-major instances like launch_sha_update_rows(.., plane_k = k, msgs).  false: k outside the tiled encoder's range
+template <int LOG2B>
+static void sha_update_rows_z_t(hipStream_t s, uint32_t* state, const fr* z, size_t nrows, uint64_t rows_before, const fr* msgs, const f29wt w8) {
+    constexpr uint32_t groups = 4u * ((1u << LOG2B) / 8u);
+    if (lig::knobs().sha_ws == 1) hipLaunchKernelGGL((k_sha_update_rows_z<LOG2B, 1>), dim3(groups), dim3(128), 0, s, state, z, nrows, rows_before, msgs, w8);
+    else hipLaunchKernelGGL((k_sha_update_rows_z<LOG2B, 2>), dim3(groups / 2), dim3(256), 0, s, state, z, nrows, rows_before, msgs, w8);
+}
+bool launch_sha_update_rows_z(hipStream_t s, uint32_t* state, const EncodePlan& ep, const fr* z, size_t nrows, uint64_t rows_before, const fr* msgs) {
+    if (!nrows) return true;
+    switch (ep.log2B) {
+        case 6: sha_update_rows_z_t<6>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        case 7: sha_update_rows_z_t<7>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        case 8: sha_update_rows_z_t<8>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        case 9: sha_update_rows_z_t<9>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        case 10: sha_update_rows_z_t<10>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        case 11: sha_update_rows_z_t<11>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        case 12: sha_update_rows_z_t<12>(s, state, z, nrows, rows_before, msgs, ep.w8_fwd); return true;
+        default: return false;
+    }
 }
 void launch_sha_final(hipStream_t s, const uint32_t* state, size_t n_inst, uint64_t rows_total, uint32_t* digests, uint32_t plane_k) {
     hipLaunchKernelGGL(k_sha_final, dim3((uint32_t)((n_inst + 63) / 64)), dim3(64), 0, s, state, n_inst, rows_total, digests, plane_k);

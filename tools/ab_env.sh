@@ -7,7 +7,7 @@ mkdir -p "$(dirname "$out")"; : > "$out"
 for r in $(seq 1 "$rounds"); do
   for v in "$@"; do
     name=${v%%:*}; envs=${v#*:}
-    line=$(env $envs python bench.py --no-cpu-baseline --no-h2d --no-verify --steps 20 --warmup 3 2>/dev/null | tail -1 |
+    line=$(env $envs python bench.py --no-cpu-baseline --no-h2d --no-verify --quad-mix 0 --steps 20 --warmup 3 2>/dev/null | tail -1 |
            python tools/pick.py value ms_per_step proof_wall_ms config.stage_ms roofline.avg_launch_ms config.proof_equals_oracle_pin)
     echo "round $r $name [$envs] $line" | tee -a "$out"
   done
