@@ -76,7 +76,8 @@ int lig_internal_comm_fault(lig_ctx* c, bool stream_ordered);
 
 // mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes) /
 // ENC_ZRES (4, rows x 3k, cosets 1..3 as the tile kernel's Z tiles: no last radix-8 pass; fast encoder only)
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr);
+// phases (fast encoder, rows <= one launch group): 1 = K1 only, 14 = everything after K1 (the Y scratch carries the rows in between)
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr, int phases = 15);
 // cw2_z: the rows of cw2 are Z tiles of coset 2 (lig::ENC_ZRES) instead of coset values
 int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on = nullptr,
                             bool cw2_z = false);

@@ -20,7 +20,8 @@ struct Knobs {
     uint32_t sha_block = 256;          // LIG_SHA_BLOCK      workgroup size of the column hash
     int      sha_ws = 2;               // LIG_SHA_WS         column hash: 0 one wave per 64 columns; 1 / 2 / 4 wave-specialised (producer + consumer waves), groups per workgroup
     uint32_t aes_blocks = 0;           // LIG_AES_BLOCKS     persistent workgroups of the big sampler launches (0: two per CU)
-    int      sha_gate = 1;             // LIG_SHA_GATE       place every chunk's hash before the encode stream goes on
+    int      sha_gate = 1;             // LIG_SHA_GATE       1: place every chunk's hash before the encode stream goes on; 2: the next chunk's K1 runs first, ALONE (the hash
+                                       //                    waits for it), then the hash is placed, then the tile kernel goes on
     size_t   sha_gate_rows = 2;        // LIG_SHA_GATE_ROWS  rows hashed before the encode stream is released
     int      sha_prio = 0;             // LIG_SHA_PRIO       1: the side stream (column hash, samplers) is a high-priority stream
     int      ctx_low_prio_every = 0;   // LIG_CTX_LOW_PRIO_EVERY  n > 0: every n-th context of the process gets lowest-priority streams (a "filler" proof)
@@ -112,7 +113,8 @@ bool encode_fast_supported(uint32_t k);
 enum { ENC_FULL = 0, ENC_HALF = 1, ENC_PLANAR = 2, ENC_DOT = 3, ENC_ZRES = 4 };
 struct EncodeDot { const fr* cw2; size_t cw2_stride; uint32_t group_rows; fr* part; bool cw2_z = false; };
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y,
-                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, int mode = ENC_FULL, const EncodeDot* dot = nullptr);
+                      fr* scratch_z, size_t rows, hipEvent_t ev0, hipEvent_t ev1, int mode = ENC_FULL, const EncodeDot* dot = nullptr,
+                      int phases = 15);      // phases: 1 = K1 only (into the Y scratch), 14 = the rest (from the Y scratch): a caller that runs K1 of the next chunk ahead
 
 // The batched prover's resident codeword matrix: message rows (coset 0, reversed) + the three computed cosets as planes.
 struct CwView {

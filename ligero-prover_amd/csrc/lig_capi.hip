@@ -557,11 +557,12 @@ int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ens
 // shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
 // codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
 // (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on) {
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on, int phases) {
     const bool half = mode == lig::ENC_HALF;
     const size_t out_stride = half ? (size_t)c->k : (mode == lig::ENC_PLANAR || mode == lig::ENC_ZRES) ? 3 * (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
     if (mode == lig::ENC_ZRES && !c->fast) return LIG_E_STATE;       // Z tiles exist only in the tiled encoder
+    if (phases != 15 && (!c->fast || rows > lig::knobs().encode_chunk)) return LIG_E_STATE;      // split phases share ONE Y scratch
     if (c->fast) {
         // rows per launch group: the Y/Z scratch (1 MiB/row) should stay inside the 256 MiB L3 so that K3's
         // re-read of Z does not go to HBM.  LIG_ENCODE_CHUNK overrides for experiments.
@@ -571,7 +572,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
         for (size_t r0 = 0; r0 < rows; r0 += chunk) {
             const size_t nr = rows - r0 < chunk ? rows - r0 : chunk;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->prof_on && !half && nr > 1) {      // only the full (3 computed cosets) multi-row launches of the dominant kernel are bracketed
+            if (c->prof_on && !half && nr > 1 && (phases & 6)) {      // only the full (3 computed cosets) multi-row launches of the dominant kernel are bracketed
                 if (c->prof_used == c->prof_events.size()) {
                     hipEvent_t a, b;
                     HIP_TRY(c, hipEventCreate(&a)); HIP_TRY(c, hipEventCreate(&b));
@@ -581,7 +582,7 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                 c->prof_used++; c->prof_rows += nr;
             }
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
-                                  c->scratch_z, nr, e0, e1, mode);
+                                  c->scratch_z, nr, e0, e1, mode, nullptr, phases);
         }
     } else if (mode == lig::ENC_PLANAR) {
         // generic path (k > 32768), planar: codewords of a few rows at a time in the Z scratch, then one strided copy per plane

@@ -329,10 +329,10 @@ bool encode_fast_supported(uint32_t k) { return k >= 512 && k <= 32768 && (k & (
 // 3 = coset 2 only, not stored: its products with the rows of dot.cw2 are added to the group partials dot.part
 template <int LOG2B>
 static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* cw, fr* Y, fr* Z, size_t rows,
-                          hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot) {
+                          hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot, int phases) {
     constexpr uint32_t B = 1u << LOG2B;
     const size_t th1 = rows * B;
-    const int kmask = lig::knobs().encode_kmask;       // experiments only: 1 = K1, 6 = K2, 8 = K3
+    const int kmask = lig::knobs().encode_kmask & phases;       // 1 = K1, 6 = K2, 8 = K3 (the knob: experiments only; phases: a caller that pipelines K1 ahead)
     // K1 / K3 have no LDS and no barrier: their workgroup size is free (LIG_K13_BLOCK, experiments)
     const uint32_t bs13 = lig::knobs().k13_block;
     if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + bs13 - 1) / bs13)), dim3(bs13), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
@@ -378,15 +378,15 @@ bool launch_gather_rows_z(hipStream_t s, const EncodePlan& ep, CwView cw, size_t
 }
 
 void encode_rows_fast(hipStream_t s, const EncodePlan& ep, const fr* msgs, fr* out, fr* scratch_y, fr* scratch_z, size_t rows,
-                      hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot) {
+                      hipEvent_t ev0, hipEvent_t ev1, int mode, const EncodeDot* dot, int phases) {
     switch (ep.log2B) {
-        case 6: encode_rows_t<6>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
-        case 7: encode_rows_t<7>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
-        case 8: encode_rows_t<8>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
-        case 9: encode_rows_t<9>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
-        case 10: encode_rows_t<10>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
-        case 11: encode_rows_t<11>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
-        case 12: encode_rows_t<12>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot); break;
+        case 6: encode_rows_t<6>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
+        case 7: encode_rows_t<7>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
+        case 8: encode_rows_t<8>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
+        case 9: encode_rows_t<9>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
+        case 10: encode_rows_t<10>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
+        case 11: encode_rows_t<11>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
+        case 12: encode_rows_t<12>(s, ep, msgs, out, scratch_y, scratch_z, rows, ev0, ev1, mode, dot, phases); break;
         default: break;
     }
 }

@@ -101,7 +101,7 @@ struct lig_trace {
     uint8_t* h_enc = nullptr;                              // pinned: 3 x n accumulators
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
-    hipEvent_t ev_gate = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_gate = nullptr, ev_k1 = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
     uint8_t* h_small = nullptr;                            // pinned: the device-side sum (32 B) | 3 decoded accumulators (3 x n x 32)
 };
 
@@ -286,6 +286,7 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
         HIP_TRY(c, hipEventCreateWithFlags(&T->ev_used[i], hipEventDisableTiming));
     }
     HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&T->ev_k1, hipEventDisableTiming));
     for (int a3 = 0; a3 < 3; a3++) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_acc[a3], hipEventDisableTiming));
     if (!T->triples.empty()) HIP_TRY(c, hipMemcpyAsync(T->tri_dev, T->triples.data(), T->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
     {   // a short first chunk (the column hash -- the longest chain of stage 1 -- starts after 128 rows instead of 512) and a short
@@ -356,7 +357,8 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     TRY(lig_internal_encode_2k_rows(c, mlin, 2, s_sha));      // mlin and mquad are adjacent rows: one pass
     uint64_t absorbed = 0;
     size_t pr_i = 0;
-    for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+    // what has to be on the encode stream in front of chunk ci's first kernel: its rows have arrived, are expanded, have their pads
+    auto pre = [&](size_t ci) -> int {
         const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
         if (streamed) {
             if (T->up_by_thread) HIP_TRY(c, hipStreamWaitValue32(s_enc, T->up_flag_dev + ci, T->up_seq, hipStreamWaitValueGte, 0xffffffffu));
@@ -368,10 +370,31 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
                 lig::launch_rng_fill_rows(s_enc, c->rk_dev, pr.pos, T->msgs + pr.first * (size_t)k, pr.count, pad, k, l, 1, pad);
             }
         }
-        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, T->zres ? lig::ENC_ZRES : lig::ENC_PLANAR, s_enc));
+        return LIG_OK;
+    };
+    const int enc_mode = T->zres ? lig::ENC_ZRES : lig::ENC_PLANAR;
+    const int gate = lig::knobs().sha_gate;
+    // LIG_SHA_GATE=2 (round 6): K1 of chunk ci+1 is queued BEHIND the last kernel of chunk ci and runs alone -- the hash of chunk ci
+    // waits for it (K1 is latency-bound: next to the hash waves it takes 2.2x as long, on the critical path of a lone proof) --
+    // then the hash is placed, then the tile kernel of chunk ci+1 goes on.  (One Y scratch: K1 of ci+1 starts after chunk ci is done with it.)
+    const bool k1_ahead = gate == 2 && c->fast && lig_tune::CHUNK <= lig::knobs().encode_chunk;
+    if (k1_ahead && !T->sched1.empty()) {
+        TRY(pre(0));
+        TRY(lig_internal_encode_rows(c, T->msgs, T->cw, T->sched1[0].second - T->sched1[0].first, enc_mode, s_enc, 1));
+    }
+    for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+        const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
+        if (!k1_ahead) TRY(pre(ci));
+        TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, enc_mode, s_enc, k1_ahead ? 14 : 15));
         HIP_TRY(c, hipEventRecord(c->ev_fork, s_enc));
         HIP_TRY(c, hipStreamWaitEvent(s_sha, c->ev_fork, 0));
-        const int gate = lig::knobs().sha_gate;
+        if (k1_ahead && ci + 1 < T->sched1.size()) {
+            const size_t b1 = T->sched1[ci + 1].first, nb1 = T->sched1[ci + 1].second - b1;
+            TRY(pre(ci + 1));
+            TRY(lig_internal_encode_rows(c, T->msgs + b1 * k, T->cw + b1 * k3, nb1, enc_mode, s_enc, 1));
+            HIP_TRY(c, hipEventRecord(T->ev_k1, s_enc));
+            HIP_TRY(c, hipStreamWaitEvent(s_sha, T->ev_k1, 0));
+        }
         const size_t g = lig::knobs().sha_gate_rows;
         if (T->zres) {
             // (same placement rule as below; the gate is a whole batch of the in-hash butterflies: 8 rows)
@@ -750,6 +773,7 @@ void lig_trace_destroy(lig_trace* T) {
         (void)hipFree(p);
     for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
     if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
+    if (T->ev_k1) (void)hipEventDestroy(T->ev_k1);
     for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
     for (hipEvent_t e : T->ev_up) (void)hipEventDestroy(e);
     if (T->up_flag) (void)hipHostFree((void*)T->up_flag);

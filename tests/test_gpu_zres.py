@@ -61,16 +61,19 @@ def run_cases(tmp_path, cases, timeout=600, env_extra=None):
     return json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("[")][-1])
 
 
-def test_zres_small_shapes_equal_the_oracle(tmp_path):
+@pytest.mark.parametrize("env", [dict(LIG_ZRES="1"), dict(LIG_ZRES="1", LIG_SHA_GATE="2"), dict(LIG_ZRES="0", LIG_SHA_GATE="2")],
+                         ids=["zres", "zres-k1ahead", "planar-k1ahead"])
+def test_zres_small_shapes_equal_the_oracle(tmp_path, env):
     """k = 512 / 1024 (tile lengths 64 and 128): empty statement, one row, odd and even row counts, more rows than one batch of
     the in-hash butterflies (8), chunk boundaries of the 512-row launches (pending half blocks between launches), and a trace with
-    quadratic triples (which keeps the planar matrix: the knob must not change its proof either)"""
+    quadratic triples (which keeps the planar matrix: the knob must not change its proof either).  Also with LIG_SHA_GATE=2 (K1 of the
+    next chunk pipelined ahead of the hash placement), with and without the resident tiles."""
     cases = [dict(shape=s) for s in [
         (320, 512, 2048, 0, 0), (320, 512, 2048, 1, 0), (320, 512, 2048, 320 * 2, 0), (320, 512, 2048, 320 * 7 + 5, 0),
         (320, 512, 2048, 320 * 8, 0), (320, 512, 2048, 320 * 9, 0), (320, 512, 2048, 320 * 23 + 1, 0),
         (320, 512, 2048, 320 * 511 + 3, 0), (320, 512, 2048, 320 * 641, 0), (320, 512, 2048, 320 * 1290, 0),
         (832, 1024, 4096, 832 * 30 + 7, 0), (320, 512, 2048, 640, 330)]]
-    for r in run_cases(tmp_path, cases):
+    for r in run_cases(tmp_path, cases, env_extra=env):
         assert r["ok"] is True and r["valid"] == [1, 1, 1], r
 
 
