@@ -62,6 +62,16 @@ int lig_read(lig_ctx *ctx, void *host_dst, const void *src, size_t bytes);   /* 
  * the runtime stages every copy).  Replaces the std::vector `limbs_` staging of include/zkp/nonbatch_context.hpp:447. */
 int lig_host_alloc(lig_ctx *ctx, size_t bytes, void **host_ptr);
 int lig_host_free(lig_ctx *ctx, void *host_ptr);
+/* Asynchronous form of lig_write for page-locked sources (lig_host_alloc): enqueued on the context stream and NOT waited for.
+ * The source must stay untouched until a fence recorded after the call has been waited for.  Fences: lig_fence_record
+ * (re)records *fence at the current end of the context stream (allocating it when *fence == NULL), lig_fence_wait blocks the
+ * host until that point has been reached.  Used by hip_context's deferred row mode (include/lig_hip_context.hpp): the
+ * reference's per-row wgpuQueueWriteBuffer (src/webgpu/device_context.cpp:364-380) batched into one transfer per <= 512 rows
+ * that runs under the caller's next rows. */
+int  lig_write_async(lig_ctx *ctx, void *dst, const void *pinned_src, size_t bytes);
+int  lig_fence_record(lig_ctx *ctx, void **fence);
+int  lig_fence_wait(lig_ctx *ctx, void *fence);
+void lig_fence_destroy(lig_ctx *ctx, void *fence);
 
 /* ---- Reed-Solomon transforms on ONE n-element buffer, in place
  * (encode_ntt_device / decode_ntt_device / ntt_{forward,inverse}_{k,2k,n}: engine.cpp:755-968) */

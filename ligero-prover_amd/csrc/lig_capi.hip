@@ -514,6 +514,35 @@ int lig_write(lig_ctx* c, void* dst, const void* src, size_t bytes) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));    // the host buffer may be reused right away (wgpuQueueWriteBuffer semantics)
     return LIG_OK;
 }
+int lig_write_async(lig_ctx* c, void* dst, const void* pinned_src, size_t bytes) {
+    CHECK_CTX(c);
+    if (!bytes) return LIG_OK;
+    if (!dst || !pinned_src) return LIG_E_ARG;
+    HIP_TRY(c, hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, c->stream));
+    return LIG_OK;
+}
+int lig_fence_record(lig_ctx* c, void** fence) {
+    CHECK_CTX(c);
+    if (!fence) return LIG_E_ARG;
+    if (!*fence) {
+        hipEvent_t ev;
+        HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        *fence = (void*)ev;
+    }
+    HIP_TRY(c, hipEventRecord((hipEvent_t)*fence, c->stream));
+    return LIG_OK;
+}
+int lig_fence_wait(lig_ctx* c, void* fence) {
+    CHECK_CTX(c);
+    if (!fence) return LIG_OK;
+    HIP_TRY(c, hipEventSynchronize((hipEvent_t)fence));
+    return LIG_OK;
+}
+void lig_fence_destroy(lig_ctx* c, void* fence) {
+    if (!c || !fence) return;
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    (void)hipEventDestroy((hipEvent_t)fence);
+}
 int lig_write_clear(lig_ctx* c, void* dst, size_t dst_bytes, const void* src, size_t bytes) {
     CHECK_CTX(c);
     if (bytes > dst_bytes) FAIL(c, LIG_E_ARG, "write_clear: source larger than destination");
@@ -909,9 +938,11 @@ int lig_rlc_rows(lig_ctx* c, const void* U, const void* Rn, size_t rows, const u
         HIP_TRY(c, hipMalloc((void**)&c->tri_dev, 3 * n_triples * sizeof(uint32_t)));
         c->tri_cap = n_triples;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->small_dev, sc.data(), sc.size() * sizeof(fr), hipMemcpyHostToDevice, c->stream));
-    if (n_triples) HIP_TRY(c, hipMemcpyAsync(c->tri_dev, triples_host, 3 * n_triples * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));    // sc / triples_host are host temporaries
+    // sc / triples_host are host temporaries: through the pinned staging ring + a copy kernel, so that the call does not wait for
+    // what is queued on the stream before it (a deferred-row flush of hip_context queues a 134 MB upload and an encode first)
+    rc = lig_internal_upload_small(c, c->small_dev, sc.data(), sc.size() * sizeof(fr), c->stream);
+    if (rc != LIG_OK) return rc;
+    if (n_triples) { rc = lig_internal_upload_small(c, c->tri_dev, triples_host, 3 * n_triples * sizeof(uint32_t), c->stream); if (rc != LIG_OK) return rc; }
     lig::launch_rlc_rows(c->stream, (const fr*)U, (const fr*)Rn, rows, c->n, c->small_dev, (fr*)code, (fr*)lin, c->tri_dev,
                          c->small_dev + rows, n_triples, (fr*)quad);
     HIP_TRY(c, hipGetLastError());

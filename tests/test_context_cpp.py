@@ -220,3 +220,40 @@ def test_sharded_row_batcher_gives_the_oracle_envelope_on_every_rank(world, n_li
     outs = mr.run_ranks(lambda r: [exe, str(r), str(world), name, str(n_lin), str(n_quad)], world, env, timeout=300)
     for r, (o, e) in enumerate(outs):
         assert ("rank %d: equal 1 " % r) in o, (o, e[-2000:])
+
+
+S3SRC = os.path.join(ROOT, "tests", "cpp", "stage123_rows.cpp")
+S3EXE = os.path.join(ROOT, "tests", "cpp", "stage123_rows")
+
+
+def build_stage123_exe():
+    mod = hip_lib.load()
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    odir = os.path.join(ROOT, "oracle")
+    ol.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), S3SRC, "-L" + os.path.dirname(mod.LIB_PATH), "-llig_hip",
+                           "-L" + odir, "-llig_oracle", "-Wl,-rpath," + os.path.dirname(mod.LIB_PATH), "-Wl,-rpath," + odir, "-o", S3EXE])
+    return S3EXE
+
+
+def test_three_stage_per_row_driver_compiles_and_links():
+    assert os.path.exists(build_stage123_exe())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("constraints,n_quad,k,deferred", [
+    (-700, 330, 512, 0),            # eager: every executor call is a launch (the literal three-line drop-in)
+    (-700, 330, 512, 512),          # deferred rows: linear rows batched, the triples' check_quadratic falls back (flush + eager)
+    (-(320 * 40 + 7), 0, 512, 5),   # a 5-row ring: flushes in the middle of every stage, staging halves alternate
+    (-(320 * 300), 0, 512, 128),    # stage 3's 256-slot sample ring wraps (sync_sample_to_host in the middle of the rows)
+    (-1, 0, 512, 512),              # one constraint: one row + the masks
+    (17, 0, 8192, 512),             # production geometry, 17 rows + masks
+])
+def test_three_stage_per_row_driver_gives_the_oracle_envelope(constraints, n_quad, k, deferred):
+    """tests/cpp/stage123_rows.cpp: miniatures of nonbatch_stage{1,2,3}_context (nonbatch_context.hpp:445-471,654-780,924-970) written
+    against the Executor template parameter drive ligero::hip_context row by row through a complete proof -- eagerly and in the
+    deferred row mode (set_deferred_rows: the same calls recorded and flushed through the batched entry points); the envelope
+    assembled from what the executor returned equals the oracle's reference-structured prover's, the self-check predicates hold"""
+    out = json.loads(subprocess.check_output([build_stage123_exe(), str(constraints), str(deferred), str(n_quad), str(k)]).decode().strip().splitlines()[-1])
+    assert out["equal"] == 1, out
