@@ -35,7 +35,7 @@ EXPORTS = [
     "lig_public_arg_bytes", "lig_instance_hash", "lig_sample_columns",
     "lig_rccl_unique_id", "lig_rccl_comm_create", "lig_rccl_comm_destroy", "lig_rccl_available", "lig_rccl_comm_count",
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
-    "lig_device_pci_bus_id", "lig_device_peer_access", "lig_host_alloc", "lig_host_free", "lig_rows_push_rands", "lig_rows_push_rands_sparse",
+    "lig_device_pci_bus_id", "lig_device_peer_access", "lig_host_alloc", "lig_host_free", "lig_write_async", "lig_fence_record", "lig_fence_wait", "lig_fence_destroy", "lig_rows_push_rands", "lig_rows_push_rands_sparse",
     "lig_abi_sizes", "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
 ]
 
@@ -214,6 +214,11 @@ def load_library():
     L.lig_device_peer_access.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lig_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.lig_host_free.argtypes = [vp, vp]
+    L.lig_write_async.argtypes = [vp, vp, vp, sz]
+    L.lig_fence_record.argtypes = [vp, C.POINTER(vp)]
+    L.lig_fence_wait.argtypes = [vp, vp]
+    L.lig_fence_destroy.argtypes = [vp, vp]
+    L.lig_fence_destroy.restype = None
     L.lig_rows_push_rands.argtypes = [vp, u64, u64, vp]
     L.lig_rows_push_rands_sparse.argtypes = [vp, u64, u64, vp, vp]
     L.lig_profile_enable.argtypes = [vp, C.c_int]
