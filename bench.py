@@ -686,9 +686,96 @@ def cpu_baseline(workload_name, budget_s=20.0):
                       % (rows, rows * L_, cores, sum(sta), sta[0], sta[1], sta[2], walla, rows1, sum(st1), sum(st0_1), sum(st0_a), 1e3 * t_row)}
 
 
+def gpus_sweep(a, argv):
+    """`python bench.py --gpus-sweep 1,2,4,8`: the bench once per N (each run is its own `bench.py --gpus N`, ranks launched by the run itself),
+    one compact JSON line per N as it finishes -- the four figures north_star asks for: `value` (independent traces: weak scaling),
+    `sharded` (ONE 2^26 trace over the N ranks: strong scaling), the number of ranks the RCCL communicator had, and the dominant kernel's
+    HBM fraction -- and a last line with all of them.  Scaling efficiency is for the reader (the driver) to compute.  On a box with fewer
+    GPUs than N the sweep only runs when LIG_BENCH_SHARE_GPU=1 (all ranks on GPU 0, collectives through comm_ipc over a gloo rendezvous):
+    every line then says `shared_device: true` -- a functional run of the N-rank code paths, NOT a scaling measurement."""
+    import subprocess
+    ns = [int(x) for x in a.gpus_sweep.split(",") if x]
+    if not ns or min(ns) < 1:
+        raise SystemExit("bench.py: --gpus-sweep takes a comma-separated list of GPU counts, e.g. 1,2,4,8")
+    rest, skip = [], False
+    for tok in argv:                      # this run's other flags go to every N
+        if skip:
+            skip = False
+            continue
+        if tok in ("--gpus-sweep", "--gpus"):
+            skip = True
+            continue
+        if tok.startswith("--gpus-sweep=") or tok.startswith("--gpus="):
+            continue
+        rest.append(tok)
+    try:
+        import torch
+        n_dev = torch.cuda.device_count()
+    except Exception:                     # (the stub workload runs without torch devices)
+        n_dev = 0
+    share = os.environ.get("LIG_BENCH_SHARE_GPU") == "1"
+    lines = []
+    for n in ns:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+        args = ["--gpus", str(n)] + rest
+        shared = a.workload != "stub" and n > 1 and n_dev < n
+        if shared and not share:
+            line = {"n_gpus": n, "skipped": "%d GPUs visible (set LIG_BENCH_SHARE_GPU=1 for a functional shared-device run)" % n_dev}
+            lines.append(line)
+            print(json.dumps(line), flush=True)
+            continue
+        if shared:
+            env.update(LIG_COMM="ipc", LIG_COMM_TAG="sweep%d_%d" % (os.getpid(), n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            if "--backend" not in rest:
+                args += ["--backend", "gloo"]
+        elif n == 1:
+            env.pop("LIG_BENCH_SHARE_GPU", None)
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, env=env, capture_output=True, timeout=a.sweep_timeout)
+            rc, so, se = p.returncode, p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+        except subprocess.TimeoutExpired as e:
+            rc, so, se = -9, (e.stdout or b"").decode(errors="replace"), "timeout after %d s" % a.sweep_timeout
+        full = None
+        for ln in reversed(so.splitlines()):
+            if ln.startswith("{"):
+                try:
+                    full = json.loads(ln)
+                    break
+                except ValueError:
+                    pass
+        line = {"n_gpus": n, "shared_device": bool(shared), "wall_s": round(time.perf_counter() - t0, 1)}
+        if full is None:
+            line["error"] = "rc %d: %s" % (rc, se[-400:])
+        else:
+            sh = full.get("sharded") or {}
+            line.update({
+                "metric": full.get("metric"), "unit": full.get("unit"), "value": full.get("value"), "scaling": full.get("scaling"), "ms_per_step": full.get("ms_per_step"),
+                "steps": full.get("steps"), "workload": (full.get("config") or {}).get("workload"),
+                "hbm_frac": (full.get("roofline") or {}).get("frac"),
+                "sharded": None if not sh else {k: sh.get(k) for k in ("log2_constraints", "ranks", "ms_per_proof", "constraints_per_s", "scaling", "transport", "proof_equals_oracle_pin",
+                                                                       "all_ranks_same_envelope", "rccl_ranks", "stage_ms", "error") if k in sh},
+                "rccl_ranks": sh.get("rccl_ranks"), "distinct_devices": (sh.get("devices") or {}).get("distinct"),
+            })
+            for key, v in full.items():           # the other sizes of the sharded leg (sharded_2p24, ...)
+                if key.startswith("sharded_2p") and isinstance(v, dict):
+                    line[key] = {k: v.get(k) for k in ("ms_per_proof", "constraints_per_s", "transport", "proof_equals_oracle_pin", "all_ranks_same_envelope", "error") if k in v}
+            if a.sweep_full:
+                line["line"] = full
+        lines.append(line)
+        print(json.dumps(line), flush=True)
+    print(json.dumps({"gpus_sweep": lines, "note": "per N: value = independent traces (weak), sharded = ONE trace over the ranks (strong); shared_device lines are functional "
+                                                   "runs on one GPU and carry no scaling information"}), flush=True)
+    return 0 if all("error" not in ln for ln in lines) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus-sweep", default=None, help="comma-separated GPU counts (e.g. 1,2,4,8): run the bench once per N and print one compact line per N "
+                    "(value = weak, sharded = strong, RCCL rank count, HBM fraction) plus a summary line; see gpus_sweep()")
+    ap.add_argument("--sweep-timeout", type=int, default=1500, help="--gpus-sweep: seconds one N may take")
+    ap.add_argument("--sweep-full", action="store_true", help="--gpus-sweep: embed every N's complete JSON line")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="full", choices=["full", "encode", "sharded", "stub"])
@@ -721,6 +808,8 @@ def main():
     global NO_VERIFY
     NO_VERIFY = a.no_verify
     log2c = a.log2_constraints if a.log2_constraints is not None else (20 if a.workload == "encode" else 24)
+    if a.gpus_sweep:
+        sys.exit(gpus_sweep(a, sys.argv[1:]))
     if a.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -765,11 +854,12 @@ def main():
 
     for _ in range(a.warmup):
         wl.step()
-    single_ms, single_prof = None, None
+    single_ms, single_prof, single_prof512 = None, None, None
     if hasattr(wl, "single_proof_ms"):            # latency probe: one proof at a time, dominant kernel bracketed as well
         ctx.profile_enable(True)
         single_ms = wl.single_proof_ms()
         single_prof = ctx.profile_read()
+        single_prof512 = ctx.profile_read_launches(512)
         ctx.profile_enable(False)
     fence()
     ctx.profile_enable(True)
@@ -782,6 +872,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     launches, prows, kms = ctx.profile_read()
+    launches512, kms512 = ctx.profile_read_launches(512)
     ctx.profile_enable(False)
     dt = group.max_over_ranks(dt)
 
@@ -925,6 +1016,12 @@ def main():
                          "algorithmic_bytes_per_launch": rows_per_launch * alg_bytes_per_row,
                          "avg_launch_ms": 1e3 * avg_launch_s, "rows_per_launch": rows_per_launch, "launches": launches,
                          "algorithmic_bytes_per_row": alg_bytes_per_row,
+                         # the full chunks alone (512 rows per launch): the figure a rocprofv3 kernel table lists for that launch size, so that
+                         # profiles/r0N_inflight*_kernel_stats.md can be set against this line without averaging over the six launch sizes of a proof
+                         "launches_of_512_rows": None if not launches512 else {
+                             "launches": launches512, "avg_launch_ms": kms512 / launches512,
+                             "achieved": 512 * alg_bytes_per_row / (kms512 / launches512 * 1e-3) / 1e9,
+                             "frac": 512 * alg_bytes_per_row / (kms512 / launches512 * 1e-3) / 1e9 / 8000.0},
                          "encode_row_bytes_survey_8d": (K_ + N_) * 32,
                          # the same launches priced with SURVEY 8(d)'s whole-row encode figure (read k*32 + write n*32): this kernel
                          # carries ~90 % of the encode's arithmetic, the two radix-8 passes around it move the remaining bytes
@@ -932,7 +1029,8 @@ def main():
                          "one_proof_in_flight": None if not single_prof or not single_prof[0] else {
                              "avg_launch_ms": single_prof[2] / single_prof[0], "rows_per_launch": single_prof[1] / single_prof[0],
                              "achieved": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9,
-                             "frac": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9 / 8000.0},
+                             "frac": (single_prof[1] * alg_bytes_per_row) / (single_prof[2] * 1e-3) / 1e9 / 8000.0,
+                             "avg_launch_ms_512_rows": None if not single_prof512 or not single_prof512[0] else single_prof512[1] / single_prof512[0]},
                          "note": "integer-VALU-bound kernel (~185k 256-bit Montgomery products per row in this kernel: since round 2 it "
                                  "also carries the inverse tile transforms that used to be a kernel of their own, same bytes, more "
                                  "arithmetic; v_mad_u64_u32 issues at half the simple-ALU rate); the HBM fraction is small by "

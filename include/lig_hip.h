@@ -316,6 +316,16 @@ int lig_rows_push_rands_sparse(lig_trace *trace, uint64_t first_row, uint64_t n_
  * after lig_rows_commit, BEFORE lig_rows_prove of the committed trace: the new rows then go to a second message matrix
  * and arrive while the current trace is being proved (commit(i) -> restart(i+1) -> prove(i) -> commit(i+1) -> ...). */
 int lig_rows_restart(lig_trace *trace, const void *msgs, int msgs_on_device);
+/* Host rows travel through one uploader thread per device that waits for every transfer on the host.  A
+ * transfer that has not completed after LIG_UPLOAD_TIMEOUT_S (default 5 s; never seen with one process per GPU) does not fail the call:
+ * lig_rows_commit / lig_rows_prove discard the stage that ran over the missing rows, wait (bounded by the same time) for the abandoned
+ * copy to leave the bus, bring the same rows again with stream-ordered copies and run the stage again -- the proof is the same proof.
+ * Only if the abandoned copy is STILL pending after that second wait (it cannot be cancelled) do the calls return LIG_E_HIP; the
+ * caller's rows and the trace's device buffers are then still referenced by a DMA transfer: keep the rows alive until
+ * *unsettled == 0 here (lig_trace_destroy keeps the device side alive by itself, lig_rows_restart / _commit refuse that trace).
+ * *retries = calls of this process that needed the second attempt on ctx's device.  No reference counterpart
+ * (src/webgpu/device_context.cpp:364-449 blocks in wgpuQueueWriteBuffer).  Either pointer may be NULL. */
+int lig_upload_health(lig_ctx *ctx, uint32_t *retries, uint32_t *unsettled);
 /* The verifier's side of a rows job (src/webgpu_verifier.cpp:263-452 with the rows of nonbatch_verifier_context,
  * include/zkp/nonbatch_context.hpp:1219-1287): begin parses the envelope, re-derives both seeds and the sample indices from the
  * job's public data (kinds, public arguments; msgs is ignored) and returns the stage-1 seed; the caller's constraint generator
@@ -420,7 +430,11 @@ void lig_shard_destroy(lig_shard *shard);
  * returns; randomness rows passed to lig_shard_rows_prove are consumed before it returns.  (Only with LIG_SHARD_UPLOADER=1 -- the round-4
  * path through the library's uploader thread, off by default: profiles/r05_rows_entry_hang.md -- host rows are read until
  * lig_shard_rows_commit has returned.)
- * FAILURE: a peer that dies, leaves or stops responding makes these calls return LIG_E_STATE (lig_comm.failed / .abort), they do not hang. ==== */
+ * FAILURE: a peer that dies, leaves or stops responding makes these calls return LIG_E_STATE (lig_comm.failed / .abort), they do not hang:
+ * every wait on the error paths and in lig_shard_destroy is a bounded poll.  If kernels queued behind the failed collective still have
+ * not drained 20 s after the communicator was aborted, the error text says "poisoned": the shard refuses further calls, lig_shard_destroy
+ * returns at once and keeps the device buffers (the queued kernels may still touch them), the rows / randomness rows handed to the failed
+ * call must stay alive, and the context must not be reused -- tear the process down. ==== */
 int lig_shard_rows_plan(const uint8_t *kinds, size_t n_rows, uint32_t world, uint64_t *rounds, uint64_t *boundaries, size_t cap);
 int lig_shard_rows_begin(lig_ctx *ctx, const lig_rows_job *job, uint32_t rank, uint32_t world, const lig_comm *comm, lig_shard **out);
 int lig_shard_rows_restart(lig_shard *shard, const void *local_msgs, int msgs_on_device);   /* next trace, same shape; after lig_shard_rows_prove of the previous one (LIG_E_STATE otherwise) */
@@ -439,6 +453,9 @@ void lig_abi_sizes(uint32_t out[LIG_ABI_STRUCTS]);
  * and returns the number of bracketed launches, the rows they covered and the summed kernel time. */
 int lig_profile_enable(lig_ctx *ctx, int on);
 int lig_profile_read(lig_ctx *ctx, uint64_t *launches, uint64_t *rows, double *total_ms);
+/* the same restricted to the bracketed launches of exactly rows_in_launch rows (512 = the full chunks: what a rocprofv3 kernel table
+ * lists per launch size) */
+int lig_profile_read_launches(lig_ctx *ctx, uint32_t rows_in_launch, uint64_t *launches, double *total_ms);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ EXPORTS = [
     "lig_shard_plan", "lig_ipc_comm_create", "lig_ipc_comm_destroy",
     "lig_device_pci_bus_id", "lig_device_peer_access", "lig_host_alloc", "lig_host_free", "lig_write_async", "lig_fence_record", "lig_fence_wait", "lig_fence_destroy", "lig_rows_push_rands", "lig_rows_push_rands_sparse",
     "lig_abi_sizes", "lig_shard_rows_plan", "lig_shard_rows_begin", "lig_shard_rows_restart", "lig_shard_rows_commit", "lig_shard_rows_prove",
+    "lig_upload_health", "lig_profile_read_launches",
 ]
 
 ROW_KINDS = dict(LINEAR=0, QX=1, QY=2, QZ=3, INIT=4, BIT=5, EQX=6, EQY=7, BQX=8, BQY=9, BQZ=10)
@@ -220,9 +221,11 @@ def load_library():
     L.lig_fence_destroy.argtypes = [vp, vp]
     L.lig_fence_destroy.restype = None
     L.lig_rows_push_rands.argtypes = [vp, u64, u64, vp]
+    L.lig_upload_health.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.lig_rows_push_rands_sparse.argtypes = [vp, u64, u64, vp, vp]
     L.lig_profile_enable.argtypes = [vp, C.c_int]
     L.lig_profile_read.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.lig_profile_read_launches.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(C.c_double)]
     return L
 
 
@@ -683,6 +686,12 @@ class Context:
     def host_free(self, p):
         self.check(self.L.lig_host_free(self.h, p))
 
+    def upload_health(self):
+        """lig_upload_health -> (retries, unsettled): calls that re-made a timed-out upload / abandoned transfers still pending"""
+        r, u = C.c_uint32(0), C.c_uint32(0)
+        self.check(self.L.lig_upload_health(self.h, C.byref(r), C.byref(u)))
+        return r.value, u.value
+
     def rows_push_rands(self, trace, first_row, n_rows, host_ptr):
         """lig_rows_push_rands: randomness rows [first_row, first_row + n_rows), host memory valid until rows_prove returns"""
         self.check(self.L.lig_rows_push_rands(trace, first_row, n_rows, C.c_void_p(host_ptr)))
@@ -734,6 +743,12 @@ class Context:
         a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
         self.check(self.L.lig_profile_read(self.h, C.byref(a), C.byref(b), C.byref(ms)))
         return a.value, b.value, ms.value
+
+    def profile_read_launches(self, rows_in_launch):
+        """lig_profile_read_launches -> (launches of exactly that many rows, their summed ms)"""
+        a, ms = C.c_uint64(), C.c_double()
+        self.check(self.L.lig_profile_read_launches(self.h, rows_in_launch, C.byref(a), C.byref(ms)))
+        return a.value, ms.value
 
     def rng_fill(self, key, first_elem, out, count):
         k = np.frombuffer(bytes(key), dtype=np.uint8).copy()

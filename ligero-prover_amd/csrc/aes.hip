@@ -74,16 +74,31 @@ __device__ __forceinline__ uint32_t x3(uint32_t a, uint32_t b, uint32_t c) { ret
 // the two lanes of a half-wave that share a replica can collide (probability 1/2 when their bytes differ) -- ~1.25 cycles
 // per half-wave instead of ~3.5.  64 KiB of LDS per workgroup, so the big fills run as <= 2 persistent workgroups per CU;
 // the round keys are read through scalar loads (uniform addresses), not from LDS.
-template <int LOGR>
-__device__ __forceinline__ uint32_t te_at(const uint32_t* tl, uint32_t table, uint32_t word, int shift) {
-    // byte `shift/8` of `word` -> table index scaled by R
-    const uint32_t idx = shift == 24 ? (word >> 24) : ((word >> shift) & 255u);
-    return tl[((table << 8) + idx) << LOGR];
+//
+// LAYOUT 1 (round 6, LIG_AES_LAYOUT=1; A/B in profiles/r06_sampler_layout_ab.md): the same 64 KiB ordered entry-major -- byte address of
+// (table t, entry i, replica r) = i * 256 + t * 64 + r * 4, 16 replicas -- so that the whole address of a lookup is ONE v_perm_b32:
+// {0, 0, byte n of the state word, the lane's r * 4}, the table in the instruction's immediate offset.  One VALU instruction per lookup
+// instead of two (extract + scale-and-add): 16 of the 36 VALU instructions of an AES round go.  Price: the bank of a lookup is
+// (16 t + r) mod 32 whatever the entry, so the two lanes of a half-wave that share a replica always collide (2 LDS cycles per
+// half-wave instead of ~1.25).
+struct TeView { const uint32_t* base; uint32_t off; };      // LAYOUT 0: base = the lane's replica of word (0, 0); LAYOUT 1: base = the tables, off = r * 4
+template <int LOGR, int LAYOUT>
+__device__ __forceinline__ uint32_t te_at(const TeView& tv, uint32_t table, uint32_t word, int shift) {
+    if constexpr (LAYOUT == 1) {
+        static_assert(LOGR == 4 || LAYOUT == 0, "entry-major layout: 16 replicas");
+        // selector bytes (most significant first): 0x0c = constant 0, 4 + n = byte n of src0 (the state word), 0 = byte 0 of src1 (the lane offset)
+        const uint32_t a = __builtin_amdgcn_perm(word, tv.off, 0x0c0c0000u | ((4u + (uint32_t)(shift >> 3)) << 8));
+        return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tv.base) + a + table * 64u);
+    } else {
+        // byte `shift/8` of `word` -> table index scaled by R
+        const uint32_t idx = shift == 24 ? (word >> 24) : ((word >> shift) & 255u);
+        return tv.base[((table << 8) + idx) << LOGR];
+    }
 }
-template <int LOGR>
-__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const uint32_t* tl, uint64_t block_index, uint32_t out[4]) {
+template <int LOGR, int LAYOUT>
+__device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, const TeView& tl, uint64_t block_index, uint32_t out[4]) {
     uint32_t s0 = rk[0], s1 = rk[1], s2 = (uint32_t)(block_index >> 32) ^ rk[2], s3 = (uint32_t)block_index ^ rk[3];
-#define T_(t, w, sh) te_at<LOGR>(tl, t, w, sh)
+#define T_(t, w, sh) te_at<LOGR, LAYOUT>(tl, t, w, sh)
 #pragma unroll
     for (int r = 1; r < 14; r++) {
         const uint32_t a0 = x3(T_(0, s0, 24), T_(1, s1, 16), T_(2, s2, 8)), a1 = x3(T_(0, s1, 24), T_(1, s2, 16), T_(2, s3, 8));
@@ -98,19 +113,25 @@ __device__ __forceinline__ void aes256_block(const uint32_t* __restrict__ rk, co
     out[3] = x3(T_(2, s3, 24) & 0xff000000u, T_(3, s0, 16) & 0x00ff0000u, T_(0, s1, 8) & 0x0000ff00u) ^ (T_(1, s2, 0) & 0xffu) ^ rk[59];
 #undef T_
 }
-// stage the replicated tables; returns the calling lane's view (pointer to its replica of word (0, 0))
-template <int LOGR>
-__device__ __forceinline__ const uint32_t* te_stage(uint32_t* te) {
-    for (uint32_t i = threadIdx.x; i < (1024u << LOGR); i += blockDim.x) te[i] = g_te[i >> LOGR];
-    __syncthreads();
-    return te + (threadIdx.x & ((1u << LOGR) - 1));
+// stage the replicated tables; returns the calling lane's view
+template <int LOGR, int LAYOUT>
+__device__ __forceinline__ TeView te_stage(uint32_t* te) {
+    if constexpr (LAYOUT == 1) {
+        for (uint32_t i = threadIdx.x; i < (1024u << LOGR); i += blockDim.x) te[i] = g_te[(((i >> 4) & 3u) << 8) + (i >> 6)];     // i = entry * 64 + table * 16 + replica
+        __syncthreads();
+        return TeView{te, (threadIdx.x & 15u) * 4u};
+    } else {
+        for (uint32_t i = threadIdx.x; i < (1024u << LOGR); i += blockDim.x) te[i] = g_te[i >> LOGR];
+        __syncthreads();
+        return TeView{te + (threadIdx.x & ((1u << LOGR) - 1)), 0u};
+    }
 }
 // keystream element -> field element (finite_field_gmp.hpp:66-78)
-template <int LOGR>
-__device__ __forceinline__ fr aes_field_elem(const uint32_t* __restrict__ rk, const uint32_t* tl, uint64_t elem) {
+template <int LOGR, int LAYOUT>
+__device__ __forceinline__ fr aes_field_elem(const uint32_t* __restrict__ rk, const TeView& tl, uint64_t elem) {
     uint32_t o[8];
-    aes256_block<LOGR>(rk, tl, 2 * elem, o);
-    aes256_block<LOGR>(rk, tl, 2 * elem + 1, o + 4);
+    aes256_block<LOGR, LAYOUT>(rk, tl, 2 * elem, o);
+    aes256_block<LOGR, LAYOUT>(rk, tl, 2 * elem + 1, o + 4);
     fr v;
 #pragma unroll
     for (int i = 0; i < 8; i++) v.v[i] = __builtin_bswap32(o[i]);   // keystream bytes -> little-endian limbs
@@ -119,41 +140,41 @@ __device__ __forceinline__ fr aes_field_elem(const uint32_t* __restrict__ rk, co
     return fr_reduce_once(v);   // v < 2^254 < 2p
 }
 
-template <int LOGR>
+template <int LOGR, int LAYOUT = 0>
 __global__ void __launch_bounds__(256) k_rng_fill(const uint32_t* __restrict__ rk, uint64_t first_elem, fr* __restrict__ out, size_t count) {
     __shared__ uint32_t te[1024 << LOGR];
-    const uint32_t* tl = te_stage<LOGR>(te);
+    const TeView tl = te_stage<LOGR, LAYOUT>(te);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
-        fr_store(out + e, aes_field_elem<LOGR>(rk, tl, first_elem + e));
+        fr_store(out + e, aes_field_elem<LOGR, LAYOUT>(rk, tl, first_elem + e));
 }
 
 // Row-structured fill: out[r*row_stride + col_off + i*elem_stride] = stream element (first + r*stream_stride + i),
 // r < rows, i < per_row.  One launch forms the k-l pad columns of a whole row batch, a dense randomness row
 // batch, or the (0, r, 0, r, ...) pattern of a mask row (elem_stride = 2).
-template <int LOGR>
+template <int LOGR, int LAYOUT = 0>
 __global__ void __launch_bounds__(256) k_rng_fill_rows(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ out, size_t rows,
                                                        uint32_t per_row, size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
     __shared__ uint32_t te[1024 << LOGR];
-    const uint32_t* tl = te_stage<LOGR>(te);
+    const TeView tl = te_stage<LOGR, LAYOUT>(te);
     const size_t total = rows * per_row;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / per_row;
         const uint32_t i = (uint32_t)(e - r * per_row);
-        fr_store(out + r * row_stride + col_off + (size_t)i * elem_stride, aes_field_elem<LOGR>(rk, tl, first + r * stream_stride + i));
+        fr_store(out + r * row_stride + col_off + (size_t)i * elem_stride, aes_field_elem<LOGR, LAYOUT>(rk, tl, first + r * stream_stride + i));
     }
 }
 // Dense variant for whole randomness rows: row r of `out` (k elements) = per_row stream elements followed by zeros, so the
 // buffer needs no memset beforehand (the runtime's fill kernel reaches only ~1.4 TB/s).
-template <int LOGR>
+template <int LOGR, int LAYOUT = 0>
 __global__ void __launch_bounds__(256) k_rng_fill_rows_dense(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ out, size_t rows,
                                                              uint32_t per_row, uint32_t k) {
     __shared__ uint32_t te[1024 << LOGR];
-    const uint32_t* tl = te_stage<LOGR>(te);
+    const TeView tl = te_stage<LOGR, LAYOUT>(te);
     const size_t total = rows * k;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / k;
         const uint32_t i = (uint32_t)(e - r * k);
-        fr_store(out + e, i < per_row ? aes_field_elem<LOGR>(rk, tl, first + r * (uint64_t)per_row + i) : fr_zero());
+        fr_store(out + e, i < per_row ? aes_field_elem<LOGR, LAYOUT>(rk, tl, first + r * (uint64_t)per_row + i) : fr_zero());
     }
 }
 // Sampler + stage-2 accumulation in one pass (the dense randomness rows of the synthetic stream, nonbatch_context.hpp:756-780
@@ -166,13 +187,13 @@ __global__ void __launch_bounds__(256) k_rng_fill_rows_dense(const uint32_t* __r
 #ifndef LIG_RLC_THREADS
 #define LIG_RLC_THREADS 256
 #endif
-template <int LOGR>
+template <int LOGR, int LAYOUT = 0>
 __global__ void __launch_bounds__(LIG_RLC_THREADS) k_rand_rlc(const uint32_t* __restrict__ rk, uint64_t first, fr* __restrict__ rand_out,
                                                   const fr* __restrict__ msgs, size_t rows, uint32_t per_row, uint32_t k,
                                                   const f29s* __restrict__ rc, uint32_t group_rows, fr* __restrict__ code_part,
                                                   fr* __restrict__ lin_part) {
     __shared__ uint32_t te[1024 << LOGR];
-    const uint32_t* tl = te_stage<LOGR>(te);
+    const TeView tl = te_stage<LOGR, LAYOUT>(te);
     // (-DLIG_RLC_THREADS=512: 512 threads share one 64 KiB set of replicated tables = four waves per SIMD instead of two to hide the LDS
     // latency of the 448 lookups per element behind the products; measured equal, profiles/r03_fused_rand_rlc_ab.md)
     const uint32_t jblocks = k / blockDim.x, groups = (uint32_t)((rows + group_rows - 1) / group_rows), tiles = jblocks * groups;
@@ -187,7 +208,7 @@ __global__ void __launch_bounds__(LIG_RLC_THREADS) k_rand_rlc(const uint32_t* __
             if (rc != nullptr) ac = f29_add(ac, f29_montmul(u, f29_load_tab(rc + r)));      // (rc == nullptr: the code test was accumulated up front)
             fr v = fr_zero();
             if (live) {
-                v = aes_field_elem<LOGR>(rk, tl, first + r * (uint64_t)per_row + j);
+                v = aes_field_elem<LOGR, LAYOUT>(rk, tl, first + r * (uint64_t)per_row + j);
                 al = f29_add(al, f29_montmul(u, unpack29(v)));
             }
             fr_store(rand_out + r * k + j, v);
@@ -209,11 +230,13 @@ static constexpr size_t BIG_FILL = (size_t)1 << 20;      // below this the 64 Ki
 static constexpr int REP = LIG_AES_REP;
 static constexpr uint32_t BIG_BLOCKS_MAX = 256u * (REP >= 4 ? 2u : REP == 3 ? 4u : 8u);     // persistent workgroups: as many as the LDS of 256 CUs holds
 #define BIG_BLOCKS (lig::knobs().aes_blocks ? lig::knobs().aes_blocks : BIG_BLOCKS_MAX)
+#define PERM_LAYOUT (REP == 4 && lig::knobs().aes_layout == 1)      // LIG_AES_LAYOUT=1: the entry-major tables of the big launches (one v_perm_b32 per lookup)
 static inline uint32_t small_blocks(size_t total, size_t cap) { size_t b = (total + 255) / 256; return (uint32_t)(b > cap ? cap : b); }
 void launch_rng_fill_rows_dense(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr* out, size_t rows, uint32_t per_row, uint32_t k) {
     const size_t total = rows * k;
     if (!total) return;
-    if (total >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill_rows_dense<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
+    if (total >= BIG_FILL && PERM_LAYOUT) hipLaunchKernelGGL((k_rng_fill_rows_dense<4, 1>), dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
+    else if (total >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill_rows_dense<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
     else hipLaunchKernelGGL(k_rng_fill_rows_dense<0>, dim3(small_blocks(total, 8192)), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, k);
 }
 
@@ -223,7 +246,10 @@ void launch_rand_rlc(hipStream_t s, const uint32_t* rk60_dev, uint64_t first, fr
     if (!rows) return;
     const uint32_t th = (k % LIG_RLC_THREADS == 0) ? LIG_RLC_THREADS : 256;      // k is a multiple of 256 (checked by the callers)
     const size_t tiles = (size_t)(k / th) * ((rows + group_rows - 1) / group_rows);
-    if (rows * k >= BIG_FILL)
+    if (rows * k >= BIG_FILL && PERM_LAYOUT)
+        hipLaunchKernelGGL((k_rand_rlc<4, 1>), dim3((uint32_t)(tiles < BIG_BLOCKS ? tiles : BIG_BLOCKS)), dim3(th), 0, s, rk60_dev, first, out, msgs, rows, per_row, k,
+                           rc_dev, group_rows, code_part, lin_part);
+    else if (rows * k >= BIG_FILL)
         hipLaunchKernelGGL(k_rand_rlc<REP>, dim3((uint32_t)(tiles < BIG_BLOCKS ? tiles : BIG_BLOCKS)), dim3(th), 0, s, rk60_dev, first, out, msgs, rows, per_row, k,
                            rc_dev, group_rows, code_part, lin_part);
     else
@@ -235,7 +261,9 @@ void launch_rng_fill_rows(hipStream_t s, const uint32_t* rk60_dev, uint64_t firs
                           size_t row_stride, uint32_t col_off, uint32_t elem_stride, uint64_t stream_stride) {
     const size_t total = rows * per_row;
     if (!total) return;
-    if (total >= BIG_FILL)
+    if (total >= BIG_FILL && PERM_LAYOUT)
+        hipLaunchKernelGGL((k_rng_fill_rows<4, 1>), dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride, col_off, elem_stride, stream_stride);
+    else if (total >= BIG_FILL)
         hipLaunchKernelGGL(k_rng_fill_rows<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride, col_off, elem_stride, stream_stride);
     else
         hipLaunchKernelGGL(k_rng_fill_rows<0>, dim3(small_blocks(total, 8192)), dim3(256), 0, s, rk60_dev, first, out, rows, per_row, row_stride, col_off,
@@ -253,7 +281,8 @@ void aes_upload_tables() {
 
 void launch_rng_fill(hipStream_t s, const uint32_t* rk60_dev, uint64_t first_elem, fr* out, size_t count) {
     if (!count) return;
-    if (count >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first_elem, out, count);
+    if (count >= BIG_FILL && PERM_LAYOUT) hipLaunchKernelGGL((k_rng_fill<4, 1>), dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first_elem, out, count);
+    else if (count >= BIG_FILL) hipLaunchKernelGGL(k_rng_fill<REP>, dim3(BIG_BLOCKS), dim3(256), 0, s, rk60_dev, first_elem, out, count);
     else hipLaunchKernelGGL(k_rng_fill<0>, dim3(small_blocks(count, 4096)), dim3(256), 0, s, rk60_dev, first_elem, out, count);
 }
 

@@ -84,6 +84,7 @@ struct Shm {
     uint32_t world;
     std::atomic<uint32_t> abort_by;       // rank + 1 of the first rank that declared the communicator dead (0: alive)
     std::atomic<int32_t> pid[MAXW];       // process of every rank (0: not arrived yet / left in good order)
+    std::atomic<uint64_t> pidns[MAXW];    // inode of that process's PID namespace (0: unknown): a pid means something only inside its own namespace
     std::atomic<uint64_t> forgot[MAXW];   // epoch up to which rank h has closed every mapping of its peers' buffers
     hipIpcMemHandle_t window[MAXW];       // every rank's staging window (exported once, at creation)
     Pub pub[MAXW][RING];
@@ -127,7 +128,7 @@ struct IpcComm {
 };
 
 using clk = std::chrono::steady_clock;
-constexpr int HOST_TIMEOUT_S = 120;
+#define HOST_TIMEOUT_S (lig::knobs().ipc_host_s)      // LIG_IPC_HOST_S (default 120): how long a rank waits ON THE HOST for a peer to reach the same collective
 
 constexpr uint32_t POISON = 0x7fffffffu;      // >= every call number, whichever signedness the comparison uses
 
@@ -160,8 +161,16 @@ void poison(Shm* sh) {
     }
 }
 // is the process of a peer still running?  (kill(pid, 0) also succeeds for a zombie nobody has reaped yet: ask /proc for the state)
-bool process_alive(int32_t pid) {
+uint64_t my_pid_namespace() {
+    struct stat st;
+    return stat("/proc/self/ns/pid", &st) == 0 ? (uint64_t)st.st_ino : 0;
+}
+// (a peer in ANOTHER PID namespace -- one container per rank sharing /dev/shm -- cannot be probed from here: unknown is not dead, the
+// stall rule below is what catches it)
+bool process_alive(int32_t pid, uint64_t pidns) {
     if (pid <= 0) return true;                   // not arrived yet, or left in good order
+    static const uint64_t mine = my_pid_namespace();
+    if (!pidns || !mine || pidns != mine) return true;
     char path[64], buf[256];
     std::snprintf(path, sizeof path, "/proc/%d/stat", (int)pid);
     FILE* f = std::fopen(path, "r");
@@ -184,13 +193,16 @@ void watchdog(IpcComm* r) {
         std::string why;
         if (const uint32_t by = sh->abort_by.load(std::memory_order_acquire)) why = "rank " + std::to_string(by - 1) + " declared the communicator dead";
         for (uint32_t h = 0; h < W && why.empty(); h++)
-            if (h != r->rank && !process_alive(sh->pid[h].load(std::memory_order_acquire)))
+            if (h != r->rank && !process_alive(sh->pid[h].load(std::memory_order_acquire), sh->pidns[h].load(std::memory_order_acquire)))
                 why = "the process of rank " + std::to_string(h) + " (pid " + std::to_string(sh->pid[h].load()) + ") is gone";
         if (why.empty()) {
             const uint64_t c = r->calls_pub.load(std::memory_order_acquire);
-            bool complete = true;
+            bool complete = true, all_published = true;
             uint64_t sum = c;
             for (uint32_t h = 0; h < W; h++) {
+                // host skew (a rank still forming its rows before it enters collective c) is bounded by host_wait's HOST_TIMEOUT_S in the
+                // ranks that wait for it: the stall clock runs only once every rank has published c
+                if (c && sh->pub[h][c % RING].seq.load(std::memory_order_acquire) < c) all_published = false;
                 for (uint32_t sl = 0; sl < SLOTS; sl++)
                     sum = sum * 1315423911u + __atomic_load_n(&sh->ready[h * RS + sl * FLAG_STRIDE], __ATOMIC_ACQUIRE) + ((uint64_t)__atomic_load_n(&sh->pulled[h * RS + sl * FLAG_STRIDE], __ATOMIC_ACQUIRE) << 32);
                 if (c && __atomic_load_n(&sh->pulled[h * RS + (c % SLOTS) * FLAG_STRIDE], __ATOMIC_ACQUIRE) < (uint32_t)c) complete = false;
@@ -198,7 +210,7 @@ void watchdog(IpcComm* r) {
             const auto now = clk::now();
             // a rank that has LEFT (its streams were drained first) will never write the flags an incomplete collective still waits for
             if (c && !complete && sh->departed.load(std::memory_order_acquire)) why = "a rank left the communicator while collective " + std::to_string(c) + " was outstanding";
-            else if (!c || complete || sum != last_sum) { last_sum = sum; last_change = now; }
+            else if (!c || complete || !all_published || sum != last_sum) { last_sum = sum; last_change = now; }
             else if (now - last_change > std::chrono::seconds(r->stall_s)) {
                 why = "collective " + std::to_string(c) + " outstanding and no flag of any rank changed for " + std::to_string(r->stall_s) + " s; flags [ready/pulled per rank, slot " + std::to_string(c % SLOTS) + "]:";
                 for (uint32_t h = 0; h < W; h++)
@@ -220,7 +232,8 @@ void watchdog(IpcComm* r) {
 
 // host-side wait for the peers' HOSTS; gives up at once when the communicator is dead
 template <class Pred>
-bool host_wait(IpcComm* r, Pred done, int timeout_s = HOST_TIMEOUT_S) {
+bool host_wait(IpcComm* r, Pred done, int timeout_s = -1) {
+    if (timeout_s < 0) timeout_s = HOST_TIMEOUT_S;
     const auto t0 = clk::now();
     for (unsigned spins = 0; !done(); spins++) {
         if (spins > 2000) usleep(50);
@@ -322,7 +335,9 @@ int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t byt
     // slot reuse across my own streams: call c - SLOTS (same slot, possibly another stream) must have written its `pulled` --
     // which follows its `ready` -- before this call writes `ready <- c`, or a late "ready <- c - SLOTS" would overwrite it
     if (c > SLOTS) IPC_TRY(r, hipStreamWaitValue32(st, pulled + me * RS, (uint32_t)(c - SLOTS), hipStreamWaitValueGte, 0xffffffffu));
-    IPC_TRY(r, hipStreamWriteValue32(st, ready + me * RS, v, 0));
+    // (LIG_FAULT_COMM=4, tests: rank 1 never raises its `ready` flag -- every rank has published the collective on the host, the peers' queued
+    // waits never complete: the GPU-side stall the watchdog's LIG_IPC_STALL_S rule exists for)
+    if (!(lig::knobs().fault_comm == 4 && me == 1)) IPC_TRY(r, hipStreamWriteValue32(st, ready + me * RS, v, 0));
     for (uint32_t i = 0; i < W; i++) {
         const uint32_t h = (me + i) % W;                    // own block first, then the peers in a rotated order (no hot spot)
         if (h != me) IPC_TRY(r, hipStreamWaitValue32(st, ready + h * RS, v, hipStreamWaitValueGte, 0xffffffffu));
@@ -475,6 +490,7 @@ int lig_ipc_comm_create(lig_ctx* c, const char* shm_name, uint32_t rank, uint32_
         (void)hipHostUnregister(r->shm->ready); if (r->window) (void)hipFree(r->window);
         return bail("window allocation / export failed", LIG_E_HIP);
     }
+    r->shm->pidns[rank].store(my_pid_namespace(), std::memory_order_release);
     r->shm->pid[rank].store((int32_t)getpid(), std::memory_order_release);
     r->shm->arrived.fetch_add(1);
     if (!host_wait(nullptr, [&] { return r->shm->arrived.load() >= world; })) { (void)hipHostUnregister(r->shm->ready); (void)hipFree(r->window); return bail("not all ranks arrived", LIG_E_STATE); }

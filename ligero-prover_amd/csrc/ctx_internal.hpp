@@ -48,6 +48,7 @@ struct lig_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
     uint64_t prof_rows = 0;
+    std::vector<uint32_t> prof_launch_rows;   // rows of bracketed launch i (lig_profile_read_launches)
     // communicators made on this context (comm_rccl.hip, comm_ipc.hip): (object, its finalizer); ended with the context
     std::vector<std::pair<void*, void (*)(void*)>> comms;
     // diagnostics: what the call in progress is waiting for (set by lig_shard_* around their queued work, read by a communicator's

@@ -20,6 +20,7 @@ struct Knobs {
     uint32_t sha_block = 256;          // LIG_SHA_BLOCK      workgroup size of the column hash
     int      sha_ws = 2;               // LIG_SHA_WS         column hash: 0 one wave per 64 columns; 1 / 2 / 4 wave-specialised (producer + consumer waves), groups per workgroup
     uint32_t aes_blocks = 0;           // LIG_AES_BLOCKS     persistent workgroups of the big sampler launches (0: two per CU)
+    int      aes_layout = 0;           // LIG_AES_LAYOUT     1: AES tables of the big sampler launches entry-major, a lookup address is one v_perm_b32 (round 6 A/B)
     int      sha_gate = 1;             // LIG_SHA_GATE       1: place every chunk's hash before the encode stream goes on; 2: the next chunk's K1 runs first, ALONE (the hash
                                        //                    waits for it), then the hash is placed, then the tile kernel goes on
     size_t   sha_gate_rows = 2;        // LIG_SHA_GATE_ROWS  rows hashed before the encode stream is released
@@ -31,8 +32,8 @@ struct Knobs {
     bool     early_code = true;        // LIG_EARLY_CODE=0   accumulate the code test inside the row loop
     int      upload_mode = 2;          // LIG_UPLOAD_MODE    2: uploader thread, 1: per-context copy stream + events
     bool     upload_prio = true;       // LIG_UPLOAD_PRIO=0  the uploader thread's stream at normal priority (shares the proof streams' hardware-queue pool: A/B only)
-    bool     fault_upload = false;     // LIG_FAULT_UPLOAD   tests: the uploader thread's first transfer never completes (exercises LIG_UPLOAD_TIMEOUT_S)
-    int      upload_timeout_s = 60;    // LIG_UPLOAD_TIMEOUT_S  uploader thread: seconds after which a transfer that has not completed is reported as failed
+    int      fault_upload = 0;         // LIG_FAULT_UPLOAD   tests: a transfer of the uploader thread never completes -- 1: the first of witness rows, 2: the first of randomness rows (exercises LIG_UPLOAD_TIMEOUT_S)
+    int      upload_timeout_s = 5;     // LIG_UPLOAD_TIMEOUT_S  uploader thread: seconds after which a transfer that has not completed is given up on (the call makes the upload again with stream copies)
     bool     shard_uploader = false;   // LIG_SHARD_UPLOADER=1  lig_shard_rows_*: host rows / randomness rows through the uploader thread + stream waits (round 4; hangs with several processes per GPU)
     int      rands_upload_mode = 2;    // LIG_RANDS_UPLOAD_MODE  caller randomness rows from host: 2 uploader thread, 1: event-chained copies on the side stream (round 3)
     bool     spin_wait = true;         // LIG_SPIN_WAIT=0    the proof's host waits block in the runtime instead of polling
@@ -42,9 +43,11 @@ struct Knobs {
     bool     zres = false;             // LIG_ZRES=1         stage 1 keeps the encoder's Z tiles instead of codeword planes: K3 inside the column hash (round 6 A/B)
     bool     trace = false;            // LIG_TRACE          synchronised phase timeline on stderr
     int      fault_comm = 0;           // LIG_FAULT_COMM     tests: 1 = the stream-ordered all-to-all of the library's communicators
-                                       //                    fails on first use, 2 = the host-synchronous one fails as well
+                                       //                    fails on first use, 2 = the host-synchronous one fails as well, 3 = the stream-ordered one hangs on the
+                                       //                    host, 4 = (comm_ipc) rank 1 never raises its ready flag: a stall inside the GPU queues
     int      comm_timeout_s = 300;     // LIG_COMM_TIMEOUT_S  lig_shard_*: seconds the host waits for queued work with collectives before it calls lig_comm.abort
-    int      ipc_stall_s = 60;         // LIG_IPC_STALL_S    comm_ipc watchdog: seconds without any flag changing before an outstanding collective is declared dead
+    int      ipc_host_s = 120;         // LIG_IPC_HOST_S     comm_ipc: seconds a rank waits on the host for a peer to reach (publish) the same collective
+    int      ipc_stall_s = 120;        // LIG_IPC_STALL_S    comm_ipc watchdog: seconds without any flag changing, once every rank has published the collective, before it is declared dead
     std::string rccl_lib;              // LIG_RCCL_LIB       the librccl to load instead of the one already mapped / found
 };
 const Knobs& knobs();

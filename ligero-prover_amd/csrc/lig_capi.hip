@@ -310,6 +310,7 @@ const lig::Knobs& lig::knobs() {
         { const long v = num("LIG_SHA_WS", 2); t.sha_ws = (v == 0 || v == 1 || v == 4) ? (int)v : 2; }
         t.sha_gate = (int)num("LIG_SHA_GATE", 1);
         { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
+        t.aes_layout = (int)num("LIG_AES_LAYOUT", 0);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
@@ -324,8 +325,8 @@ const lig::Knobs& lig::knobs() {
         t.rands_upload_mode = (int)num("LIG_RANDS_UPLOAD_MODE", 2);
         t.upload_prio = num("LIG_UPLOAD_PRIO", 1) != 0;
         t.shard_uploader = num("LIG_SHARD_UPLOADER", 0) != 0;
-        t.upload_timeout_s = (int)pos("LIG_UPLOAD_TIMEOUT_S", 60);
-        t.fault_upload = num("LIG_FAULT_UPLOAD", 0) != 0;
+        t.upload_timeout_s = (int)pos("LIG_UPLOAD_TIMEOUT_S", 5);
+        t.fault_upload = (int)num("LIG_FAULT_UPLOAD", 0);
         t.d2h_kernel = num("LIG_D2H_KERNEL", 1) != 0;
         t.spin_wait = num("LIG_SPIN_WAIT", 1) != 0;
         t.spin_wait_ms = (int)pos("LIG_SPIN_WAIT_MS", 50);
@@ -333,7 +334,8 @@ const lig::Knobs& lig::knobs() {
         t.trace = std::getenv("LIG_TRACE") != nullptr;
         t.zres = num("LIG_ZRES", 0) != 0;
         t.fault_comm = (int)num("LIG_FAULT_COMM", 0);
-        t.ipc_stall_s = (int)pos("LIG_IPC_STALL_S", 60);
+        t.ipc_stall_s = (int)pos("LIG_IPC_STALL_S", 120);
+        t.ipc_host_s = (int)pos("LIG_IPC_HOST_S", 120);
         t.comm_timeout_s = (int)pos("LIG_COMM_TIMEOUT_S", 300);
         { const char* e = std::getenv("LIG_RCCL_LIB"); if (e) t.rccl_lib = e; }
         return t;
@@ -608,6 +610,8 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                     c->prof_events.push_back({a, b});
                 }
                 e0 = c->prof_events[c->prof_used].first; e1 = c->prof_events[c->prof_used].second;
+                if (c->prof_launch_rows.size() < c->prof_used + 1) c->prof_launch_rows.resize(c->prof_used + 1);
+                c->prof_launch_rows[c->prof_used] = (uint32_t)nr;
                 c->prof_used++; c->prof_rows += nr;
             }
             lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
@@ -967,6 +971,24 @@ int lig_profile_read(lig_ctx* c, uint64_t* launches, uint64_t* rows, double* tot
     }
     if (launches) *launches = c->prof_used;
     if (rows) *rows = c->prof_rows;
+    if (total_ms) *total_ms = ms;
+    return LIG_OK;
+}
+
+// the same for the launches of exactly `rows_in_launch` rows (bench.py: the 512-row launches, the figure a rocprofv3 kernel table shows per
+// launch size -- DESIGN.md section 6's reconciliation needs no arithmetic over the six launch sizes of a proof)
+int lig_profile_read_launches(lig_ctx* c, uint32_t rows_in_launch, uint64_t* launches, double* total_ms) {
+    CHECK_CTX(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double ms = 0;
+    uint64_t cnt = 0;
+    for (size_t i = 0; i < c->prof_used; i++) {
+        if (c->prof_launch_rows[i] != rows_in_launch) continue;
+        float t = 0;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->prof_events[i].first, c->prof_events[i].second));
+        ms += t; cnt++;
+    }
+    if (launches) *launches = cnt;
     if (total_ms) *total_ms = ms;
     return LIG_OK;
 }

@@ -70,6 +70,9 @@ struct lig_trace {
     uint64_t rands_pushed = 0;          // rows handed to the uploader so far (word up_words - 1 counts the rows that have ARRIVED)
     size_t up_words = 0;                // words in up_flag: [stage-1 chunks | stage-2 chunks: randomness rows arrived | ... consumed]
     bool push_sync = false;             // lig_rows_push_rands without an uploader thread: the pushed rows were copied synchronously
+    std::vector<UploadJob> push_log;    // the pushes of the committed trace (their host rows stay valid until lig_rows_prove returns): what a retry copies again
+    bool up_retry = false;              // prove_stage1 failed because a witness-rows transfer timed out (LIG_UPLOAD_TIMEOUT_S): lig_rows_commit makes the upload again
+    bool leak = false;                  // an abandoned transfer of this trace is still pending and cannot be cancelled: its buffers are never freed or reused
     std::atomic<int> up_abort{0};       // a failed lig_rows_prove: the uploader drops the randomness-row copies it still holds
     std::atomic<int> up_pending{0};     // chunk copies of this trace the uploader thread still has to make
     std::atomic<int> up_failed{0}, rand_pending{0}, rand_failed{0};      // hipError_t of a chunk copy that failed (the chunk is published all the same: no stream may hang)   -- rand_*: the same for randomness-row uploads, kept apart: lig_rows_prove must not wait for (or swallow the error of) the NEXT trace's witness prefetch
@@ -435,7 +438,10 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
     HIP_TRY(c, wait_stream(s));
     if (streamed && T->up_by_thread) {
         // every chunk has been waited for by now; a copy the uploader thread could not make leaves garbage rows behind
-        if (const int e = T->up_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("rows upload failed: ") + hipGetErrorString((hipError_t)e));
+        if (const int e = T->up_failed.exchange(0)) {
+            T->up_retry = e == (int)hipErrorLaunchTimeOut;
+            FAIL(c, LIG_E_HIP, std::string("rows upload failed: ") + hipGetErrorString((hipError_t)e));
+        }
     }
     std::memcpy(info->root, T->h_nodes, 32);
     TRY(lig_internal_download(c, T->h_nodes, T->nodes, lig_merkle_nodes(n) * 32, s));      // ... the tree for the decommitment (stage 3) under stage 2
@@ -767,6 +773,9 @@ void lig_trace_destroy(lig_trace* T) {
     rand_drain(T);
     if (T->c->stream_sha) (void)hipStreamSynchronize(T->c->stream_sha);      // (experiment knob LIG_SHA_CUMASK: the stage-1 hash stream)
     T->c->sha.erase(T->sha_state);
+    if (T->leak) {      // destinations of a transfer that was given up on and has never completed (upload_settled): they outlive the trace
+        T->rands_full = nullptr; T->msgs_alt = nullptr; T->msgs = nullptr; T->randb = nullptr; T->packed_dev = nullptr;
+    }
     for (void* p : {(void*)T->rands_full, (void*)T->msgs_alt, (void*)T->msgs, (void*)T->cw, (void*)T->maskcw, (void*)T->randb, (void*)T->rcw, (void*)T->acc, (void*)T->parts, (void*)T->dots,
                     (void*)T->samples, (void*)T->sha_state, (void*)T->leaves, (void*)T->nodes, (void*)T->tri_dev,
                     (void*)T->coef_dev})
@@ -819,6 +828,21 @@ struct Uploader {
     std::atomic<uint64_t> cur_bytes{0}, cur_since_us{0}, done_jobs{0};      // diagnostics
     std::atomic<int> phase{0};                                              // 0 idle, 1 copy call, 2 waiting for the copy, 3 publishing
     std::atomic<bool> broken{false};                                        // a transfer timed out: no further jobs
+    bool fault_done = false;                                                // LIG_FAULT_UPLOAD: the injected fault has been spent
+    std::atomic<uint32_t> abandoned{0};                                     // transfers given up on that may still be in flight on `st` (cleared by settle())
+    std::atomic<uint32_t> retries{0};                                       // calls that re-made a timed-out upload with stream-ordered copies
+    // The copy this thread stopped waiting for is still queued on `st` and cannot be cancelled.  settle(): has it finished by now?  (Bounded
+    // poll from the calling thread; hipStreamQuery is thread-safe.)  Until it has, its source rows and its destination must stay alive.
+    bool settle(double seconds) {
+        if (!abandoned.load(std::memory_order_acquire)) return true;
+        const auto t0 = clk::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipErrorNotReady) { (void)hipGetLastError(); abandoned.store(0, std::memory_order_release); return true; }
+            if (std::chrono::duration<double>(clk::now() - t0).count() > seconds) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<UploadJob, std::atomic<int>*>> q;
@@ -863,10 +887,14 @@ struct Uploader {
             phase.store(2, std::memory_order_release);
             // bounded: a transfer that does not complete (seen with several processes on one GPU, profiles/r05_rows_entry_hang.md) must
             // not hang every stream that waits for its word -- after LIG_UPLOAD_TIMEOUT_S the job is reported as failed (the word is
-            // published, lig_rows_commit / _prove return LIG_E_HIP once their streams have drained) and this thread takes no more jobs:
-            // callers fall back on stream-ordered copies (lig_internal_uploader_available turns false)
+            // published; lig_rows_commit / _prove let their streams drain, wait -- bounded -- for the abandoned copy to leave the bus and
+            // make the upload again with stream-ordered copies: rows_retry_*) and this thread takes no more jobs: callers fall back on
+            // stream-ordered copies from then on (lig_internal_uploader_available turns false)
             hipError_t e2 = e;
-            const bool injected = lig::knobs().fault_upload && !skip && done_jobs.load() == 0;      // tests (LIG_FAULT_UPLOAD): the first transfer "never completes"
+            // tests (LIG_FAULT_UPLOAD): one transfer "never completes" -- 1: the first one of witness rows, 2: the first one of randomness rows
+            const int fu = lig::knobs().fault_upload;
+            const bool injected = fu && !skip && !fault_done && (fu == 2) == (j.first.prio == 1);
+            if (injected) fault_done = true;
             if (e == hipSuccess) {
                 const auto t_wait = clk::now();
                 const double limit = (double)lig::knobs().upload_timeout_s;
@@ -874,7 +902,7 @@ struct Uploader {
                     e2 = injected ? hipErrorNotReady : hipStreamQuery(st);
                     if (e2 != hipErrorNotReady) break;
                     if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
-                    if ((spins & 1023) == 1023 && std::chrono::duration<double>(clk::now() - t_wait).count() > limit) { e2 = hipErrorLaunchTimeOut; broken.store(true, std::memory_order_release); break; }
+                    if ((spins & 1023) == 1023 && std::chrono::duration<double>(clk::now() - t_wait).count() > limit) { e2 = hipErrorLaunchTimeOut; abandoned.fetch_add(1, std::memory_order_acq_rel); broken.store(true, std::memory_order_release); break; }
                 }
                 if (e2 == hipErrorNotReady) e2 = hipSuccess;
             }
@@ -926,6 +954,14 @@ std::string lig_internal_uploader_state(int device) {
            ", " + std::to_string(queued) + " queued, " + std::to_string(u->done_jobs.load()) + " done";
 }
 extern "C" {
+int lig_upload_health(lig_ctx* c, uint32_t* retries, uint32_t* unsettled) {
+    CHECK_CTX(c);
+    Uploader* u = (c->device >= 0 && c->device < 64) ? g_uploader[c->device] : nullptr;
+    if (u && u->abandoned.load(std::memory_order_acquire)) (void)u->settle(0.0);      // one query: has it finished in the meantime?
+    if (retries) *retries = u ? u->retries.load(std::memory_order_relaxed) : 0;
+    if (unsettled) *unsettled = u ? u->abandoned.load(std::memory_order_acquire) : 0;
+    return LIG_OK;
+}
 void lig_internal_uploader_submit(int device, const std::vector<UploadJob>& jobs, std::atomic<int>* pending) {
     Uploader* u = g_uploader[device];
     pending->fetch_add((int)jobs.size(), std::memory_order_acq_rel);
@@ -952,6 +988,37 @@ static int ensure_up_flags(lig_ctx* c, lig_trace* T) {
     HIP_TRY(c, hipHostGetDevicePointer((void**)&T->up_flag_dev, (void*)T->up_flag, 0));
     return LIG_OK;
 }
+// witness rows by stream-ordered copies on the context's copy stream, one event per stage-1 chunk (LIG_UPLOAD_MODE=1, devices without
+// stream memory operations, and the second attempt after a transfer of the uploader thread has timed out)
+static int rows_copy_by_stream(lig_ctx* c, lig_trace* T, uint8_t* up_dst) {
+    const uint32_t k = c->k;
+    auto chunk_src = [&](size_t b) -> size_t { return T->narrow ? (size_t)T->src_off[b] : b * (size_t)k * 32; };
+    T->up_by_thread = false;
+    if (T->ev_up.empty()) {
+        T->ev_up.resize(T->sched1.size(), nullptr);
+        for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    for (size_t ci = 0; ci < T->sched1.size(); ci++) {
+        const size_t b = T->sched1[ci].first, e = T->sched1[ci].second;
+        const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
+        if (bytes) HIP_TRY(c, hipMemcpyAsync(up_dst + off, T->host_msgs + off, bytes, hipMemcpyHostToDevice, c->stream3));
+        HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
+    }
+    HIP_TRY(c, hipGetLastError());
+    return LIG_OK;
+}
+// A transfer of the uploader thread timed out (Uploader::run): the waiting streams were released and have drained.  The copy itself is
+// still queued on the uploader's stream and cannot be cancelled.  Bounded wait for it to leave the bus: true = it has (its bytes are where
+// they belong or will be overwritten by the second attempt); false = it is still pending -- what it reads (the caller's rows) and writes
+// (this trace's buffers) must stay alive: the trace is marked, its buffers are never freed or reused, lig_upload_health() reports it.
+static bool upload_settled(lig_ctx* c, lig_trace* T) {
+    Uploader* u = g_uploader[c->device];
+    if (!u || u->settle((double)lig::knobs().upload_timeout_s)) return true;
+    T->leak = true;
+    return false;
+}
+static const char* const UPLOAD_PENDING_MSG = "; the transfer is still pending and cannot be cancelled: keep the rows alive until lig_upload_health reports no unsettled "
+                                              "transfer (the trace's device buffers are kept for the life of the process)";
 // message rows of a rows job -> T->msgs.  Device rows: one copy on the main stream.  Host rows: the upload starts now, on
 // the copy stream, one event per stage-1 chunk: lig_rows_commit encodes chunk b while chunk b+1 is still on the bus.
 static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device) {
@@ -1001,19 +1068,7 @@ static int rows_load(lig_ctx* c, lig_trace* T, const void* msgs, bool on_device)
         T->up_by_thread = true;
         return LIG_OK;
     }
-    T->up_by_thread = false;
-    if (T->ev_up.empty()) {
-        T->ev_up.resize(T->sched1.size(), nullptr);
-        for (auto& e : T->ev_up) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    for (size_t ci = 0; ci < T->sched1.size(); ci++) {
-        const size_t b = T->sched1[ci].first, e = T->sched1[ci].second;
-        const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
-        if (bytes) HIP_TRY(c, hipMemcpyAsync(up_dst + off, T->host_msgs + off, bytes, hipMemcpyHostToDevice, c->stream3));
-        HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
-    }
-    HIP_TRY(c, hipGetLastError());
-    return LIG_OK;
+    return rows_copy_by_stream(c, T, up_dst);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1106,6 +1161,7 @@ int lig_rows_restart(lig_trace* T, const void* msgs, int msgs_on_device) {
     CHECK_CTX(c);
     if (!T->from_rows) FAIL(c, LIG_E_STATE, "lig_rows_restart: not a rows trace");
     if (T->R && !msgs) FAIL(c, LIG_E_ARG, "lig_rows_restart: null rows");
+    if (T->leak) FAIL(c, LIG_E_STATE, "lig_rows_restart: a transfer into this trace's buffers never completed (lig_upload_health): destroy the trace");
     if (T->loaded && T->host_msgs) { uploader_drain(T); HIP_TRY(c, hipStreamSynchronize(c->stream3)); }      // an upload nobody committed: let it finish first
     return rows_load(c, T, msgs, msgs_on_device != 0);
 }
@@ -1120,8 +1176,24 @@ int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
     T->info1.rows = T->R + 3;
     const auto t_begin = clk::now();
     {
-        const int rc = prove_stage1(T, &T->info1, make_mark(c));
-        if (rc != LIG_OK) {           // the caller is told it may free its rows: nothing of ours may still read them
+        if (T->leak) FAIL(c, LIG_E_STATE, "lig_rows_commit: a transfer into this trace's buffers never completed (lig_upload_health): destroy the trace");
+        T->up_retry = false;
+        int rc = prove_stage1(T, &T->info1, make_mark(c));
+        if (rc != LIG_OK && T->up_retry) {
+            // a chunk of the rows did not arrive within LIG_UPLOAD_TIMEOUT_S (the uploader thread has released the streams, stage 1 ran over
+            // garbage and is discarded): once the abandoned copy has left the bus the same rows are brought by stream-ordered copies and
+            // stage 1 runs again -- the caller sees a slow commit, not an error
+            T->up_retry = false;
+            const std::string why = c->err;
+            uploader_drain(T);
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream_sha}) if (st) (void)hipStreamSynchronize(st);
+            if (upload_settled(c, T)) {
+                g_uploader[c->device]->retries.fetch_add(1, std::memory_order_relaxed);
+                rc = rows_copy_by_stream(c, T, T->narrow ? T->packed_dev : (uint8_t*)T->msgs);
+                if (rc == LIG_OK) rc = prove_stage1(T, &T->info1, make_mark(c));
+            } else c->err = why + UPLOAD_PENDING_MSG;
+        }
+        if (rc != LIG_OK) {           // the caller is told it may free its rows: nothing of ours may still read them (but see T->leak)
             const std::string why = c->err;
             uploader_drain(T);
             for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream_sha}) if (st) (void)hipStreamSynchronize(st);
@@ -1165,23 +1237,48 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
         if (T->rands_pushed != T->R) FAIL(c, LIG_E_STATE, "lig_rows_prove: lig_rows_push_rands has not delivered every row");
         rs.dev = T->rands_full; rs.pushed = true;
     }
-    {
+    for (int attempt = 0;; attempt++) {
         int rc = prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c));
         const std::string why = c->err;
         if (rc != LIG_OK) {           // randomness-row copies the uploader thread still holds read the caller's memory: drop them, wait
             T->rands_pushed = 0;
+            T->push_log.clear();
             T->up_abort.store(1, std::memory_order_release);
             rand_drain(T);
             for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream_sha}) if (st) (void)hipStreamSynchronize(st);
             c->err = why;
             return rc;
         }
-        if (rs.host || rs.pushed) {
-            rand_drain(T);
-            T->rands_pushed = 0;
-            if (const int e = T->rand_failed.exchange(0)) FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
+        if (!(rs.host || rs.pushed)) break;
+        rand_drain(T);
+        const int e = T->rand_failed.exchange(0);
+        if (!e) break;
+        if (e == (int)hipErrorLaunchTimeOut && attempt == 0) {
+            // a randomness-row transfer timed out: stages 2 / 3 ran over garbage and are discarded.  Same second attempt as in
+            // lig_rows_commit: host rows come by stream-ordered copies now (the uploader is out of service), pushed rows are copied again
+            // from the pushes' host memory (valid until this call returns)
+            for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream_sha}) if (st) (void)hipStreamSynchronize(st);
+            if (upload_settled(c, T)) {
+                g_uploader[c->device]->retries.fetch_add(1, std::memory_order_relaxed);
+                if (rs.pushed) {
+                    for (const UploadJob& j : T->push_log) {
+                        if (j.segs) { for (const UploadSeg& g : *j.segs) { if (!g.bytes) continue; HIP_TRY(c, g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, c->stream3) : hipMemsetAsync(g.dst, 0, g.bytes, c->stream3)); } }
+                        else if (j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, c->stream3));
+                    }
+                    HIP_TRY(c, hipStreamSynchronize(c->stream3));
+                    T->push_sync = true;          // every row is there: stage 2 has no arrival word to wait for
+                }
+                *info = T->info1;
+                continue;
+            }
+            T->rands_pushed = 0; T->push_log.clear();
+            FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e) + UPLOAD_PENDING_MSG);
         }
+        T->rands_pushed = 0; T->push_log.clear();
+        FAIL(c, LIG_E_HIP, std::string("randomness rows upload failed: ") + hipGetErrorString((hipError_t)e));
     }
+    T->rands_pushed = 0;
+    T->push_log.clear();
     info->ms_total = info->ms_stage1 + ms_since(t_begin);
     T->committed = false;
     return LIG_OK;
@@ -1225,7 +1322,7 @@ int lig_rows_push_rands_sparse(lig_trace* T, uint64_t first_row, uint64_t n_rows
     if (first_row == 0) T->push_sync = false;
     TRY(ensure_up_flags(c, T));
     volatile uint32_t* arrived = T->up_flag + T->up_words - 1;
-    if (first_row == 0) { __atomic_store_n(arrived, 0u, __ATOMIC_RELEASE); T->up_abort.store(0, std::memory_order_release); }
+    if (first_row == 0) { __atomic_store_n(arrived, 0u, __ATOMIC_RELEASE); T->up_abort.store(0, std::memory_order_release); T->push_log.clear(); }
     // one job per push: the uploader publishes the number of rows that have arrived (jobs of a trace are taken in order)
     UploadJob j{(uint8_t*)T->rands_full + first_row * row_bytes, (const uint8_t*)host_rows, n_rows * row_bytes, arrived, (uint32_t)(first_row + n_rows), &T->rand_failed};
     if (present && n_present != n_rows) {       // runs of present rows are copied from where they follow each other in host_rows, the others zero-filled on the device
@@ -1241,6 +1338,7 @@ int lig_rows_push_rands_sparse(lig_trace* T, uint64_t first_row, uint64_t n_rows
         }
     }
     j.abort = &T->up_abort; j.prio = 1;
+    T->push_log.push_back(j);
     lig_internal_uploader_submit(c->device, {j}, &T->rand_pending);
     T->rands_pushed = first_row + n_rows;
     return LIG_OK;

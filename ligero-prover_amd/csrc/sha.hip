@@ -160,6 +160,11 @@ __device__ __forceinline__ void sha256_rounds(uint32_t& a, uint32_t& b, uint32_t
     }
 }
 
+// Residency: the producer and the consumer wave of a group spin on LDS words of their own workgroup.  A workgroup is dispatched to a CU
+// only when ALL of its waves (and its LDS) fit -- the hardware never starts half a workgroup -- so both waves of every group are resident
+// for the kernel's whole life; nothing else (no second workgroup, no other kernel) is waited for.  GROUPS * 2 waves x <= 168 VGPRs fit the
+// 512-register file of a SIMD for GROUPS <= 4 (one or two of these waves per SIMD).  Every variant and every ragged shape is checked against
+// the oracle in tests/test_gpu_sha_ws.py; LIG_SHA_WS=0 (the one-wave kernel above) is the documented fallback.
 template <int GROUPS>
 __global__ void __launch_bounds__(GROUPS * 128) k_sha_update_rows_ws(uint32_t* __restrict__ st, size_t n_inst, const fr* __restrict__ rows, size_t row_stride,
                                                                       size_t nrows, uint64_t rows_before, uint32_t pk, const fr* __restrict__ msgs) {

@@ -29,6 +29,8 @@ struct lig_shard {
     lig_synth_job job;
     lig_comm comm;
     uint32_t rank = 0, world = 1;
+    std::atomic<const char*> dbg_wait{nullptr}; std::atomic<uint64_t> dbg_wait_since_ms{0};     // what shard_bounded_wait is polling for, since when (shard_debug)
+    bool poisoned = false;                     // work queued behind a failed collective never drained (shard_quiesce): no further calls, buffers outlive the shard
     std::vector<RowDesc> rows;                 // global plan
     std::vector<size_t> gb;                    // G + 1 global chunk boundaries
     std::vector<size_t> lrow0;                 // local row offset of my c-th chunk (rounds + 1 entries)
@@ -276,14 +278,44 @@ static int shard_alloc(lig_ctx* c, uint32_t rank, uint32_t world, lig_shard* S) 
     return LIG_OK;
 }
 
+// Bounded replacement for hipStreamSynchronize on the error / teardown paths: when a collective failed and neither the
+// communicator's abort nor the watchdog released the kernels queued behind it, a blocking synchronize would hang exactly where
+// shard_bounded_wait gave up.  Polls the context's streams for `seconds`; false = something is still queued: the shard is poisoned
+// (every later call on it returns LIG_E_STATE; lig_shard_destroy keeps the device buffers the queued kernels may still touch).
+static bool shard_quiesce(lig_shard* S, double seconds) {
+    lig_ctx* c = S->c;
+    const auto t0 = clk::now();
+    for (unsigned spins = 0;; spins++) {
+        bool busy = false;
+        for (hipStream_t st : {c->stream, c->stream2, c->stream3}) {
+            if (!st) continue;
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipErrorNotReady) busy = true; else if (e != hipSuccess) (void)hipGetLastError();
+        }
+        if (!busy) return true;
+        if (spins < 4000) { std::this_thread::yield(); continue; }
+        usleep(50);
+        if ((spins & 63) == 0 && std::chrono::duration<double>(clk::now() - t0).count() > seconds) { S->poisoned = true; return false; }
+    }
+}
+static constexpr double SHARD_QUIESCE_S = 20.0;
+static const char* const SHARD_POISONED_MSG = "; the streams still hold work queued behind the failed collective: the shard is poisoned (rows and randomness rows of this call "
+                                              "must stay alive; destroy the shard and do not reuse the context)";
+
 void lig_shard_destroy(lig_shard* S) {
     if (!S) return;
     (void)hipSetDevice(S->c->device);
-    (void)hipStreamSynchronize(S->c->stream);
-    (void)hipStreamSynchronize(S->c->stream2);
-    (void)hipStreamSynchronize(S->c->stream3);
+    if (!S->poisoned) (void)shard_quiesce(S, SHARD_QUIESCE_S);
     S->up_abort.store(1, std::memory_order_release);
     while (S->up_pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();       // the uploader thread is done with our buffers
+    if (S->poisoned) {
+        // kernels behind a collective that never completed are still queued: they may run (and touch these buffers) whenever the queue is
+        // released.  The device and pinned buffers, the events and the flag page outlive the shard; only the host object goes.  (The
+        // context's streams are in the same state: destroy the context's process, or at least never reuse the context.)
+        S->c->sha.erase(S->sha_state);
+        delete S;
+        return;
+    }
     if (S->up_flag) (void)hipHostFree((void*)S->up_flag);
     // the send buffers below are about to be freed.  forget() may be a host collective (comm_ipc): a shard that fails before its
     // first collective (a local error in *_begin / *_prepare) has exported nothing and must not wait for peers that are not there
@@ -314,6 +346,9 @@ static int shard_bounded_wait(lig_shard* S, const std::function<hipError_t()>& q
     bool aborted = false, failed = false;
     auto t_fail = t0;
     std::string why;
+    S->dbg_wait_since_ms.store((uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(t0.time_since_epoch()).count(), std::memory_order_release);
+    S->dbg_wait.store(what, std::memory_order_release);
+    struct Clear { lig_shard* S; ~Clear() { S->dbg_wait.store(nullptr, std::memory_order_release); } } clear_on_exit{S};
     for (unsigned spins = 0;; spins++) {
         const hipError_t e = query();
         if (e == hipSuccess) break;
@@ -368,11 +403,16 @@ struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
     (void)l; (void)pad; (void)RM; (void)t; (void)s_comm; (void)W; (void)Rl; (void)R; (void)CAP; (void)ncol; (void)s_hash; (void)all_gather; (void)drain; (void)drain_event
 
 // what a watchdog prints when it declares the communicator dead while a sharded call is in progress
+// (No HIP call in here: it runs on a communicator's watchdog thread under the context's debug mutex, in exactly the situation where the
+// runtime may be wedged -- a blocked query would keep the mutex and with it the API call's return.  What the calling thread is waiting
+// for is published by shard_bounded_wait in two atomics instead.  ADVICE r5.)
 static std::string shard_debug(lig_shard* S, const char* stage, uint32_t rseq) {
     lig_ctx* c = S->c;
-    (void)hipSetDevice(c->device);                  // (called from a communicator's watchdog thread)
-    auto q = [](hipStream_t st) { const hipError_t e = hipStreamQuery(st); (void)hipGetLastError(); return e == hipSuccess ? "drained" : e == hipErrorNotReady ? "BUSY" : "error"; };
-    std::string o = std::string("[lig_shard] rank ") + std::to_string(S->rank) + " in " + stage + ": streams main " + q(c->stream) + ", side " + q(c->stream2) + ", copy " + q(c->stream3);
+    const char* w = S->dbg_wait.load(std::memory_order_acquire);
+    const uint64_t now = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(clk::now().time_since_epoch()).count();
+    std::string o = std::string("[lig_shard] rank ") + std::to_string(S->rank) + " in " + stage + ": " +
+                    (w ? std::string("the calling thread has been waiting for '") + w + "' for " + std::to_string(now - S->dbg_wait_since_ms.load(std::memory_order_acquire)) + " ms"
+                       : std::string("the calling thread is enqueueing"));
     o += "; rows upload seq " + std::to_string(S->up_seq) + ", randomness seq " + std::to_string(rseq) + ", pending " + std::to_string(S->up_pending.load()) + ", flag words [arrived rows | arrived rands | consumed]:";
     if (S->up_flag && S->rounds) for (size_t i = 0; i < 3 * S->rounds && i < 24; i++) o += (i % S->rounds == 0 ? " | " : " ") + std::to_string(S->up_flag[i]);
     else o += " none";
@@ -707,6 +747,7 @@ int lig_shard_prove(lig_shard* S, const uint8_t** proof, size_t* proof_len, lig_
     if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = S->c;
     CHECK_CTX(c);
+    if (S->poisoned) FAIL(c, LIG_E_STATE, "lig_shard_prove: the shard is poisoned (work queued behind a failed collective never drained): destroy it");
     if (S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_prove on a shard made by lig_shard_rows_begin (use lig_shard_rows_commit / _prove)");
     std::memset(info, 0, sizeof *info);
     info->rows = S->R + 3;
@@ -851,6 +892,7 @@ int lig_shard_rows_restart(lig_shard* S, const void* local_msgs, int msgs_on_dev
     if (!S) return LIG_E_ARG;
     lig_ctx* c = S->c;
     CHECK_CTX(c);
+    if (S->poisoned) FAIL(c, LIG_E_STATE, "lig_shard_rows_restart: the shard is poisoned (work queued behind a failed collective never drained): destroy it");
     if (!S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_rows_restart: not a rows shard");
     // (unlike lig_rows_restart there is no second message matrix here: stage 2 of a committed trace still reads the local rows)
     if (S->committed) FAIL(c, LIG_E_STATE, "lig_shard_rows_restart: the committed trace has not been proved yet");
@@ -860,6 +902,7 @@ int lig_shard_rows_commit(lig_shard* S, uint8_t root[32], uint8_t stage1_seed[32
     if (!S) return LIG_E_ARG;
     lig_ctx* c = S->c;
     CHECK_CTX(c);
+    if (S->poisoned) FAIL(c, LIG_E_STATE, "lig_shard_rows_commit: the shard is poisoned (work queued behind a failed collective never drained): destroy it");
     if (!S->from_rows) FAIL(c, LIG_E_STATE, "lig_shard_rows_commit: not a rows shard");
     if (S->committed) FAIL(c, LIG_E_STATE, "lig_shard_rows_commit: the committed trace has not been proved yet");
     std::memset(&S->info1, 0, sizeof S->info1);
@@ -870,9 +913,9 @@ int lig_shard_rows_commit(lig_shard* S, uint8_t root[32], uint8_t stage1_seed[32
         if (rc != LIG_OK) {               // the caller is told it may free its rows
             const std::string why = c->err;
             shard_up_drain(S);
-            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
+            const bool quiet = shard_quiesce(S, SHARD_QUIESCE_S);
             S->rows_by_thread = false;
-            c->err = why;
+            c->err = quiet ? why : why + SHARD_POISONED_MSG;
             return rc;
         }
     }
@@ -887,6 +930,7 @@ int lig_shard_rows_prove(lig_shard* S, const void* local_rands, int rands_on_dev
     if (!S || !proof || !proof_len || !info) return LIG_E_ARG;
     lig_ctx* c = S->c;
     CHECK_CTX(c);
+    if (S->poisoned) FAIL(c, LIG_E_STATE, "lig_shard_rows_prove: the shard is poisoned (work queued behind a failed collective never drained): destroy it");
     if (!S->from_rows || !S->committed) FAIL(c, LIG_E_STATE, "lig_shard_rows_prove: lig_shard_rows_commit has not run on this shard");
     if (S->Rl && !local_rands && !S->dense_rands) FAIL(c, LIG_E_ARG, "lig_shard_rows_prove: null randomness rows");
     if (const_sum) {
@@ -904,8 +948,8 @@ int lig_shard_rows_prove(lig_shard* S, const void* local_rands, int rands_on_dev
             const std::string why = c->err;
             S->up_abort.store(1, std::memory_order_release);
             shard_up_drain(S);
-            for (hipStream_t st : {c->stream, c->stream2, c->stream3}) (void)hipStreamSynchronize(st);
-            c->err = why;
+            const bool quiet = shard_quiesce(S, SHARD_QUIESCE_S);
+            c->err = quiet ? why : why + SHARD_POISONED_MSG;
             return rc;
         }
         if (rs.host) {

@@ -109,3 +109,17 @@ def test_transport_ladder_under_torch_distributed_run():
                             "--master-port", "29963"])
     assert out["spawned_by_bench"] is False and out["sharded"]["transport"] == "stub-ok"
     assert [a["ok"] for a in out["sharded"]["attempts"]] == [False, True]
+
+
+def test_gpus_sweep_runs_every_n_and_prints_one_line_per_n_plus_a_summary():
+    """round 6: `python bench.py --gpus-sweep 1,2,4` = the bench once per N, each its own `bench.py --gpus N`; one compact
+    line per N (value, the sharded figure, RCCL ranks, HBM fraction) and a summary line -- here with the stub workload (no GPU)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus-sweep", "1,2,4", "--workload", "stub", "--steps", "2", "--warmup", "1"],
+                       env=_env(), capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 4
+    assert [ln["n_gpus"] for ln in lines[:3]] == [1, 2, 4] and all(ln["value"] > 0 and ln["scaling"] == "weak" and ln["steps"] == 2 for ln in lines[:3])
+    assert lines[3]["gpus_sweep"] == lines[:3] and "shared_device" in lines[3]["note"]
+    # the keys a reader of the sweep needs are there even when the workload has nothing to say about them
+    assert all({"value", "sharded", "rccl_ranks", "hbm_frac", "shared_device"} <= set(ln) for ln in lines[:3])

@@ -522,3 +522,21 @@ def test_batched_prover_chunk_boundaries(amd, n_linear, n_quad):
         assert proof == bytes(pr.proof[:pr.proof_len])
     finally:
         ol.lib().lo_proof_free(C.byref(pr))
+
+
+def test_hip_encode_and_leaves_equal_the_wgsl_kernels_executing(ctx512):
+    """ingest hook (round 6): when tests/golden/wgsl_encode_k512.json exists (dumped from the reference's webgpu_context,
+    tools/make_wgsl_pin.py) the HIP encoder and column hash must reproduce the WGSL kernels' codewords and leaves bit for bit"""
+    import test_ref_pins as trp
+    g, msgs, cws, leaves = trp._wgsl_fixture()
+    c = ctx512
+    n, k = g["n"], g["k"]
+    dm, dc = c.upload(msgs), c.malloc(32 * n * g["rows"])
+    c.encode_rows(dm, dc, g["rows"])
+    got = c.download(dc, (g["rows"], n, 8))
+    for r in range(g["rows"]):
+        assert np.array_equal(got[r], cws[r])
+    st, dl = c.sha_state(n), c.malloc(32 * n)
+    c.sha_update_rows(st, dc, g["rows"])
+    c.sha_final(st, dl)
+    assert np.array_equal(c.download(dl, (n, 32), dtype=np.uint8), leaves)

@@ -193,15 +193,16 @@ def test_sharded_configs3_trace_full_size_equals_oracle_pin(tmp_path):
     assert out["root"] == pin["root"] and out["sha"] == pin["proof_sha256"]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_configs3_trace_full_size_over_ipc_comm_equals_oracle_pin(tmp_path, world):
-    """configs[3]'s 2^26-constraint trace sharded over W REAL ranks (processes on the one GPU, comm_ipc.hip): 9 / 5 exchange
-    rounds with the stream-ordered double-buffered pipeline; every rank's envelope equals the oracle's pin"""
+    """configs[3]'s 2^26-constraint trace sharded over W REAL ranks (processes on the one GPU, comm_ipc.hip): 9 / 5 / 3 exchange
+    rounds with the stream-ordered double-buffered pipeline; every rank's envelope equals the oracle's pin.  W = 8 is the node's
+    shape (round 6): 4096 columns per rank, seven peers per exchange, 8-way all-gathers."""
     with open(os.path.join(ROOT, "tests", "golden", "full_pin_2p26.json")) as f:
         pin = json.load(f)
     script = tmp_path / "big_worker.py"
     script.write_text(BIG_WORKER)
-    outs = mr.run_ranks(mr.python_argv(script, ROOT, "26", "gloo"), world, mr.rendezvous_env(world, "ipc"), timeout=420)
+    outs = mr.run_ranks(mr.python_argv(script, ROOT, "26", "gloo"), world, mr.rendezvous_env(world, "ipc"), timeout=420 if world < 8 else 900)
     for o, _ in outs:
         out = mr.last_json(o)
         assert out["valid"] == [1, 1, 1] and out["rows"] == pin["rows"]
@@ -399,6 +400,8 @@ def run_rows_world(tmp_path, world, l, k, n, n_lin, n_quad, batch, mode, comm, t
     (4, 320 * 4300 + 1, 0, False, "library_pads", "ipc"),       # three rounds on 4 ranks
     (2, 320 * 700 + 9, 330 + 5, False, "dense_rands", "ipc"),  # the dense coefficient rows generated (and accumulated) by the library on every rank
     (4, 900, 330, True, "dense_rands", None),
+    (8, 320 * 9000 + 11, 330, False, "library_pads", "ipc"),   # the node's shape (round 6): 8 ranks, three rounds, caller rows
+    (8, 900, 330, True, "own_pads", "ipc"),                    # 8 ranks, fewer chunks than ranks: most ranks own no row
 ])
 def test_sharded_rows_entry_equals_rows_prove_and_oracle(tmp_path, world, n_lin, n_quad, batch, mode, comm):
     """lig_shard_rows_*: one trace whose rows come from the caller, sharded over W ranks (each rank passes all kinds + its own
@@ -438,8 +441,9 @@ FAILING_PEER_WORKER = textwrap.dedent('''
             os.kill(os.getpid(), signal.SIGKILL)
         if how == "leaves":                          # an orderly exit of a rank that never joins the collective
             ctx.shard_destroy(sh); ctx.ipc_comm_destroy(comm); ctx.close(); os._exit(0)
-        if how == "stalls":                          # alive, but never reaches the collective
+        if how == "never_arrives":                   # alive, but never reaches the collective (host skew without end)
             time.sleep(25); os._exit(0)
+        # (how == "gpu_stall": this rank runs the call like rank 0; LIG_FAULT_COMM=4 makes it never raise its `ready` flag)
     t0 = time.time()
     try:
         ctx.shard_rows_commit(sh)
@@ -462,18 +466,23 @@ FAILING_PEER_WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("how,needle,limit", [
-    ("killed", "is gone", 30),                       # the peer's process is killed: noticed through its pid
-    ("leaves", "left the communicator", 30),         # the peer destroys its communicator without ever joining the collective
-    ("stalls", "no flag of any rank changed", 30),   # the peer is alive but stuck: the stall timer (LIG_IPC_STALL_S = 5 here)
+@pytest.mark.parametrize("how,needle,limit,knobs", [
+    ("killed", "is gone", 30, {}),                                # the peer's process is killed: noticed through its pid
+    ("leaves", "left the communicator", 30, {}),                  # the peer destroys its communicator without ever joining the collective
+    # the peer is alive but never reaches the collective: that is host skew, bounded by the HOST wait of the ranks that wait for its
+    # publication (LIG_IPC_HOST_S = 5 here, 120 by default) -- not by the stall timer, which must not fire on a slow constraint generator
+    ("never_arrives", "never reached collective", 30, dict(LIG_IPC_HOST_S=5, LIG_IPC_STALL_S=2)),
+    # every rank has published the collective on the host, but a peer's flag never comes (LIG_FAULT_COMM=4): the queued waits would never
+    # complete -- the watchdog's stall timer (LIG_IPC_STALL_S = 5 here) declares the communicator dead and releases them
+    ("gpu_stall", "no flag of any rank changed", 40, dict(LIG_IPC_STALL_S=5, LIG_FAULT_COMM=4)),
 ])
-def test_a_failing_peer_makes_the_sharded_call_return_an_error_instead_of_hanging(tmp_path, how, needle, limit):
+def test_a_failing_peer_makes_the_sharded_call_return_an_error_instead_of_hanging(tmp_path, how, needle, limit, knobs):
     """stream-ordered collectives wait inside GPU queues, where nothing times out.  comm_ipc's watchdog thread
     declares the communicator dead (dead pid / departed peer / stall), releases the queued waits, and lig_shard_rows_commit returns
     LIG_E_STATE with the reason -- in seconds, with every stream drained so that the shard and the context can be destroyed."""
     script = tmp_path / "failing_peer_worker.py"
     script.write_text(FAILING_PEER_WORKER)
-    env = mr.rendezvous_env(2, "ipc", LIG_IPC_STALL_S=5)
+    env = mr.rendezvous_env(2, "ipc", **knobs)
     tmpd = tmp_path / "ranks"
     tmpd.mkdir()
     procs, files = [], []
@@ -493,3 +502,26 @@ def test_a_failing_peer_makes_the_sharded_call_return_an_error_instead_of_hangin
     assert out["error"] and needle in out["error"], out
     assert out["seconds"] < limit and out["closed_after"] < limit + 10, out
     assert out["again"] and out["again_seconds"] < 5, out
+
+
+def test_gpus_sweep_1_2_8_on_one_gpu_is_a_labelled_functional_run(tmp_path):
+    """round 6: the hardware-day command `python bench.py --gpus-sweep 1,2,4,8` end to end on this one-GPU box
+    (LIG_BENCH_SHARE_GPU=1: all ranks of an N on GPU 0, comm_ipc over gloo): per N one line with the weak figure, the sharded (strong) figure
+    whose envelope equals the oracle pin on every rank, the HBM fraction -- and `shared_device: true` for N > 1, so that the numbers cannot
+    be mistaken for a scaling curve.  N = 8 is the node's shape: the 8-rank deal, the 7-peer exchange, the 8-way all-gathers."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", LIG_BENCH_SHARE_GPU="1")
+    args = ["--gpus-sweep", "1,2,8", "--steps", "2", "--warmup", "1", "--log2-constraints", "22", "--sharded-log2", "22,24", "--sharded-steps", "2",
+            "--sharded-leg", "--no-cpu-baseline", "--no-verify", "--no-h2d", "--quad-mix", "0", "--sharded-timeout", "300"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout.decode()[-2000:], p.stderr.decode()[-2000:])
+    lines = [json.loads(ln) for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 4 and [ln["n_gpus"] for ln in lines[:3]] == [1, 2, 8]
+    for ln in lines[:3]:
+        assert "error" not in ln and ln["value"] > 0 and ln["scaling"] == "weak" and 0 < ln["hbm_frac"] < 1, ln
+        assert ln["shared_device"] is (ln["n_gpus"] > 1)
+        sh = ln["sharded"]
+        assert sh["ranks"] == ln["n_gpus"] and sh["log2_constraints"] == 24 and sh["scaling"] == "strong", ln
+        assert sh["proof_equals_oracle_pin"] is True and sh["all_ranks_same_envelope"] is True, ln
+        assert ln["sharded_2p22"]["all_ranks_same_envelope"] is True, ln
+    assert lines[2]["sharded"]["transport"] == "ipc-stream" and lines[2]["distinct_devices"] is False

@@ -10,7 +10,7 @@ from kernel_facts import ROOT, kernel_facts           # noqa: E402
 
 KERNELS = ["k_encode_in<10>", "k_encode_tiles<10, true>", "k_encode_tiles<10, false>", "k_encode_out<10, 2>", "k_encode_out<10, 0>",
            "k_encode_out_dot<10>",
-           "k_encode_out_dot_z<10>", "k_gather_rows_z<10>", "k_sha_update_rows", "k_sha_update_rows_ws<2>", "k_sha_update_rows_z<10, 2>", "k_rand_rlc<4>", "k_rng_fill_rows_dense<4>", "k_rlc_partial",
+           "k_encode_out_dot_z<10>", "k_gather_rows_z<10>", "k_sha_update_rows", "k_sha_update_rows_ws<2>", "k_sha_update_rows_z<10, 2>", "k_rand_rlc<4, 0>", "k_rand_rlc<4, 1>", "k_rng_fill_rows_dense<4, 0>", "k_rlc_partial",
            "k_quad_rows<EvenOfView>", "k_merkle_level", "k_tiled_pass1<7, false>", "k_tiled_pass2<8>", "k_div_batched<4>"]
 BEGIN, END = "<!-- isa-table:begin -->", "<!-- isa-table:end -->"
 
