@@ -69,7 +69,7 @@ def test_under_torch_distributed_run_as_the_driver_launches_it():
 
 def _ladder(extra, launcher=None, timeout=300):
     cmd = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "2", "--warmup", "0", "--sharded-leg",
-           "--sharded-timeout", "10", "--sharded-log2", "24,26"] + extra
+           "--sharded-timeout", "20", "--sharded-log2", "24,26"] + extra      # (20 s: a rung's children import torch + rendezvous; 10 s was seen to be too short once on a loaded box)
     cmd = (launcher or [sys.executable]) + cmd
     p = subprocess.run(cmd, env=_env(), capture_output=True, timeout=timeout)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -97,7 +97,7 @@ def test_transport_ladder_with_every_rung_failing_still_prints_the_weak_line():
 
 
 def test_transport_ladder_time_budget_stops_further_rungs():
-    out = _ladder(["--sharded-transports", "stub-hang,stub-ok", "--sharded-budget", "20"])
+    out = _ladder(["--sharded-transports", "stub-hang,stub-ok", "--sharded-budget", "15"])
     att = out["sharded"]["attempts"]
     assert att[0]["ok"] is False and "skipped" in att[1] and "error" in out["sharded"]
 
