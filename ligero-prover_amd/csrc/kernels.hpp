@@ -20,13 +20,14 @@ struct Knobs {
     uint32_t sha_block = 256;          // LIG_SHA_BLOCK      workgroup size of the column hash
     int      sha_ws = 2;               // LIG_SHA_WS         column hash: 0 one wave per 64 columns; 1 / 2 / 4 wave-specialised (producer + consumer waves), groups per workgroup
     uint32_t aes_blocks = 0;           // LIG_AES_BLOCKS     persistent workgroups of the big sampler launches (0: two per CU)
-    int      aes_layout = 0;           // LIG_AES_LAYOUT     1: AES tables of the big sampler launches entry-major, a lookup address is one v_perm_b32 (round 6 A/B)
+    int      aes_layout = 1;           // LIG_AES_LAYOUT     1 (default since round 6): AES tables of the big sampler launches entry-major, a lookup address is one v_perm_b32; 0: table-major (rounds 2-5)
     int      sha_gate = 1;             // LIG_SHA_GATE       1: place every chunk's hash before the encode stream goes on; 2: the next chunk's K1 runs first, ALONE (the hash
                                        //                    waits for it), then the hash is placed, then the tile kernel goes on
     size_t   sha_gate_rows = 2;        // LIG_SHA_GATE_ROWS  rows hashed before the encode stream is released
     int      sha_prio = 0;             // LIG_SHA_PRIO       1: the side stream (column hash, samplers) is a high-priority stream
     int      ctx_low_prio_every = 0;   // LIG_CTX_LOW_PRIO_EVERY  n > 0: every n-th context of the process gets lowest-priority streams (a "filler" proof)
     int      sha_cumask = 0;           // LIG_SHA_CUMASK     1: the stage-1 hash of even / odd contexts runs on disjoint halves of the CUs (CU-masked stream)
+    int      gpu_slots = 0;            // LIG_GPU_SLOTS      > 0: at most that many proofs of the process in their GPU-heavy phases per device (prover.hip: GpuSlots)
     size_t   s1_head = 128, s1_tail = 96, s2_head = 192;   // LIG_S1_HEAD / LIG_S1_TAIL / LIG_S2_HEAD  chunk schedule
     bool     fused_rlc = true;         // LIG_NO_FUSED_RLC   (set: the two-kernel sampler / accumulate path of round 2)
     bool     early_code = true;        // LIG_EARLY_CODE=0   accumulate the code test inside the row loop

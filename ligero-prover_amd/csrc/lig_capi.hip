@@ -310,7 +310,7 @@ const lig::Knobs& lig::knobs() {
         { const long v = num("LIG_SHA_WS", 2); t.sha_ws = (v == 0 || v == 1 || v == 4) ? (int)v : 2; }
         t.sha_gate = (int)num("LIG_SHA_GATE", 1);
         { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
-        t.aes_layout = (int)num("LIG_AES_LAYOUT", 0);
+        t.aes_layout = (int)num("LIG_AES_LAYOUT", 1);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
@@ -318,6 +318,7 @@ const lig::Knobs& lig::knobs() {
         t.sha_cumask = (int)num("LIG_SHA_CUMASK", 0);
         t.ctx_low_prio_every = (int)num("LIG_CTX_LOW_PRIO_EVERY", 0);
 #endif
+        t.gpu_slots = (int)num("LIG_GPU_SLOTS", 0);
         t.s1_head = (size_t)num("LIG_S1_HEAD", 128); t.s1_tail = (size_t)num("LIG_S1_TAIL", 96); t.s2_head = (size_t)num("LIG_S2_HEAD", 192);
         t.fused_rlc = std::getenv("LIG_NO_FUSED_RLC") == nullptr;
         t.early_code = num("LIG_EARLY_CODE", 1) != 0;

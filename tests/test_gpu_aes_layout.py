@@ -1,4 +1,4 @@
-"""LIG_AES_LAYOUT=1 (round 6): the sampler's AES tables entry-major in LDS so that a lookup address is one v_perm_b32
+"""LIG_AES_LAYOUT (round 6; 1 = default): the sampler's AES tables entry-major in LDS so that a lookup address is one v_perm_b32
 (csrc/aes.hip).  Same keystream, same field elements (include/util/csprng.hpp:54-107, include/zkp/finite_field_gmp.hpp:66-78): the big
 launches (>= 2^20 elements: persistent workgroups with replicated tables) against the oracle's sampler, a 300-row proof at k = 8192
 against the oracle's prover, configs[2]'s 2^24 pin.  The knob is read once per process: child process."""
@@ -49,10 +49,11 @@ CHILD = textwrap.dedent('''
 ''')
 
 
-def test_entry_major_aes_tables_give_the_same_stream_and_proofs(tmp_path):
+@pytest.mark.parametrize("layout", ["1", "0"])          # 1 = the default since round 6; 0 = the table-major layout of rounds 2-5 (kept as a knob)
+def test_both_aes_table_layouts_give_the_same_stream_and_proofs(tmp_path, layout):
     script = tmp_path / "aes_layout_child.py"
     script.write_text(CHILD)
-    p = subprocess.run([sys.executable, str(script), ROOT], env=dict(os.environ, LIG_AES_LAYOUT="1"), capture_output=True, timeout=900)
+    p = subprocess.run([sys.executable, str(script), ROOT], env=dict(os.environ, LIG_AES_LAYOUT=layout), capture_output=True, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert out and all(v is True for v in out.values()), out
