@@ -27,7 +27,6 @@ struct Knobs {
     int      sha_prio = 0;             // LIG_SHA_PRIO       1: the side stream (column hash, samplers) is a high-priority stream
     int      ctx_low_prio_every = 0;   // LIG_CTX_LOW_PRIO_EVERY  n > 0: every n-th context of the process gets lowest-priority streams (a "filler" proof)
     int      sha_cumask = 0;           // LIG_SHA_CUMASK     1: the stage-1 hash of even / odd contexts runs on disjoint halves of the CUs (CU-masked stream)
-    int      gpu_slots = 0;            // LIG_GPU_SLOTS      > 0: at most that many proofs of the process in their GPU-heavy phases per device (prover.hip: GpuSlots)
     size_t   s1_head = 128, s1_tail = 96, s2_head = 192;   // LIG_S1_HEAD / LIG_S1_TAIL / LIG_S2_HEAD  chunk schedule
     bool     fused_rlc = true;         // LIG_NO_FUSED_RLC   (set: the two-kernel sampler / accumulate path of round 2)
     bool     early_code = true;        // LIG_EARLY_CODE=0   accumulate the code test inside the row loop

@@ -318,7 +318,6 @@ const lig::Knobs& lig::knobs() {
         t.sha_cumask = (int)num("LIG_SHA_CUMASK", 0);
         t.ctx_low_prio_every = (int)num("LIG_CTX_LOW_PRIO_EVERY", 0);
 #endif
-        t.gpu_slots = (int)num("LIG_GPU_SLOTS", 0);
         t.s1_head = (size_t)num("LIG_S1_HEAD", 128); t.s1_tail = (size_t)num("LIG_S1_TAIL", 96); t.s2_head = (size_t)num("LIG_S2_HEAD", 192);
         t.fused_rlc = std::getenv("LIG_NO_FUSED_RLC") == nullptr;
         t.early_code = num("LIG_EARLY_CODE", 1) != 0;

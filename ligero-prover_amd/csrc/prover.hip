@@ -317,55 +317,6 @@ static bool instance_hash_of(const uint8_t* args, const uint64_t* lens, uint64_t
     return true;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// GPU slots (round 6, LIG_GPU_SLOTS = S > 0; default off): at most S proofs of this process are in their GPU-heavy phases on a device at
-// any time.  A proof ends with a host-only tail (the sequential SHA-256 of the stage-2 seed over the accumulators, sampling, the
-// decommitment, the envelope: ~1.3 ms of 2^24 constraints) during which its streams are all but idle.  With two proofs in flight the
-// other proof then has the chip to itself -- at the lone-proof rate, a third below what two proofs get out of it together; a third
-// proof in flight would fill that hole but costs more than it brings while all three are in their heavy phases (workgroup-granular
-// sharing: profiles/r05_issue_timeline.md).  With S = 2 slots and three proofs in flight the third proof starts exactly when one of the
-// two others enters its tail: the slot is taken at the start of stage 1 and given back when the last accumulator of stage 2 has
-// arrived on the host (stage 3 -- one gather and a PCIe-bound copy -- runs without a slot).
-namespace {
-struct GpuSlots {
-    std::mutex mu;
-    std::condition_variable cv;
-    int free = 0;
-    uint64_t next_ticket = 0, serving = 0;       // first come, first served: a proof that waits is not overtaken
-};
-GpuSlots* g_slots[64] = {nullptr};
-std::mutex g_slots_mu;
-GpuSlots* slots_of(int device) {
-    const int S = lig::knobs().gpu_slots;
-    if (S <= 0 || device < 0 || device >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(g_slots_mu);
-    if (!g_slots[device]) { g_slots[device] = new GpuSlots(); g_slots[device]->free = S; }
-    return g_slots[device];
-}
-struct SlotHold {
-    GpuSlots* g = nullptr;
-    bool held = false;
-    explicit SlotHold(int device) : g(slots_of(device)) {}
-    void acquire() {
-        if (!g || held) return;
-        std::unique_lock<std::mutex> lk(g->mu);
-        const uint64_t my = g->next_ticket++;
-        g->cv.wait(lk, [&] { return g->serving == my && g->free > 0; });
-        g->free--; g->serving++;
-        held = true;
-        lk.unlock();
-        g->cv.notify_all();
-    }
-    void release() {
-        if (!g || !held) return;
-        { std::lock_guard<std::mutex> lk(g->mu); g->free++; }
-        held = false;
-        g->cv.notify_all();
-    }
-    ~SlotHold() { release(); }
-};
-}  // namespace
-
 // ================= stage 1: row forming (pads + masks from the encoding stream), encode, column hash, Merkle root
 static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<void(const char*)>& mark) {
     lig_ctx* c = T->c;
@@ -505,7 +456,7 @@ struct RandSource { const fr* dev = nullptr; const uint8_t* host = nullptr; bool
 
 // ================= stage 2 + 3
 static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* const_sum_given, const uint8_t** proof, size_t* proof_len,
-                         lig_proof_info* info, const std::function<void(const char*)>& mark, SlotHold* slot = nullptr) {
+                         lig_proof_info* info, const std::function<void(const char*)>& mark) {
     lig_ctx* c = T->c;
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192;
     const size_t R = T->R;
@@ -703,7 +654,6 @@ static int prove_stage23(lig_trace* T, const RandSource& rs, const uint8_t* cons
         h2.add("LigetronStage2", 15).add(info->root, 32);
         for (int a3 = 0; a3 < 3; a3++) {
             HIP_TRY(c, wait_event(T->ev_acc[a3]));
-            if (a3 == 1 && slot) slot->release();      // the row loop has drained: the host-only tail begins (GPU slots, above)
             h2.add(enc + (size_t)a3 * vec_bytes, vec_bytes);
         }
         h2.finish(info->stage2_seed);
@@ -851,11 +801,9 @@ int lig_synth_prove(lig_trace* T, const uint8_t** proof, size_t* proof_len, lig_
     info->rows = T->R + 3;
     const auto t_begin = clk::now();
     const auto mark = make_mark(c);
-    SlotHold slot(c->device);
-    slot.acquire();
     TRY(prove_stage1(T, info, mark));
     info->ms_stage1 = ms_since(t_begin);
-    TRY(prove_stage23(T, RandSource{}, nullptr, proof, proof_len, info, mark, &slot));
+    TRY(prove_stage23(T, RandSource{}, nullptr, proof, proof_len, info, mark));
     info->ms_total = ms_since(t_begin);
     return LIG_OK;
 }
@@ -1230,8 +1178,6 @@ int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
     {
         if (T->leak) FAIL(c, LIG_E_STATE, "lig_rows_commit: a transfer into this trace's buffers never completed (lig_upload_health): destroy the trace");
         T->up_retry = false;
-        SlotHold slot(c->device);
-        slot.acquire();
         int rc = prove_stage1(T, &T->info1, make_mark(c));
         if (rc != LIG_OK && T->up_retry) {
             // a chunk of the rows did not arrive within LIG_UPLOAD_TIMEOUT_S (the uploader thread has released the streams, stage 1 ran over
@@ -1292,9 +1238,7 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
         rs.dev = T->rands_full; rs.pushed = true;
     }
     for (int attempt = 0;; attempt++) {
-        SlotHold slot(c->device);
-        slot.acquire();
-        int rc = prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c), &slot);
+        int rc = prove_stage23(T, rs, const_sum, proof, proof_len, info, make_mark(c));
         const std::string why = c->err;
         if (rc != LIG_OK) {           // randomness-row copies the uploader thread still holds read the caller's memory: drop them, wait
             T->rands_pushed = 0;
