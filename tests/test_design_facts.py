@@ -55,3 +55,23 @@ def test_the_library_reads_its_environment_in_one_place_and_design_md_lists_ever
     doc = _design()
     missing = [n for n in sorted(names) if n not in doc]
     assert not missing, "knobs not documented in DESIGN.md's appendix: %s" % missing
+
+
+def test_measured_figures_of_design_md_are_the_committed_json():
+    """every speed / traffic figure DESIGN.md states is a row of section 6's generated table (profiles/ file + JSON
+    path); the block is regenerated from the committed files and must be what the document shows -- a figure cannot go stale against the
+    JSON it cites.  Outside the block the document does not restate the headline or the dominant kernel's launch time."""
+    import design_measured_table as t
+    s = _design()
+    have = s[s.index(t.BEGIN) + len(t.BEGIN):s.index(t.END)].strip()
+    want = t.table().strip()
+    assert have == want, "DESIGN.md section 6's measured table is stale: run `python tools/design_measured_table.py --write`"
+    assert len([r for r in have.splitlines() if r.startswith("| ")]) >= 20
+    outside = s[:s.index(t.BEGIN)] + s[s.index(t.END):]
+    # the two figures that went stale in round 5 (headline, K2's in-run launch time) appear in the table only
+    import json
+    with open(os.path.join(ROOT, "profiles", t.BENCH)) as f:
+        line = json.load(f)
+    assert ("%.3f × 10⁹" % (line["value"] / 1e9)) not in outside
+    assert ("%.1f µs" % (line["roofline"]["avg_launch_ms"] * 1e3)) not in outside
+    assert "HIP events of `r05_bench_default.json`" not in s

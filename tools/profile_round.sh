@@ -11,7 +11,7 @@ for n in 1 2; do
     {
         echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-h2d --no-verify --no-sharded-leg --quad-mix 0 --inflight $n   ($n proof(s) in flight; tools/rocpd_summary.py)"
         echo
-        python tools/rocpd_summary.py "$db" "k_encode_tiles<10, true>;k_encode_in<10>;k_rand_rlc<4>;k_encode_tiles<10, false>;k_sha_update_rows"
+        python tools/rocpd_summary.py "$db" "k_encode_tiles<10, true>;k_encode_in<10>;k_rand_rlc<4, 1>;k_encode_tiles<10, false>;k_sha_update_rows"
     } > gpurun_out/prof/inflight${n}_kernel_stats.md
 done
 python bench.py --no-cpu-baseline --no-h2d --quad-mix 0 > gpurun_out/prof/bench_unprofiled.json 2>/dev/null
