@@ -44,6 +44,7 @@ struct lig_ctx {
     size_t small_cap = 0;
     uint32_t* tri_dev = nullptr; size_t tri_cap = 0;
     // optional per-kernel timing (lig_profile_*): HIP events recorded on the ctx stream around the dominant kernel
+    bool streams_shared = false;              // LIG_STREAM_MAP: the three streams are process-wide physical streams, not destroyed with the context
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;

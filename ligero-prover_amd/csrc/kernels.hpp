@@ -48,6 +48,8 @@ struct Knobs {
     int      comm_timeout_s = 300;     // LIG_COMM_TIMEOUT_S  lig_shard_*: seconds the host waits for queued work with collectives before it calls lig_comm.abort
     int      ipc_host_s = 120;         // LIG_IPC_HOST_S     comm_ipc: seconds a rank waits on the host for a peer to reach (publish) the same collective
     int      ipc_stall_s = 120;        // LIG_IPC_STALL_S    comm_ipc watchdog: seconds without any flag changing, once every rank has published the collective, before it is declared dead
+    std::string stream_map;            // LIG_STREAM_MAP     experiment: six digits, the physical stream of [main, side, copy] of even | odd contexts (lig_ctx_create)
+    std::string stream_pad;            // LIG_STREAM_PAD     experiment: "even,odd[,order]" dummy streams before a context's streams / their creation order
     std::string rccl_lib;              // LIG_RCCL_LIB       the librccl to load instead of the one already mapped / found
 };
 const Knobs& knobs();

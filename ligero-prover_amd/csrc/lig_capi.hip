@@ -315,6 +315,8 @@ const lig::Knobs& lig::knobs() {
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
         t.sha_prio = (int)num("LIG_SHA_PRIO", 0);
+        if (const char* v = std::getenv("LIG_STREAM_MAP")) t.stream_map = v;      // round 6: profiles/r06_stream_map_ab.md
+        if (const char* v = std::getenv("LIG_STREAM_PAD")) t.stream_pad = v;
         t.sha_cumask = (int)num("LIG_SHA_CUMASK", 0);
         t.ctx_low_prio_every = (int)num("LIG_CTX_LOW_PRIO_EVERY", 0);
 #endif
@@ -377,7 +379,47 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     const bool low = every > 0 && (ctx_index % (uint32_t)every) == (uint32_t)every - 1;
     int prio_lo = 0, prio_hi = 0;
     if (low) HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    auto make_stream = [&](hipStream_t* st) { return low ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    // EXPERIMENT (LIG_STREAM_MAP, round 6; profiles/r06_stream_map_ab.md): which streams of the proofs in flight share a hardware queue decides
+    // 15 % of the throughput (GPU_MAX_HW_QUEUES sweep) and is an accident of creation order.  The knob makes it explicit: six digits =
+    // the PHYSICAL stream of [main, side, copy] of even contexts, then of odd contexts; physical streams live for the process and are
+    // shared by every context that names them (the runtime must then give each its own queue: GPU_MAX_HW_QUEUES >= their number).
+    static hipStream_t g_phys[64][10] = {};
+    static std::mutex g_phys_mu;
+    const std::string& smap = lig::knobs().stream_map;
+    int role = 0;
+    auto make_stream = [&](hipStream_t* st) -> hipError_t {
+        const int my_role = role++;
+        if (smap.size() == 6 && device >= 0 && device < 64 && !low) {
+            const int idx = smap[(ctx_index & 1u) * 3 + my_role] - '0';
+            if (idx >= 0 && idx < 10) {
+                std::lock_guard<std::mutex> lk(g_phys_mu);
+                if (!g_phys[device][idx]) { const hipError_t e = hipStreamCreateWithFlags(&g_phys[device][idx], hipStreamNonBlocking); if (e != hipSuccess) return e; }
+                *st = g_phys[device][idx];
+                c->streams_shared = true;
+                return hipSuccess;
+            }
+        }
+        return low ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    // EXPERIMENT (LIG_STREAM_PAD = "even,odd[,order]"): dummy streams created (and kept) before the streams of an even / odd context, and
+    // the creation order of {main, side, copy} as a permutation string ("012" = main, side, copy): shifts which streams the runtime's
+    // least-used-queue rule puts together when there are more streams than GPU_MAX_HW_QUEUES
+    hipStream_t* slots3[3] = {&c->stream, &c->stream2, &c->stream3};
+    int order3[3] = {0, 1, 2};
+    {
+        const std::string& pad = lig::knobs().stream_pad;
+        if (!pad.empty()) {
+            int a = 0, b = 0; char ord[8] = "012";
+            std::sscanf(pad.c_str(), "%d,%d,%3s", &a, &b, ord);
+            const int n_pad = (ctx_index & 1u) ? b : a;
+            for (int i = 0; i < n_pad && i < 8; i++) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
+            for (int i = 0; i < 3; i++) if (ord[i] >= '0' && ord[i] <= '2') order3[i] = ord[i] - '0';
+        }
+    }
+    const bool permuted = !(order3[0] == 0 && order3[1] == 1 && order3[2] == 2);
+    if (permuted) {
+        for (int i = 0; i < 3; i++) { role = order3[i]; HIP_TRY(c, make_stream(slots3[order3[i]])); }
+    } else
     HIP_TRY(c, make_stream(&c->stream));
     H::Fr wk, w2k, w4k;
     H::omegas(k, wk, w2k, w4k);
@@ -390,9 +432,10 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
         int lo = 0, hi = 0;
         HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
-    } else
+    } else if (!permuted) {
     HIP_TRY(c, make_stream(&c->stream2));      // side stream: column hash, samplers
-    HIP_TRY(c, make_stream(&c->stream3));      // copy stream
+    }
+    if (!permuted) HIP_TRY(c, make_stream(&c->stream3));      // copy stream
     if (lig::knobs().sha_cumask) {
         // experiment (profiles/r04_sha_cumask_ab.md): with two proofs in flight the hash kernels of both may be placed on the same
         // CUs (two hash waves per SIMD: both chains at half speed); even / odd contexts hash on disjoint halves of the chip
@@ -452,9 +495,11 @@ void lig_ctx_destroy(lig_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream_sha) { (void)hipStreamSynchronize(c->stream_sha); (void)hipStreamDestroy(c->stream_sha); }
-    if (c->stream3) (void)hipStreamDestroy(c->stream3);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (!c->streams_shared) {       // (LIG_STREAM_MAP: the physical streams belong to the process)
+        if (c->stream3) (void)hipStreamDestroy(c->stream3);
+        if (c->stream2) (void)hipStreamDestroy(c->stream2);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 
