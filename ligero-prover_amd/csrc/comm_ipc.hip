@@ -401,7 +401,7 @@ void finalize(IpcComm* r) {
     // a dead communicator: the watchdog keeps the flags poisoned while this rank's streams drain (below), and is stopped after
     if (r->ctx) {
         (void)hipSetDevice(r->ctx->device);
-        (void)hipStreamSynchronize(r->ctx->stream); (void)hipStreamSynchronize(r->ctx->stream2); (void)hipStreamSynchronize(r->ctx->stream3);
+        (void)hipStreamSynchronize(r->ctx->stream); (void)hipStreamSynchronize(r->ctx->stream2); if (r->ctx->stream3) (void)hipStreamSynchronize(r->ctx->stream3);
     }
     for (uint32_t h = 0; h < MAXW; h++) {
         for (const Mapping& m : r->maps[h]) (void)hipIpcCloseMemHandle(m.base);

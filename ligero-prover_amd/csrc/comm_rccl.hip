@@ -145,7 +145,7 @@ void comm_abort(void* user) {
 void finalize(RcclComm* r) {
     if (r->ctx) {
         (void)hipSetDevice(r->ctx->device);
-        (void)hipStreamSynchronize(r->ctx->stream); (void)hipStreamSynchronize(r->ctx->stream2); (void)hipStreamSynchronize(r->ctx->stream3);
+        (void)hipStreamSynchronize(r->ctx->stream); (void)hipStreamSynchronize(r->ctx->stream2); if (r->ctx->stream3) (void)hipStreamSynchronize(r->ctx->stream3);
     }
     if (r->comm) (void)api().CommDestroy(r->comm);
     r->comm = nullptr;

@@ -17,8 +17,10 @@ struct lig_ctx {
     int device = 0;
     uint32_t l = 0, k = 0, n = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // side stream: column hash and samplers, overlapped with the encodes on `stream`
-    hipStream_t stream3 = nullptr;            // copy stream: host rows of lig_rows_begin arrive here under the encodes
+    hipStream_t stream2 = nullptr;            // side stream: column hash and samplers, overlapped with the encodes on `stream`.  ONE per device and process,
+                                              // shared by every context (side_shared; lig_capi.hip: why), unless LIG_SHARED_SIDE=0
+    bool side_shared = false, copy_is_main = false;
+    hipStream_t stream3 = nullptr;            // copy stream (stream-ordered host-row uploads, the sharded prover's exchange): created on first use, lig_internal_copy_stream()
     hipStream_t stream_sha = nullptr;         // experiment (LIG_SHA_CUMASK): a CU-masked stream for the stage-1 column hash; null: stream2
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2
@@ -57,6 +59,12 @@ struct lig_ctx {
     std::mutex debug_mu;
     std::function<std::string()> debug_state;
 };
+// the context's copy stream, created on first use: a context that never uploads through stream-ordered copies (resident witness, the
+// uploader thread) holds two streams, so that two contexts + the null stream fit the runtime's four hardware queues one to one
+inline hipStream_t lig_internal_copy_stream(lig_ctx* c) {
+    if (!c->stream3 && hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->stream3 = c->stream; c->copy_is_main = true; }
+    return c->stream3;
+}
 inline void lig_internal_set_debug_state(lig_ctx* c, std::function<std::string()> f) { std::lock_guard<std::mutex> lk(c->debug_mu); c->debug_state = std::move(f); }
 inline std::string lig_internal_debug_state(lig_ctx* c) { std::lock_guard<std::mutex> lk(c->debug_mu); return c->debug_state ? c->debug_state() : std::string(); }
 

@@ -311,6 +311,7 @@ const lig::Knobs& lig::knobs() {
         t.sha_gate = (int)num("LIG_SHA_GATE", 1);
         { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
         t.aes_layout = (int)num("LIG_AES_LAYOUT", 1);
+        t.shared_side = num("LIG_SHARED_SIDE", 1) != 0;
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
@@ -389,8 +390,11 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
     int role = 0;
     auto make_stream = [&](hipStream_t* st) -> hipError_t {
         const int my_role = role++;
-        if (smap.size() == 6 && device >= 0 && device < 64 && !low) {
-            const int idx = smap[(ctx_index & 1u) * 3 + my_role] - '0';
+        // "a" + groups of FOUR digits: [main, side, copy, hash] -- the stage-1 column hash on a physical stream of its own (c->stream_sha)
+        const bool four = !smap.empty() && smap[0] == 'a';
+        const size_t per = four ? 4 : 3, off0 = four ? 1 : 0;
+        if (smap.size() >= off0 + 2 * per && (smap.size() - off0) % per == 0 && device >= 0 && device < 64 && !low) {       // contexts cycle through the groups
+            const int idx = smap[off0 + (ctx_index % (uint32_t)((smap.size() - off0) / per)) * per + my_role] - '0';
             if (idx >= 0 && idx < 10) {
                 std::lock_guard<std::mutex> lk(g_phys_mu);
                 if (!g_phys[device][idx]) { const hipError_t e = hipStreamCreateWithFlags(&g_phys[device][idx], hipStreamNonBlocking); if (e != hipSuccess) return e; }
@@ -433,9 +437,24 @@ int lig_ctx_create(lig_ctx** out, int device, uint32_t l, uint32_t k, uint32_t n
         HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
     } else if (!permuted) {
-    HIP_TRY(c, make_stream(&c->stream2));      // side stream: column hash, samplers
+        // The side stream (column hash of stage 1, samplers of stage 2) is ONE stream per device for the whole process: with several proofs in
+        // flight NO two side kernels may run next to each other -- not two column hashes, not a hash next to the other proof's sampler.  Measured
+        // (profiles/r06_stream_map_ab.md): side work of the proofs serialised 2.04 x 10^9 constraints/s, on streams of their own 1.75-1.92 x 10^9.
+        // Rounds 2-5 had this by an accident of the runtime (7 streams on 4 hardware queues: the two side streams happened to land in one queue).
+        static hipStream_t g_side[64] = {};
+        static std::mutex g_side_mu;
+        const bool own_side = !lig::knobs().shared_side || low || smap.size() >= 6 || device < 0 || device >= 64;
+        if (own_side) HIP_TRY(c, make_stream(&c->stream2));
+        else {
+            std::lock_guard<std::mutex> lk(g_side_mu);
+            if (!g_side[device]) HIP_TRY(c, hipStreamCreateWithFlags(&g_side[device], hipStreamNonBlocking));
+            c->stream2 = g_side[device];
+            c->side_shared = true;
+        }
     }
-    if (!permuted) HIP_TRY(c, make_stream(&c->stream3));      // copy stream
+    // (the copy stream is created on first use: lig_internal_copy_stream)
+    if (!permuted && smap.size() >= 6) HIP_TRY(c, make_stream(&c->stream3));
+    if (!smap.empty() && smap[0] == 'a') { role = 3; HIP_TRY(c, make_stream(&c->stream_sha)); }
     if (lig::knobs().sha_cumask) {
         // experiment (profiles/r04_sha_cumask_ab.md): with two proofs in flight the hash kernels of both may be placed on the same
         // CUs (two hash waves per SIMD: both chains at half speed); even / odd contexts hash on disjoint halves of the chip
@@ -494,10 +513,10 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream_sha) { (void)hipStreamSynchronize(c->stream_sha); (void)hipStreamDestroy(c->stream_sha); }
+    if (c->stream_sha) { (void)hipStreamSynchronize(c->stream_sha); if (!c->streams_shared) (void)hipStreamDestroy(c->stream_sha); }
     if (!c->streams_shared) {       // (LIG_STREAM_MAP: the physical streams belong to the process)
-        if (c->stream3) (void)hipStreamDestroy(c->stream3);
-        if (c->stream2) (void)hipStreamDestroy(c->stream2);
+        if (c->stream3 && !c->copy_is_main) (void)hipStreamDestroy(c->stream3);
+        if (c->stream2 && !c->side_shared) (void)hipStreamDestroy(c->stream2);      // (the shared side stream lives for the process)
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;

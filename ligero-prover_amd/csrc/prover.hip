@@ -767,7 +767,7 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipSetDevice(T->c->device);
     (void)hipStreamSynchronize(T->c->stream);
     (void)hipStreamSynchronize(T->c->stream2);
-    (void)hipStreamSynchronize(T->c->stream3);
+    if (T->c->stream3) (void)hipStreamSynchronize(T->c->stream3);
     T->up_abort.store(1, std::memory_order_release);      // (copies that wait for a buffer of a proof that never ran)
     uploader_drain(T);                                    // an upload still in flight
     rand_drain(T);
@@ -1001,8 +1001,8 @@ static int rows_copy_by_stream(lig_ctx* c, lig_trace* T, uint8_t* up_dst) {
     for (size_t ci = 0; ci < T->sched1.size(); ci++) {
         const size_t b = T->sched1[ci].first, e = T->sched1[ci].second;
         const size_t off = chunk_src(b), bytes = chunk_src(e) - off;
-        if (bytes) HIP_TRY(c, hipMemcpyAsync(up_dst + off, T->host_msgs + off, bytes, hipMemcpyHostToDevice, c->stream3));
-        HIP_TRY(c, hipEventRecord(T->ev_up[ci], c->stream3));
+        if (bytes) HIP_TRY(c, hipMemcpyAsync(up_dst + off, T->host_msgs + off, bytes, hipMemcpyHostToDevice, lig_internal_copy_stream(c)));
+        HIP_TRY(c, hipEventRecord(T->ev_up[ci], lig_internal_copy_stream(c)));
     }
     HIP_TRY(c, hipGetLastError());
     return LIG_OK;
@@ -1162,7 +1162,7 @@ int lig_rows_restart(lig_trace* T, const void* msgs, int msgs_on_device) {
     if (!T->from_rows) FAIL(c, LIG_E_STATE, "lig_rows_restart: not a rows trace");
     if (T->R && !msgs) FAIL(c, LIG_E_ARG, "lig_rows_restart: null rows");
     if (T->leak) FAIL(c, LIG_E_STATE, "lig_rows_restart: a transfer into this trace's buffers never completed (lig_upload_health): destroy the trace");
-    if (T->loaded && T->host_msgs) { uploader_drain(T); HIP_TRY(c, hipStreamSynchronize(c->stream3)); }      // an upload nobody committed: let it finish first
+    if (T->loaded && T->host_msgs) { uploader_drain(T); if (c->stream3) HIP_TRY(c, hipStreamSynchronize(c->stream3)); }      // an upload nobody committed: let it finish first
     return rows_load(c, T, msgs, msgs_on_device != 0);
 }
 int lig_rows_commit(lig_trace* T, uint8_t root[32], uint8_t stage1_seed[32]) {
@@ -1262,10 +1262,10 @@ int lig_rows_prove(lig_trace* T, const void* rands, int rands_on_device, const u
                 g_uploader[c->device]->retries.fetch_add(1, std::memory_order_relaxed);
                 if (rs.pushed) {
                     for (const UploadJob& j : T->push_log) {
-                        if (j.segs) { for (const UploadSeg& g : *j.segs) { if (!g.bytes) continue; HIP_TRY(c, g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, c->stream3) : hipMemsetAsync(g.dst, 0, g.bytes, c->stream3)); } }
-                        else if (j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, c->stream3));
+                        if (j.segs) { for (const UploadSeg& g : *j.segs) { if (!g.bytes) continue; HIP_TRY(c, g.src ? hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, lig_internal_copy_stream(c)) : hipMemsetAsync(g.dst, 0, g.bytes, lig_internal_copy_stream(c))); } }
+                        else if (j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, lig_internal_copy_stream(c)));
                     }
-                    HIP_TRY(c, hipStreamSynchronize(c->stream3));
+                    if (c->stream3) HIP_TRY(c, hipStreamSynchronize(c->stream3));
                     T->push_sync = true;          // every row is there: stage 2 has no arrival word to wait for
                 }
                 *info = T->info1;
@@ -1311,11 +1311,11 @@ int lig_rows_push_rands_sparse(lig_trace* T, uint64_t first_row, uint64_t n_rows
             uint64_t e = i + 1;
             const bool p = !present || present[i] != 0;
             while (e < n_rows && (!present || (present[e] != 0) == p)) e++;
-            if (p) { HIP_TRY(c, hipMemcpyAsync(dst + i * row_bytes, src, (size_t)(e - i) * row_bytes, hipMemcpyHostToDevice, c->stream3)); src += (e - i) * row_bytes; }
-            else HIP_TRY(c, hipMemsetAsync(dst + i * row_bytes, 0, (size_t)(e - i) * row_bytes, c->stream3));
+            if (p) { HIP_TRY(c, hipMemcpyAsync(dst + i * row_bytes, src, (size_t)(e - i) * row_bytes, hipMemcpyHostToDevice, lig_internal_copy_stream(c))); src += (e - i) * row_bytes; }
+            else HIP_TRY(c, hipMemsetAsync(dst + i * row_bytes, 0, (size_t)(e - i) * row_bytes, lig_internal_copy_stream(c)));
             i = e;
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream3));
+        if (c->stream3) HIP_TRY(c, hipStreamSynchronize(c->stream3));
         T->rands_pushed = first_row + n_rows;
         return LIG_OK;
     }

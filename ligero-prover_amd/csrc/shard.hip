@@ -382,7 +382,7 @@ struct ShardRands { const fr* dev = nullptr; const uint8_t* host = nullptr; };
     lig_ctx* c = S->c; \
     const uint32_t l = c->l, k = c->k, n = c->n, t = 192, pad = k - l, W = S->world; \
     const size_t R = S->R, Rl = S->Rl, RM = S->rows_max, ncol = S->ncol, CAP = S->ch_cap; \
-    hipStream_t s = c->stream, s_hash = c->stream2, s_comm = c->stream3; \
+    hipStream_t s = c->stream, s_hash = c->stream2, s_comm = lig_internal_copy_stream(c); \
     const bool ordered = S->comm.all_to_all_on != nullptr && S->comm.all_gather_on != nullptr; \
     auto comm_fail = [&](const char* what) { if (c->err.find("nccl") == std::string::npos && c->err.find("ipc comm") == std::string::npos && c->err.find("injected fault") == std::string::npos) c->err = std::string("collective failed: ") + what; else c->err = std::string(what) + ": " + c->err; return (int)LIG_E_STATE; }; \
     auto all_gather = [&](const void* src, void* dst, size_t bytes, hipStream_t st, const char* what) -> int { \

@@ -159,7 +159,7 @@ static int verify_core(lig_ctx* c, const std::vector<RowDesc>& rows, const uint8
         return LIG_OK;
     };
     auto dm = [&](void** p, size_t bytes) -> int { return dm0(p, bytes, true); };
-    struct Cleanup { std::vector<void*>& v; lig_ctx* c; uint32_t*& sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
+    struct Cleanup { std::vector<void*>& v; lig_ctx* c; uint32_t*& sha; ~Cleanup() { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2); if (c->stream3) (void)hipStreamSynchronize(c->stream3); c->sha.erase(sha); for (void* p : v) (void)hipFree(p); } };
     Cleanup cleanup{owned, c, dsha};            // constructed before the first allocation: a failing TRY below frees what exists
     const std::vector<uint32_t> triples = quad_terms(rows);
     const size_t NT = triples.size() / 3;
