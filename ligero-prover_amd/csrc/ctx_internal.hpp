@@ -21,6 +21,7 @@ struct lig_ctx {
                                               // shared by every context (side_shared; lig_capi.hip: why), unless LIG_SHARED_SIDE=0
     bool side_shared = false, copy_is_main = false;
     hipStream_t stream3 = nullptr;            // copy stream (stream-ordered host-row uploads, the sharded prover's exchange): created on first use, lig_internal_copy_stream()
+    hipStream_t stream_pipe = nullptr;        // LIG_S1_PIPE: K1 / K3 of the pipelined stage 1 (K2 stays on `stream`); created on first use
     hipStream_t stream_sha = nullptr;         // experiment (LIG_SHA_CUMASK): a CU-masked stream for the stage-1 column hash; null: stream2
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2
@@ -87,7 +88,8 @@ int lig_internal_comm_fault(lig_ctx* c, bool stream_ordered);
 // mode: lig::ENC_FULL (0, rows x n) / ENC_HALF (1, rows x k, coset 2) / ENC_PLANAR (2, rows x 3k, cosets 1..3 as planes) /
 // ENC_ZRES (4, rows x 3k, cosets 1..3 as the tile kernel's Z tiles: no last radix-8 pass; fast encoder only)
 // phases (fast encoder, rows <= one launch group): 1 = K1 only, 14 = everything after K1 (the Y scratch carries the rows in between)
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr, int phases = 15);
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on = nullptr, int phases = 15,
+                             void* y_scratch = nullptr, void* z_scratch = nullptr);      // (own Y / Z scratch of >= rows rows: a caller that pipelines chunks)
 // cw2_z: the rows of cw2 are Z tiles of coset 2 (lig::ENC_ZRES) instead of coset values
 int lig_internal_encode_dot(lig_ctx* c, const void* rands, size_t rows, const void* cw2, size_t cw2_stride, uint32_t group_rows, void* part, hipStream_t on = nullptr,
                             bool cw2_z = false);

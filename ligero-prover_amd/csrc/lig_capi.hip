@@ -312,6 +312,7 @@ const lig::Knobs& lig::knobs() {
         { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
         t.aes_layout = (int)num("LIG_AES_LAYOUT", 1);
         t.shared_side = num("LIG_SHARED_SIDE", 1) != 0;
+        t.s1_pipe = (int)num("LIG_S1_PIPE", 0);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
@@ -513,6 +514,7 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream_pipe) { (void)hipStreamSynchronize(c->stream_pipe); (void)hipStreamDestroy(c->stream_pipe); }
     if (c->stream_sha) { (void)hipStreamSynchronize(c->stream_sha); if (!c->streams_shared) (void)hipStreamDestroy(c->stream_sha); }
     if (!c->streams_shared) {       // (LIG_STREAM_MAP: the physical streams belong to the process)
         if (c->stream3 && !c->copy_is_main) (void)hipStreamDestroy(c->stream3);
@@ -652,7 +654,7 @@ int lig_internal_reserve_scratch(lig_ctx* c, size_t rows) { return c->fast ? ens
 // shared by lig_encode_rows and the batched prover (msgs and out must not overlap).  half = false: out = rows x n
 // codewords.  half = true: out = rows x k, out[q] = P(w_n^(4q + 2)): the odd points of the order-2k subgroup <w_n^2>
 // (its even points are the message row itself, reversed: w_n^4 = w_k^-1).
-int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on, int phases) {
+int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t rows, int mode, hipStream_t on, int phases, void* y_scratch, void* z_scratch) {
     const bool half = mode == lig::ENC_HALF;
     const size_t out_stride = half ? (size_t)c->k : (mode == lig::ENC_PLANAR || mode == lig::ENC_ZRES) ? 3 * (size_t)c->k : (size_t)c->n;
     hipStream_t st = on ? on : c->stream;
@@ -678,8 +680,8 @@ int lig_internal_encode_rows(lig_ctx* c, const void* msgs, void* out, size_t row
                 c->prof_launch_rows[c->prof_used] = (uint32_t)nr;
                 c->prof_used++; c->prof_rows += nr;
             }
-            lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, c->scratch_y,
-                                  c->scratch_z, nr, e0, e1, mode, nullptr, phases);
+            lig::encode_rows_fast(st, c->ep, (const fr*)msgs + r0 * c->k, (fr*)out + r0 * out_stride, y_scratch ? (fr*)y_scratch : c->scratch_y,
+                                  z_scratch ? (fr*)z_scratch : c->scratch_z, nr, e0, e1, mode, nullptr, phases);
         }
     } else if (mode == lig::ENC_PLANAR) {
         // generic path (k > 32768), planar: codewords of a few rows at a time in the Z scratch, then one strided copy per plane
