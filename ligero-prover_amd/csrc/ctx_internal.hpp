@@ -21,7 +21,6 @@ struct lig_ctx {
                                               // shared by every context (side_shared; lig_capi.hip: why), unless LIG_SHARED_SIDE=0
     bool side_shared = false, copy_is_main = false;
     hipStream_t stream3 = nullptr;            // copy stream (stream-ordered host-row uploads, the sharded prover's exchange): created on first use, lig_internal_copy_stream()
-    hipStream_t stream_pipe = nullptr;        // LIG_S1_PIPE: K1 / K3 of the pipelined stage 1 (K2 stays on `stream`); created on first use
     hipStream_t stream_sha = nullptr;         // experiment (LIG_SHA_CUMASK): a CU-masked stream for the stage-1 column hash; null: stream2
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lig::NttPlan plan_half;                   // size 2k, root w_n^2

@@ -312,7 +312,6 @@ const lig::Knobs& lig::knobs() {
         { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
         t.aes_layout = (int)num("LIG_AES_LAYOUT", 1);
         t.shared_side = num("LIG_SHARED_SIDE", 1) != 0;
-        t.s1_pipe = (int)num("LIG_S1_PIPE", 0);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables
@@ -514,7 +513,6 @@ void lig_ctx_destroy(lig_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream_pipe) { (void)hipStreamSynchronize(c->stream_pipe); (void)hipStreamDestroy(c->stream_pipe); }
     if (c->stream_sha) { (void)hipStreamSynchronize(c->stream_sha); if (!c->streams_shared) (void)hipStreamDestroy(c->stream_sha); }
     if (!c->streams_shared) {       // (LIG_STREAM_MAP: the physical streams belong to the process)
         if (c->stream3 && !c->copy_is_main) (void)hipStreamDestroy(c->stream3);

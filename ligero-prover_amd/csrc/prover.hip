@@ -105,8 +105,6 @@ struct lig_trace {
     uint8_t* h_nodes = nullptr;                            // pinned: Merkle nodes
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};   // double-buffered randomness rows
     hipEvent_t ev_gate = nullptr, ev_k1 = nullptr, ev_acc[3] = {nullptr, nullptr, nullptr};
-    fr* pipe_y[2] = {nullptr, nullptr}; fr* pipe_z[2] = {nullptr, nullptr};        // LIG_S1_PIPE: double-buffered Y / Z scratch of the pipelined stage 1
-    hipEvent_t ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr}, ev_p3[2] = {nullptr, nullptr};     // K1 / K2 / K3 of the chunk in buffer i have finished
     uint8_t* h_small = nullptr;                            // pinned: the device-side sum (32 B) | 3 decoded accumulators (3 x n x 32)
 };
 
@@ -292,17 +290,6 @@ static int trace_alloc(lig_ctx* c, lig_trace* T) {
     }
     HIP_TRY(c, hipEventCreateWithFlags(&T->ev_gate, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&T->ev_k1, hipEventDisableTiming));
-    if (lig::knobs().s1_pipe && c->fast) {
-        const size_t pr = R < lig_tune::CHUNK ? (R ? R : 1) : lig_tune::CHUNK;
-        for (int i = 0; i < 2; i++) {
-            TRY(dm((void**)&T->pipe_y[i], pr * (size_t)k * 32));
-            TRY(dm((void**)&T->pipe_z[i], pr * (size_t)n * 32));
-            HIP_TRY(c, hipEventCreateWithFlags(&T->ev_p1[i], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&T->ev_p2[i], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&T->ev_p3[i], hipEventDisableTiming));
-        }
-        if (!c->stream_pipe) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_pipe, hipStreamNonBlocking));
-    }
     for (int a3 = 0; a3 < 3; a3++) HIP_TRY(c, hipEventCreateWithFlags(&T->ev_acc[a3], hipEventDisableTiming));
     if (!T->triples.empty()) HIP_TRY(c, hipMemcpyAsync(T->tri_dev, T->triples.data(), T->triples.size() * 4, hipMemcpyHostToDevice, c->stream));
     {   // a short first chunk (the column hash -- the longest chain of stage 1 -- starts after 128 rows instead of 512) and a short
@@ -398,51 +385,6 @@ static int prove_stage1(lig_trace* T, lig_proof_info* info, const std::function<
         TRY(pre(0, s_enc));
         TRY(lig_internal_encode_rows(c, T->msgs, T->cw, T->sched1[0].second - T->sched1[0].first, enc_mode, s_enc, 1));
     }
-    // LIG_S1_PIPE=1 (round 6): the chunks of stage 1 software-pipelined.  With the proofs in flight taking turns stage by stage (one side
-    // stream per device: DESIGN.md section 2 item 9) a stage runs at its LONE speed, and alone the chunk loop K1 -> K2 -> K3 leaves the
-    // issue slots of the latency-bound radix-8 passes K1 / K3 empty (0.26 + 0.15 ms of a 1.21 ms chunk).  Here K2 stays on the main stream,
-    // chunk after chunk, and a second stream carries K1 of chunk b+1 and K3 of chunk b-1 next to K2 of chunk b (Y / Z scratch double-buffered
-    // in the trace).  The hash placement gate is kept: K2 of chunk b+1 starts when the hash of chunk b has been placed.
-    const bool piped = lig::knobs().s1_pipe && c->fast && !T->zres && gate == 1 && T->pipe_y[0] && c->stream_pipe && T->sched1.size() >= 2;
-    if (piped) {
-        hipStream_t P = c->stream_pipe;
-        const size_t nch = T->sched1.size();
-        HIP_TRY(c, hipEventRecord(c->ev_fork, s));                 // the prologue (keys, pads of resident rows, masks) precedes the first K1
-        HIP_TRY(c, hipStreamWaitEvent(P, c->ev_fork, 0));
-        const size_t g = lig::knobs().sha_gate_rows;
-        auto finish_chunk = [&](size_t cj, bool more) -> int {     // K3 of chunk cj on P, then its hash on the side stream
-            const size_t b = T->sched1[cj].first, nb = T->sched1[cj].second - b;
-            const int j = (int)(cj & 1);
-            HIP_TRY(c, hipStreamWaitEvent(P, T->ev_p2[j], 0));
-            TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, enc_mode, P, 8, T->pipe_y[j], T->pipe_z[j]));
-            HIP_TRY(c, hipEventRecord(T->ev_p3[j], P));
-            HIP_TRY(c, hipStreamWaitEvent(s_sha, T->ev_p3[j], 0));
-            if (nb > 2 * g) {
-                lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, g, absorbed, k, T->msgs + b * k);
-                HIP_TRY(c, hipEventRecord(T->ev_gate, s_sha));
-                lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + (b + g) * k3, 0, nb - g, absorbed + g, k, T->msgs + (b + g) * k);
-                if (more) HIP_TRY(c, hipStreamWaitEvent(s, T->ev_gate, 0));
-            } else lig::launch_sha_update_rows(s_sha, T->sha_state, n, T->cw + b * k3, 0, nb, absorbed, k, T->msgs + b * k);
-            absorbed += nb;
-            return LIG_OK;
-        };
-        for (size_t ci = 0; ci < nch; ci++) {
-            const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
-            const int i = (int)(ci & 1);
-            TRY(pre(ci, P));
-            if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(P, T->ev_p2[i], 0));                       // K2 of chunk ci-2 is done with Y[i]
-            TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, enc_mode, P, 1, T->pipe_y[i], T->pipe_z[i]));
-            HIP_TRY(c, hipEventRecord(T->ev_p1[i], P));
-            if (ci >= 1) TRY(finish_chunk(ci - 1, true));
-            HIP_TRY(c, hipStreamWaitEvent(s, T->ev_p1[i], 0));
-            if (ci >= 2) HIP_TRY(c, hipStreamWaitEvent(s, T->ev_p3[i], 0));                       // K3 of chunk ci-2 is done with Z[i]
-            TRY(lig_internal_encode_rows(c, T->msgs + b * k, T->cw + b * k3, nb, enc_mode, s, 6, T->pipe_y[i], T->pipe_z[i]));
-            HIP_TRY(c, hipEventRecord(T->ev_p2[i], s));
-        }
-        TRY(finish_chunk(nch - 1, false));
-        HIP_TRY(c, hipStreamWaitEvent(s, T->ev_p3[0], 0));         // the codeword planes are complete before anything later on the main stream
-        HIP_TRY(c, hipStreamWaitEvent(s, T->ev_p3[1], 0));
-    } else
     for (size_t ci = 0; ci < T->sched1.size(); ci++) {
         const size_t b = T->sched1[ci].first, nb = T->sched1[ci].second - b;
         if (!k1_ahead) TRY(pre(ci, s_enc));
@@ -826,7 +768,6 @@ void lig_trace_destroy(lig_trace* T) {
     (void)hipStreamSynchronize(T->c->stream);
     (void)hipStreamSynchronize(T->c->stream2);
     if (T->c->stream3) (void)hipStreamSynchronize(T->c->stream3);
-    if (T->c->stream_pipe) (void)hipStreamSynchronize(T->c->stream_pipe);
     T->up_abort.store(1, std::memory_order_release);      // (copies that wait for a buffer of a proof that never ran)
     uploader_drain(T);                                    // an upload still in flight
     rand_drain(T);
@@ -840,10 +781,6 @@ void lig_trace_destroy(lig_trace* T) {
                     (void*)T->coef_dev})
         (void)hipFree(p);
     for (int i = 0; i < 2; i++) { if (T->ev_ready[i]) (void)hipEventDestroy(T->ev_ready[i]); if (T->ev_used[i]) (void)hipEventDestroy(T->ev_used[i]); }
-    for (int i = 0; i < 2; i++) {
-        (void)hipFree(T->pipe_y[i]); (void)hipFree(T->pipe_z[i]);
-        for (hipEvent_t e : {T->ev_p1[i], T->ev_p2[i], T->ev_p3[i]}) if (e) (void)hipEventDestroy(e);
-    }
     if (T->ev_gate) (void)hipEventDestroy(T->ev_gate);
     if (T->ev_k1) (void)hipEventDestroy(T->ev_k1);
     for (int a3 = 0; a3 < 3; a3++) if (T->ev_acc[a3]) (void)hipEventDestroy(T->ev_acc[a3]);
