@@ -34,6 +34,12 @@ import os
 import sys
 import time
 
+# Before the HIP runtime initialises: enough hardware queues for every stream of this process.  The runtime folds the streams of a process
+# onto GPU_MAX_HW_QUEUES (default 4) queues; the library needs a queue of its own for each proof's main stream and for the ONE side
+# stream the proofs share (profiles/r06_stream_map_ab.md: 2.04e9 constraints/s, 1.83e9 when a main stream lands in a shared queue).  At
+# N = 1 that is null + 2 main + side = 4; a rank of an N > 1 run also owns torch's / RCCL's streams.  With the shared side stream 8 queues
+# cost nothing (2.04e9 with 4, 6 and 8).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 L_, K_, N_, T_ = 8000, 8192, 32768, 192
 NO_VERIFY = False
