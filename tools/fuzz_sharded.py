@@ -15,7 +15,7 @@ for i in range(cases):
     n_quad = rng.choice([0, rng.randint(0, 2000), rng.randint(0, 60000)])
     batch = rng.random() < 0.4
     with tempfile.TemporaryDirectory() as d:
-        outs = ts.run_world(pathlib.Path(d), world, 320, 512, 2048, n_lin, n_quad, 29900 + i, batch=batch)
+        outs = ts.run_world(pathlib.Path(d), world, 320, 512, 2048, n_lin, n_quad, batch=batch, comm=rng.choice([None, "ipc"]))
     ok = all(o["again"] and o["all_equal"] for o in outs) and outs[0]["ref_sha"] == outs[0]["sha"]
     print("case %2d W=%d lin %6d quad %6d batch %-5s rows %5d -> %s" % (i, world, n_lin, n_quad, batch, outs[0]["rows"], "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
