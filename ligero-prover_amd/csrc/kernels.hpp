@@ -20,7 +20,6 @@ struct Knobs {
     uint32_t sha_block = 256;          // LIG_SHA_BLOCK      workgroup size of the column hash
     int      sha_ws = 2;               // LIG_SHA_WS         column hash: 0 one wave per 64 columns; 1 / 2 / 4 wave-specialised (producer + consumer waves), groups per workgroup
     uint32_t aes_blocks = 0;           // LIG_AES_BLOCKS     persistent workgroups of the big sampler launches (0: two per CU)
-    int      k1_fold = 0;              // LIG_K1_FOLD        1: K1 (first radix-8 pass of the encoder) folded into the tile kernel's load (round 6)
     bool     shared_side = true;       // LIG_SHARED_SIDE    1: one side stream (column hash, samplers) per device for all contexts of the process; 0: one per context (rounds 1-5)
     int      aes_layout = 1;           // LIG_AES_LAYOUT     1 (default since round 6): AES tables of the big sampler launches entry-major, a lookup address is one v_perm_b32; 0: table-major (rounds 2-5)
     int      sha_gate = 1;             // LIG_SHA_GATE       1: place every chunk's hash before the encode stream goes on; 2: the next chunk's K1 runs first, ALONE (the hash

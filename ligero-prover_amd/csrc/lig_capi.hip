@@ -312,7 +312,6 @@ const lig::Knobs& lig::knobs() {
         { const long v = num("LIG_AES_BLOCKS", 0); t.aes_blocks = v >= 64 && v <= 4096 ? (uint32_t)v : 0u; }
         t.aes_layout = (int)num("LIG_AES_LAYOUT", 1);
         t.shared_side = num("LIG_SHARED_SIDE", 1) != 0;
-        t.k1_fold = (int)num("LIG_K1_FOLD", 0);
         t.sha_gate_rows = (size_t)pos("LIG_SHA_GATE_ROWS", 2);
 #ifdef LIG_EXPERIMENTS      // measured and rejected in round 4 (profiles/r04_sha_priority_ab.md, r04_sha_cumask_ab.md, r04_filler_proof_ab.md): only an
         // A/B build (`make EXPERIMENTS=1`) reads them; the product build ignores the variables

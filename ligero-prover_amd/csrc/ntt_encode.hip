@@ -78,15 +78,9 @@ __global__ void __launch_bounds__(256, LIG_K1_WAVES) k_encode_in(const fr* __res
 #else
 #define LIG_K2_Y_QUAL __restrict__
 #endif
-// FOLD (LIG_K1_FOLD=1, round 6): K1 folded into the tile kernel's load.  `Y` is then the MESSAGE matrix: a workgroup computes output j1 of
-// the radix-8 butterfly over msg[i*B + i2], i < 8, for every position i2 of its tile -- a single output costs 0 (j1 = 0, 4), 1 (j1 = 2, 6)
-// or 3 (odd j1) products with the 8th roots of unity instead of the 5 per 8 outputs of the full butterfly, + the seam twiddle: 2.6
-// products per element against K1's 1.6 (+8k of a row's 215k), and eight times the tile's input through L2 -- for one launch, one HBM round
-// trip (Y) and the latency-bound K1 phase of every chunk less.
-template <int LOG2B, bool FULL, bool FOLD = false>
+template <int LOG2B, bool FULL>
 __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_encode_tiles(const fr* LIG_K2_Y_QUAL Y, fr* LIG_K2_Y_QUAL Z,
-                                                                   const f29wt tw_inv, const f29wt tw_fwd, const f29wt twist, const f29wt seam_fwd,
-                                                                   const f29wt seam_inv = f29wt{}, const f29wt w8_inv = f29wt{}, uint32_t n_rows = 0) {
+                                                                   const f29wt tw_inv, const f29wt tw_fwd, const f29wt twist, const f29wt seam_fwd) {
     constexpr uint32_t B = 1u << LOG2B, T = B / 4, NC = FULL ? 3 : 1;
 #ifdef LIG_K2_CB_GLOBAL
     constexpr bool CBG = FULL;
@@ -98,63 +92,13 @@ __global__ void __launch_bounds__((1 << LOG2B) / 4, FULL ? LIG_K2_WAVES : 4) k_e
     __builtin_amdgcn_s_setprio(LIG_K2_SETPRIO);
 #endif
     const uint32_t t = threadIdx.x;
-    // FOLD: the eight tiles of a row read the SAME 8B message elements, so they should share an L2: workgroups go to the eight XCDs round
-    // robin by their linear id, hence tile j1 of row 8g + x is workgroup 64g + 8 j1 + x -- all eight tiles of a row have id = x (mod 8), and
-    // are dispatched within 64 consecutive ids.  (Workgroup-to-XCD assignment: MI355X_MICROARCH.md.)  Without it the message rows are
-    // fetched by eight L2s: measured 1100 us per 512-row launch against 780.
-    const uint32_t j1 = FOLD ? (blockIdx.x >> 3) & 7u : blockIdx.x & 7u;
-    const size_t row = FOLD ? (size_t)(blockIdx.x >> 6) * 8 + (blockIdx.x & 7u) : blockIdx.x >> 3;
-    if constexpr (FOLD) { if (row >= n_rows) return; }                   // (the grid is rounded up to whole groups of eight rows)
-    const fr* y = Y + (row * 8 + j1) * (size_t)B;
+    const uint32_t j1 = blockIdx.x & 7u;
+    const size_t row = blockIdx.x >> 3;
+    const fr* y = Y + (size_t)blockIdx.x * B;
     f29 x[4], cb[4];
     auto pos = [t](int q) { return __brev(4 * t + q) >> (32 - LOG2B); };
-    if constexpr (FOLD) {
-        const fr* m = Y + row * (size_t)(8u * B);                       // the message row
-        const bool odd = j1 & 1u;
-        const auto WI = tab_get_uniform(w8_inv + 2);                    // w^2: the 4th root of unity
-#pragma unroll 1
-        for (int q = 0; q < 4; q++) {
-            const uint32_t i2 = t + (uint32_t)q * T;                    // natural order: coalesced loads; the bit-reversed entry order of the tile transform comes out of LDS below
-            f29 b[4];
-#pragma unroll
-            for (int mm = 0; mm < 4; mm++) {
-                const f29 lo = unpack29(fr_load(m + (size_t)mm * B + i2)), hi = unpack29(fr_load(m + (size_t)(mm + 4) * B + i2));      // canonical inputs
-                b[mm] = odd ? f29_sub_k2(lo, hi) : f29_add(lo, hi);     // x_m + (-1)^j1 x_(m+4): limbs < 1.5 * 2^30, < 3p
-            }
-            f29 yv;
-            if (odd) {
-                // w^j1 = +-w or +-w^3: y = b0 + s13 c1 b1 + s2 w^2 b2 + s13 c3 b3, (c1, c3) = (w, w^3) for j1 = 1, 5 and (w^3, w) for j1 = 3, 7
-                const bool swp = (j1 & 2u) != 0, n13 = j1 >= 5u, n2 = swp;
-                const f29 p1 = tab_mul(b[1], tab_get_uniform(w8_inv + (swp ? 3 : 1)));
-                const f29 p2 = tab_mul(b[2], WI);
-                const f29 p3 = tab_mul(b[3], tab_get_uniform(w8_inv + (swp ? 1 : 3)));
-                f29 u = f29_qnorm(n13 ? f29_sub_k2(b[0], p1) : f29_add(b[0], p1));                  // < 2.5 * 2^30 before, < 2^29 + 8 after
-                u = n2 ? f29_sub_k2(u, p2) : f29_add(u, p2);
-                u = n13 ? f29_sub_k2(u, p3) : f29_add(u, p3);                                       // limbs < 2.5 * 2^30, value < 12p
-                yv = f29_qnorm(u);
-            } else if (j1 & 2u) {
-                // j1 = 2: y = (b0 - b2) + w^2 (b1 - b3);  j1 = 6: y = (b0 - b2) + w^2 (b3 - b1)
-                const f29 d02 = f29_sub_k4(b[0], b[2]);
-                const f29 d13 = j1 == 2u ? f29_sub_k4(b[1], b[3]) : f29_sub_k4(b[3], b[1]);         // limbs < 2.5 * 2^30, < 6p
-                yv = f29_qnorm(f29_add(d02, tab_mul(d13, WI)));
-            } else {
-                // j1 = 0: the plain sum of the eight inputs (limbs < 2^32); j1 = 4: (b0 - b1) + (b2 - b3), each difference + 4p (limbs < 2.5 * 2^30),
-                // one renormalisation in between so that the sum stays below 2^32
-                if (j1 == 0u) yv = f29_add(f29_add(b[0], b[2]), f29_add(b[1], b[3]));
-                else yv = f29_qnorm(f29_add(f29_qnorm(f29_sub_k4(b[0], b[1])), f29_sub_k4(b[2], b[3])));
-            }
-            if (j1 != 0u) yv = f29_mulw(yv, f29_load_w(seam_inv + (size_t)j1 * B + i2));             // seam twiddle w_k^(-i2*j1): normalised, < 1.0001p
-            else yv = f29_reduce_2p(yv);
-            lds_put(L, i2, yv);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = lds_get(L, pos(q));
-        __syncthreads();                               // every wave has its inputs before the transform's first exchange overwrites the buffer
-    } else {
 #pragma unroll
     for (int q = 0; q < 4; q++) x[q] = unpack29(fr_load(y + pos(q)));
-    }
     tile_dft<LOG2B>(x, tw_inv, L, t);
     fr* const cg = const_cast<fr*>(y);
     if constexpr (CBG) {
@@ -391,21 +335,12 @@ static void encode_rows_t(hipStream_t s, const EncodePlan& ep, const fr* msgs, f
     const int kmask = lig::knobs().encode_kmask & phases;       // 1 = K1, 6 = K2, 8 = K3 (the knob: experiments only; phases: a caller that pipelines K1 ahead)
     // K1 / K3 have no LDS and no barrier: their workgroup size is free (LIG_K13_BLOCK, experiments)
     const uint32_t bs13 = lig::knobs().k13_block;
-    // LIG_K1_FOLD: K1 inside the tile kernel (a caller that splits K1 off keeps the three-launch form; tiles of 4096 elements = 1024 threads
-    // per workgroup leave 128 registers per thread: not enough for the folded kernel)
-    const bool half_mode = mode == 1 || mode == 3;
-    const bool fold = lig::knobs().k1_fold && (lig::knobs().k1_fold != 2 || !half_mode) && (phases & 7) == 7 && LOG2B <= 11;      // 2: the full (three-coset) kernel only
-    if ((kmask & 1) && !fold) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + bs13 - 1) / bs13)), dim3(bs13), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
+    if (kmask & 1) hipLaunchKernelGGL(k_encode_in<LOG2B>, dim3((uint32_t)((th1 + bs13 - 1) / bs13)), dim3(bs13), 0, s, msgs, Y, ep.seam_inv, ep.w8_inv, rows);
     if (ev0) (void)hipEventRecord(ev0, s);
     if (kmask & 6) {
         // LIG_K2_DYN_LDS (experiments): unused dynamic LDS per workgroup, to lower the tile kernel's workgroups per CU below what its
         // registers allow (3) and leave room for the waves of the other stream's kernels
         const uint32_t dyn = lig::knobs().k2_dyn_lds;
-        if (fold) {
-            const uint32_t gridf = (uint32_t)((rows + 7) / 8 * 64);
-            if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false, true>), dim3(gridf), dim3(B / 4), dyn, s, msgs, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd, ep.seam_inv, ep.w8_inv, (uint32_t)rows);
-            else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true, true>), dim3(gridf), dim3(B / 4), dyn, s, msgs, mode == ENC_ZRES ? cw : Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd, ep.seam_inv, ep.w8_inv, (uint32_t)rows);
-        } else
         if (mode == 1 || mode == 3) hipLaunchKernelGGL((k_encode_tiles<LOG2B, false>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
         else hipLaunchKernelGGL((k_encode_tiles<LOG2B, true>), dim3((uint32_t)(rows * 8)), dim3(B / 4), dyn, s, Y, mode == ENC_ZRES ? cw : Z, ep.tw_b_inv, ep.tw_b, ep.twist, ep.seam_fwd);
     }
