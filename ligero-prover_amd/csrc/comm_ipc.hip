@@ -362,6 +362,12 @@ int ag_on(void* user, const void* send, void* recv, size_t bytes, void* stream) 
 // collectives delivered is data or the leftovers of a poisoned wait
 int comm_failed(void* user) {
     IpcComm* r = static_cast<IpcComm*>(user);
+    // A PEER's watchdog may have declared the communicator dead and poisoned the shared flags -- which releases this rank's queued waits too --
+    // a moment before this rank's own watchdog notices the abort word: streams that drained over poisoned waits must not be taken for a
+    // completed collective (round 6: seen once in three runs of the GPU suite with LIG_FAULT_COMM=4).  The abort word is the shared truth.
+    if (!r->dead.load(std::memory_order_acquire) && r->shm) {
+        if (const uint32_t by = r->shm->abort_by.load(std::memory_order_acquire)) declare_dead(r, "rank " + std::to_string(by - 1) + " declared the communicator dead");
+    }
     if (!r->dead.load(std::memory_order_acquire)) return 0;
     if (r->ctx) r->ctx->err = "ipc comm: " + dead_reason(r);
     return 1;
