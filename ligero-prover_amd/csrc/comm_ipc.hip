@@ -308,6 +308,8 @@ int publish(IpcComm* r, const void* send, size_t total_bytes, uint64_t* call, bo
 // what = 0: all-to-all (recv block h <- peer h's send block `me`), 1: all-gather (recv block h <- peer h's send)
 int collective_on(IpcComm* r, int what, const void* send, void* recv, size_t bytes, hipStream_t st) {
     if (!r->shm || !r->ctx) return 1;
+    if (!r->dead.load(std::memory_order_acquire))         // (the shared abort word first: this rank's watchdog may not have seen it yet)
+        if (const uint32_t by = r->shm->abort_by.load(std::memory_order_acquire)) declare_dead(r, "rank " + std::to_string(by - 1) + " declared the communicator dead");
     if (r->dead.load(std::memory_order_acquire)) { r->ctx->err = "ipc comm: " + dead_reason(r); return 1; }
     if (hipSetDevice(r->ctx->device) != hipSuccess) return fail(r, "hipSetDevice");
     const uint32_t W = r->world, me = r->rank;

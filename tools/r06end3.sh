@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the round-end sequence (GPU suite, smoke, default bench) three times on one box -- flakiness check of the final build
 O=gpurun_out/r06end3; mkdir -p $O
-for i in 1 2 3; do
+for i in ${RUNS:-1 2 3}; do
   python -m pytest tests -q -m gpu -x > $O/suite_$i.log 2>&1; echo "run $i suite rc $? $(tail -1 $O/suite_$i.log)" | tee -a $O/summary.txt
   python -c "import __graft_entry__ as g; g.smoke(); print('run $i smoke ok')" 2>&1 | tail -1 | tee -a $O/summary.txt
   python bench.py --gpus 1 2>/dev/null | tail -1 > $O/bench_$i.json
